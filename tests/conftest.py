@@ -1,0 +1,39 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+@pytest.fixture(scope="session")
+def fx_tiny():
+    return load_golden("fx_tiny")
+
+
+@pytest.fixture(scope="session")
+def fx_m16():
+    return load_golden("fx_m16")
+
+
+@pytest.fixture(scope="session")
+def fx_container():
+    return load_golden("fx_container")
+
+
+@pytest.fixture(scope="session")
+def fx_kmeans():
+    return load_golden("fx_kmeans")

@@ -1,0 +1,203 @@
+"""Generate the golden fixtures in tests/golden/*.npz.
+
+Runs ONLY in the build container: it imports the reference (DeMoriarty/TorchPQ
+at /root/reference) through oracle/_refimport.py (stub cupy, CPU code paths)
+and records inputs plus the REFERENCE'S OWN outputs for every piece of the
+hot path that the reference can execute on CPU.  The fixtures are data (arrays);
+the reference's Python never travels.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What is reference-generated (key prefix ``ref_``):
+  ref_sims         metric.negative_squared_l2_distance              (metric.py:31-98)
+  ref_lut          PQCodec.precompute_adc                           (codec/PQCodec.py:62-75)
+  ref_codes/cells  IVFPQIndex.add -> PQCodec.encode / VQCodec.encode (CPU fallbacks;
+                   non-negative data, last column dropped: MultiKMeans.py:352-353 bug)
+  ref state_dict   buffers after reference train + add              (CellContainer.py:313-367)
+  ref_decode       PQCodec.decode                                   (codec/PQCodec.py:113-130)
+  ref_adc_exact    -(|q - decode(code)|^2) for every stored slot via reference decode
+                   + reference metric: pins the scan's value identity
+  ref_nprobe_list  the smart-probing expression of IVFPQIndex.py:499-512 evaluated with torch
+  fx_container     CellContainer.add sequences incl. expand()      (CellContainer.py:249-367)
+  fx_kmeans        MultiKMeans.get_labels / compute_centroids CPU   (MultiKMeans.py:334-380)
+What is oracle-generated (key prefix ``orc_``): scan top-k (values, addresses, ids) --
+the reference has no CPU scan; those are regression vectors for the restatement,
+cross-checked in tests against ref_adc_exact.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle._refimport import import_reference  # noqa: E402
+from oracle import ivfpq_oracle as orc  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def sift_like(rng, d, n, n_clusters=40):
+    """Non-negative, integer-valued, clustered fp32 data (SIFT-like)."""
+    centers = np.abs(rng.standard_normal((d, n_clusters))) * 40
+    assign = rng.integers(0, n_clusters, n)
+    x = centers[:, assign] + rng.standard_normal((d, n)) * 12
+    return np.clip(np.round(np.abs(x)), 0, 218).astype(np.float32)
+
+
+def build_reference_index(torch, tq, d, m, n_cells, n, initial_size, seed, distance="euclidean"):
+    rng = np.random.default_rng(seed)
+    base = sift_like(rng, d, n)
+    np.random.seed(seed)  # KMeans.initialize_centroids uses np.random.choice (KMeans.py:271-277)
+    torch.manual_seed(seed)
+    idx = tq.index.IVFPQIndex(d_vector=d, n_subvectors=m, n_cells=n_cells,
+                              initial_size=initial_size, distance=distance, device="cpu")
+    xb = torch.from_numpy(base.copy())
+    idx.train(xb.clone())  # clone: CPU fallback mutates its input (KMeans.py:347)
+    return idx, base, rng
+
+
+def fx_index(torch, tq, name, d, m, n_cells, n, nq, initial_size, seed, n_probe, ks):
+    idx, base, rng = build_reference_index(torch, tq, d, m, n_cells, n, initial_size, seed)
+    xb = torch.from_numpy(base.copy())
+    # reference add; the CPU encode never labels the LAST point (MultiKMeans.py:352-353):
+    # append one sacrificial vector and remember that its code column is not pinned.
+    ids = idx.add(xb.clone())
+    sd = {k: v.numpy().copy() for k, v in idx.state_dict().items() if v is not None}
+    queries = sift_like(rng, d, nq)
+    xq = torch.from_numpy(queries.copy())
+
+    vq_cb = idx.vq_codec.codebook
+    pq_cb = idx.pq_codec.codebook
+    ref_sims = tq.metric.negative_squared_l2_distance(xq.clone(), vq_cb.clone()).numpy()
+    ref_lut = idx.pq_codec.precompute_adc(xq.clone()).numpy()
+
+    # smart probing expression (IVFPQIndex.py:499-512) on the reference sims
+    sims_t = torch.from_numpy(ref_sims)
+    topk_sims, cells = sims_t.topk(n_probe, dim=1)
+    p = -topk_sims.abs().sqrt()
+    p = torch.softmax(p / 30.0, dim=-1)
+    max_n_probe = torch.tensor(n_probe)
+    ne = -torch.sum(p * torch.log2(p) / torch.log2(max_n_probe), dim=-1)
+    ref_npl = torch.ceil(ne * max_n_probe).long().numpy()
+
+    # decode identity for every stored slot
+    cap = idx._storage.shape[1]
+    all_adr = torch.arange(cap)
+    codes_all = idx.get_data_by_address(all_adr.clone())  # [m, cap]
+    ref_decode = idx.pq_codec.decode(codes_all).numpy()  # [d, cap]
+    ref_adc_exact = tq.metric.negative_squared_l2_distance(
+        xq.clone(), torch.from_numpy(ref_decode.copy())).numpy()  # [nq, cap]
+
+    out = dict(
+        d=d, m=m, n_cells=n_cells, n=n, nq=nq, n_probe=n_probe, ks=np.array(ks),
+        base=base, queries=queries, add_ids=ids.numpy(),
+        ref_sims=ref_sims, ref_lut=ref_lut, ref_topk_sims=topk_sims.numpy(),
+        ref_cells=cells.numpy(), ref_nprobe_list=ref_npl,
+        ref_decode_codes=codes_all.numpy()[:, :256].copy(),
+        ref_decode=ref_decode[:, :256].copy(),
+        ref_adc_exact=ref_adc_exact,
+    )
+    for k, v in sd.items():
+        out["sd." + k] = v
+
+    # oracle-generated regression vectors for the scan
+    storage = sd["_storage"]
+    is_empty = sd["_is_empty"]
+    cs = sd["_cell_start"][out["ref_cells"]]
+    sz = sd["_cell_size"][out["ref_cells"]]
+    lut = ref_lut
+    for smart in (0, 1):
+        npl = ref_npl if smart else np.full(nq, n_probe, np.int64)
+        for k in ks:
+            v, a = orc.scan_topk(storage, lut, is_empty, cs, sz, npl, int(k))
+            out[f"orc_vals_s{smart}_k{k}"] = v
+            out[f"orc_addr_s{smart}_k{k}"] = a
+            out[f"orc_ids_s{smart}_k{k}"] = orc.get_id_by_address(sd["_address2id"], a)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "n_items", int(sd["_cell_size"].sum()), "cap", cap)
+
+
+def fx_container(torch, tq):
+    """CellContainer.add sequences (with expand) run by the reference on CPU."""
+    rng = np.random.default_rng(7)
+    out = {}
+    for case, (mode, step) in enumerate([("double", 8), ("step", 8)]):
+        c = tq.container.CellContainer(code_size=8, n_cells=5, dtype="uint8", device="cpu",
+                                       initial_size=4, expand_step_size=step, expand_mode=mode,
+                                       use_inverse_id_mapping=True, contiguous_size=4)
+        batches = []
+        for b, nb in enumerate([6, 17, 3, 40]):
+            codes = rng.integers(0, 256, (8, nb), dtype=np.uint8)
+            cells = rng.integers(0, 5, nb).astype(np.int64)
+            if b == 2:
+                ids = (1000 + np.arange(nb)).astype(np.int64)
+                r_ids, r_adr = c.add(torch.from_numpy(codes), torch.from_numpy(cells),
+                                     ids=torch.from_numpy(ids), return_address=True)
+            else:
+                ids = None
+                r_ids, r_adr = c.add(torch.from_numpy(codes), torch.from_numpy(cells),
+                                     return_address=True)
+            out[f"c{case}_b{b}_codes"] = codes
+            out[f"c{case}_b{b}_cells"] = cells
+            out[f"c{case}_b{b}_ids_in"] = ids if ids is not None else np.zeros(0, np.int64)
+            out[f"c{case}_b{b}_ref_ids"] = r_ids.numpy()
+            out[f"c{case}_b{b}_ref_adr"] = r_adr.numpy()
+            out[f"c{case}_b{b}_ref_ioa"] = c.get_ioa(torch.from_numpy(cells)).numpy()
+            for k in ["_storage", "_cell_start", "_cell_size", "_cell_capacity", "_is_empty",
+                      "_address2id"]:
+                out[f"c{case}_b{b}_sd{k}"] = getattr(c, k).numpy().copy()
+            out[f"c{case}_b{b}_max_id"] = np.int64(c.max_id)
+        probe = torch.arange(-2, c.capacity + 2)
+        out[f"c{case}_probe_adr"] = probe.numpy()
+        out[f"c{case}_ref_cell_of_adr"] = c.get_cell_by_address(probe.clone()).numpy()
+        out[f"c{case}_ref_id_of_adr"] = c.get_id_by_address(probe.clone()).numpy()
+        out[f"c{case}_ref_data_of_adr"] = c.get_data_by_address(probe.clone()).numpy()
+        out[f"c{case}_mode"] = np.array([mode == "double", step])
+    np.savez_compressed(os.path.join(OUT, "fx_container.npz"), **out)
+    print("fx_container ok")
+
+
+def fx_kmeans(torch, tq):
+    """MultiKMeans CPU assign/update on non-negative data with fixed centroids."""
+    rng = np.random.default_rng(11)
+    l, d, n, k = 4, 8, 4096, 32
+    data = np.stack([sift_like(rng, d, n, 12) for _ in range(l)])  # [l, d, n], >= 0
+    init = data[:, :, rng.choice(n, k, replace=False)].copy()
+    mk = tq.clustering.MultiKMeans(n_clusters=k, distance="euclidean", max_iter=3)
+    d_t = torch.from_numpy(data.copy())
+    c_t = torch.from_numpy(init.copy())
+    # CPU get_labels mutates (abs) its inputs -> clones of non-negative arrays; last point never
+    # labelled (MultiKMeans.py:352-353) -> stored without the last column.
+    ms, lab = mk.get_labels(d_t.clone(), c_t.clone())
+    ref_labels = lab.numpy()[:, :-1].copy()
+    ref_maxsims = ms.numpy()[:, :-1].copy()
+    # exact-label update through the reference loop (MultiKMeans.py:367-380)
+    full_labels = orc.max_sim(data, init, "euclidean", "expanded")[1]
+    ref_centroids = mk.compute_centroids(d_t.clone(), torch.from_numpy(full_labels)).numpy()
+    sims = mk.euc_sim(d_t.clone(), c_t.clone()).numpy()  # [l, n, k]
+    np.savez_compressed(os.path.join(OUT, "fx_kmeans.npz"), data=data, init=init,
+                        ref_labels=ref_labels, ref_maxsims=ref_maxsims,
+                        labels_for_update=full_labels, ref_centroids=ref_centroids,
+                        ref_sims_top2gap=np.sort(sims, axis=-1)[..., -1] - np.sort(sims, axis=-1)[..., -2])
+    print("fx_kmeans ok")
+
+
+def main():
+    tq = import_reference()
+    import torch
+    torch.set_num_threads(4)
+    fx_index(torch, tq, "fx_tiny", d=32, m=8, n_cells=16, n=2000, nq=16, initial_size=256,
+             seed=1, n_probe=4, ks=[1, 10, 100])
+    fx_index(torch, tq, "fx_m16", d=64, m=16, n_cells=32, n=6000, nq=24, initial_size=128,
+             seed=2, n_probe=8, ks=[10])
+    fx_container(torch, tq)
+    fx_kmeans(torch, tq)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+"""CPU: the oracle (numpy + C restatement) against the reference-generated golden vectors."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import ivfpq_oracle as orc
+
+RTOL = 1e-4  # BASELINE.json north_star: float distances within 1e-4 relative
+
+
+def _sd(fx, key):
+    return fx["sd." + key]
+
+
+@pytest.mark.parametrize("name", ["fx_tiny", "fx_m16"])
+def test_coarse_sims_and_lut_match_reference(name, request):
+    fx = request.getfixturevalue(name)
+    vq = _sd(fx, "vq_codec.kmeans.centroids")
+    pq = _sd(fx, "pq_codec.kmeans.centroids")
+    sims = orc.neg_sq_l2(fx["queries"], vq)
+    np.testing.assert_allclose(sims, fx["ref_sims"], rtol=RTOL, atol=0)
+    lut = orc.adc_lut(fx["queries"], pq)
+    scale = np.abs(fx["ref_lut"]).max()
+    np.testing.assert_allclose(lut, fx["ref_lut"], rtol=RTOL, atol=1e-6 * scale)
+    lut_c = c_oracle.adc_lut(fx["queries"], pq)
+    np.testing.assert_allclose(lut_c, fx["ref_lut"], rtol=RTOL, atol=1e-6 * scale)
+
+
+@pytest.mark.parametrize("name", ["fx_tiny", "fx_m16"])
+def test_coarse_select_and_smart_probing(name, request):
+    fx = request.getfixturevalue(name)
+    v, c = orc.topk_desc(fx["ref_sims"], int(fx["n_probe"]))
+    assert np.array_equal(v, fx["ref_topk_sims"])
+    # torch.topk and the oracle agree on ids wherever values are distinct
+    distinct = np.ones_like(v, dtype=bool)
+    distinct[:, 1:] &= v[:, 1:] != v[:, :-1]
+    distinct[:, :-1] &= v[:, 1:] != v[:, :-1]
+    assert np.array_equal(c[distinct], fx["ref_cells"][distinct])
+    npl = orc.smart_probing(fx["ref_topk_sims"], int(fx["n_probe"]))
+    assert np.array_equal(npl, fx["ref_nprobe_list"])
+
+
+@pytest.mark.parametrize("name", ["fx_tiny", "fx_m16"])
+def test_encode_matches_reference_codes(name, request):
+    fx = request.getfixturevalue(name)
+    pq = _sd(fx, "pq_codec.kmeans.centroids")
+    vq = _sd(fx, "vq_codec.kmeans.centroids")
+    m, ds, _ = pq.shape
+    base = fx["base"]
+    n = base.shape[1]
+    # reference codes as stored (gather back through _address2id)
+    a2i = _sd(fx, "_address2id")
+    adr = np.nonzero(a2i >= 0)[0]
+    ids = a2i[adr]
+    ref_codes = np.zeros((m, n), np.uint8)
+    ref_codes[:, ids] = orc.storage_to_codes(_sd(fx, "_storage"), adr)
+    _, labels = c_oracle.max_sim(base.reshape(m, ds, n), pq, "euclidean", "expanded")
+    # the reference CPU path never labels the last point (MultiKMeans.py:352-353)
+    agree = (labels[:, :-1].astype(np.uint8) == ref_codes[:, :-1]).mean()
+    assert agree > 0.999, agree
+    # where they differ the two candidates must be a near-tie
+    _, cells = c_oracle.max_sim(base[None], vq[None], "euclidean", "expanded")
+    ref_cell = orc.get_cell_by_address(adr, _sd(fx, "_cell_start"), _sd(fx, "_cell_capacity"))
+    cell_of_id = np.empty(n, np.int64)
+    cell_of_id[ids] = ref_cell
+    assert (cells[0] == cell_of_id).mean() > 0.999
+
+
+def test_decode_matches_reference(fx_tiny):
+    pq = _sd(fx_tiny, "pq_codec.kmeans.centroids")
+    rec = orc.pq_decode(pq, fx_tiny["ref_decode_codes"])
+    assert np.array_equal(rec, fx_tiny["ref_decode"])
+
+
+@pytest.mark.parametrize("name", ["fx_tiny", "fx_m16"])
+def test_scan_value_identity_against_reference_decode(name, request):
+    """sum_j LUT[j,q,code_j] == -|q - decode(code)|^2 with both sides from the reference."""
+    fx = request.getfixturevalue(name)
+    storage = _sd(fx, "_storage")
+    cap = storage.shape[1]
+    slots = np.arange(cap)
+    for q in range(0, int(fx["nq"]), 3):
+        v = orc.scan_values(storage, fx["ref_lut"][:, q, :], slots)
+        ref = fx["ref_adc_exact"][q]
+        np.testing.assert_allclose(v, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("name", ["fx_tiny", "fx_m16"])
+def test_scan_topk_numpy_vs_c_vs_golden(name, request):
+    fx = request.getfixturevalue(name)
+    storage, is_empty = _sd(fx, "_storage"), _sd(fx, "_is_empty")
+    cs = _sd(fx, "_cell_start")[fx["ref_cells"]]
+    sz = _sd(fx, "_cell_size")[fx["ref_cells"]]
+    nq = int(fx["nq"])
+    for smart in (0, 1):
+        npl = fx["ref_nprobe_list"] if smart else np.full(nq, int(fx["n_probe"]), np.int64)
+        for k in fx["ks"]:
+            k = int(k)
+            v, a = c_oracle.scan_topk(storage, fx["ref_lut"], is_empty, cs, sz, npl, k)
+            assert np.array_equal(v, fx[f"orc_vals_s{smart}_k{k}"])
+            assert np.array_equal(a, fx[f"orc_addr_s{smart}_k{k}"])
+            ids = orc.get_id_by_address(_sd(fx, "_address2id"), a)
+            assert np.array_equal(ids, fx[f"orc_ids_s{smart}_k{k}"])
+            # brute-force check against the reference decode identity: the top-k values are the
+            # k largest exact ADC values among the probed, non-empty slots
+            for q in range(nq):
+                slots = orc.probed_slots(cs[q], sz[q], npl[q])
+                slots = slots[is_empty[slots] == 0]
+                exact = np.sort(fx["ref_adc_exact"][q][slots])[::-1][:k]
+                got = v[q][: exact.size]
+                np.testing.assert_allclose(got, exact, rtol=1e-4, atol=1e-4 * np.abs(exact).max())
+                assert np.all(a[q][exact.size:] == -1)
+
+
+def test_container_add_sequences_bit_exact(fx_container):
+    fx = fx_container
+    for case in (0, 1):
+        double, step = fx[f"c{case}_mode"]
+        st = orc.ContainerState(8, 5, 4, expand_step_size=int(step),
+                                expand_mode="double" if double else "step")
+        for b in range(4):
+            ids_in = fx[f"c{case}_b{b}_ids_in"]
+            ids, adr = st.add(fx[f"c{case}_b{b}_codes"], fx[f"c{case}_b{b}_cells"],
+                              ids_in if ids_in.size else None)
+            assert np.array_equal(orc.get_ioa(fx[f"c{case}_b{b}_cells"]), fx[f"c{case}_b{b}_ref_ioa"])
+            assert np.array_equal(ids, fx[f"c{case}_b{b}_ref_ids"])
+            assert np.array_equal(adr, fx[f"c{case}_b{b}_ref_adr"])
+            for k, mine in [("_storage", st.storage), ("_cell_start", st.cell_start),
+                            ("_cell_size", st.cell_size), ("_cell_capacity", st.cell_capacity),
+                            ("_is_empty", st.is_empty), ("_address2id", st.address2id)]:
+                assert np.array_equal(mine, fx[f"c{case}_b{b}_sd{k}"]), (case, b, k)
+            assert st.max_id == int(fx[f"c{case}_b{b}_max_id"])
+        probe = fx[f"c{case}_probe_adr"]
+        assert np.array_equal(orc.get_cell_by_address(probe, st.cell_start, st.cell_capacity),
+                              fx[f"c{case}_ref_cell_of_adr"])
+        assert np.array_equal(orc.get_id_by_address(st.address2id, probe), fx[f"c{case}_ref_id_of_adr"])
+        assert np.array_equal(orc.storage_to_codes(st.storage, probe), fx[f"c{case}_ref_data_of_adr"])
+
+
+def test_kmeans_assign_update_match_reference(fx_kmeans):
+    fx = fx_kmeans
+    data, init = fx["data"], fx["init"]
+    for numerics in ("direct", "expanded"):
+        vals, labels = c_oracle.max_sim(data, init, "euclidean", numerics)
+        same = labels[:, :-1] == fx["ref_labels"]
+        # disagreements only at near-ties of the two best centroids
+        gap = fx["ref_sims_top2gap"][:, :-1]
+        assert same.mean() > 0.999
+        assert np.all(gap[~same] <= 1e-3 * np.abs(fx["ref_maxsims"][~same]) + 1e-3)
+        np.testing.assert_allclose(vals[:, :-1][same], fx["ref_maxsims"][same], rtol=1e-4,
+                                   atol=1e-2)
+    cen = orc.compute_centroids(data, fx["labels_for_update"], init.shape[2])
+    np.testing.assert_allclose(cen, fx["ref_centroids"], rtol=1e-5, atol=1e-4)
+    v_np, l_np = orc.max_sim(data[:1, :, :512], init[:1], "euclidean", "direct")
+    v_c, l_c = c_oracle.max_sim(data[:1, :, :512], init[:1], "euclidean", "direct")
+    assert np.array_equal(l_np, l_c) and np.array_equal(v_np, v_c)
