@@ -1,0 +1,189 @@
+/* torchpq_amd.h -- C ABI of libtorchpq_amd.so: the MI355X (gfx950) IVFPQ hot path.
+ *
+ * Drop-in boundary for DeMoriarty/TorchPQ's kernel-wrapper layer
+ * (the torchpq/kernels/ xxxCuda.py wrappers).  Every entry point replaces one CuPy RawKernel
+ * wrapper of the reference; the reference file:line each one stands in for is
+ * cited at its declaration (paths relative to the reference repository root).
+ *
+ * Conventions (same contract as the reference wrappers):
+ *   - all pointers are DEVICE pointers owned by the caller (torch's caching
+ *     allocator in the Python host); the library never allocates, frees or
+ *     keeps device memory between calls, and holds no global state;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*;
+ *     NULL = the null stream) and never synchronises;
+ *   - tensors are dense, row-major, in the reference's layouts;
+ *   - return value: TPQ_OK (0) or a negative TPQ_ERR_* code; the message is
+ *     available from tpq_last_error() (thread-local).
+ */
+#ifndef TORCHPQ_AMD_H_
+#define TORCHPQ_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TPQ_VERSION 100 /* 0.1.0 */
+
+#define TPQ_OK 0
+#define TPQ_ERR_INVALID_ARGUMENT (-1)
+#define TPQ_ERR_HIP (-2)
+#define TPQ_ERR_WORKSPACE (-3)
+#define TPQ_ERR_UNSUPPORTED (-4)
+
+/* similarity metrics (values are "larger = closer", as in the reference) */
+#define TPQ_METRIC_NEG_SQ_L2 0 /* "euclidean": -|a-b|^2 */
+#define TPQ_METRIC_INNER 1     /* "cosine"/"inner": a.b (inputs pre-normalised by the host) */
+
+typedef void* tpq_stream_t; /* hipStream_t */
+
+int tpq_version(void);
+const char* tpq_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * a-1 / a-2  IVF list scan + top-k
+ * replaces IVFPQTopkCuda.topk      torchpq/kernels/IVFPQTopkCuda.py:81-142
+ *          IVFPQTop1Cuda.topk      torchpq/kernels/IVFPQTop1Cuda.py:86-140
+ * kernels  ivfpq_topk              torchpq/kernels/cuda/ivfpq_topk.cu:822-971
+ *          ivfpq_top1              torchpq/kernels/cuda/ivfpq_top1.cu:385-455
+ *
+ * codes        u8  [m/4][n_slots][4]   CellContainer._storage (contiguous_size=4)
+ * lut          f32 [m][nq][256]        PQCodec.precompute_adc output
+ * is_empty     u8  [n_slots] or NULL   1 = free/tombstone (NULL: no slot is skipped)
+ * cell_start   i64 [nq][max_nprobe]    _cell_start[cells]
+ * cell_size    i64 [nq][max_nprobe]    _cell_size[cells]
+ * n_probe_list i64 [nq]                cells actually scanned per query (<= max_nprobe)
+ * out_vals     f32 [nq][k]             descending; unfilled = -inf
+ * out_addr     i64 [nq][k]             slot addresses; unfilled = -1
+ * address2id   i64 [n_slots] or NULL   when given, out_ids (i64 [nq][k]) receives
+ * out_ids                               BaseContainer.get_id_by_address(out_addr)
+ *                                       (torchpq/container/BaseContainer.py:58-65)
+ * n_split      workgroups per query (>=1); >1 needs workspace of
+ *              tpq_ivfpq_scan_workspace_bytes(nq, k, n_split)
+ *
+ * value(slot) = 0.f; for j = 0..m-1 ascending: value += lut[j][q][code_j]  (fp32,
+ * the order of consume_data, ivfpq_topk.cu:662-679).  Ordering: value descending,
+ * exact ties by ascending address.  1 <= k <= 1024, m % 4 == 0, m <= 156.
+ * ------------------------------------------------------------------------- */
+size_t tpq_ivfpq_scan_workspace_bytes(int nq, int k, int n_split);
+
+int tpq_ivfpq_scan_topk(const uint8_t* codes, const float* lut, const uint8_t* is_empty,
+                        const int64_t* cell_start, const int64_t* cell_size,
+                        const int64_t* n_probe_list, float* out_vals, int64_t* out_addr,
+                        const int64_t* address2id, int64_t* out_ids, int64_t n_slots, int nq,
+                        int max_nprobe, int m, int k, int n_split, void* workspace,
+                        size_t workspace_bytes, tpq_stream_t stream);
+
+/* MI355X scan layout ("packed"): same bytes as `codes`, permuted per slot so that
+ * the 32 lanes of a half-wave always hit 32 distinct LDS banks.
+ *   packed u8 [m/W][n_slots][W], W = 16 if m%16==0, else 8 if m%8==0, else 4.
+ * tpq_ivfpq_pack_codes (re)builds slots [slot_begin, slot_end) of `packed` from `codes`.
+ * tpq_ivfpq_scan_topk_packed has the contract of tpq_ivfpq_scan_topk (bit-identical
+ * results) but streams `packed`; `codes` is still needed for the exact re-evaluation of
+ * the few candidates that pass the threshold filter. */
+int tpq_ivfpq_pack_codes(const uint8_t* codes, uint8_t* packed, int64_t n_slots, int m,
+                         int64_t slot_begin, int64_t slot_end, tpq_stream_t stream);
+
+int tpq_ivfpq_scan_topk_packed(const uint8_t* packed, const uint8_t* codes, const float* lut,
+                               const uint8_t* is_empty, const int64_t* cell_start,
+                               const int64_t* cell_size, const int64_t* n_probe_list,
+                               float* out_vals, int64_t* out_addr, const int64_t* address2id,
+                               int64_t* out_ids, int64_t n_slots, int nq, int max_nprobe, int m,
+                               int k, int n_split, void* workspace, size_t workspace_bytes,
+                               tpq_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * a-3  ADC look-up table
+ * replaces PQCodec.precompute_adc  torchpq/codec/PQCodec.py:62-75
+ *          (-> MultiKMeans.sim/euc_sim, torchpq/clustering/MultiKMeans.py:184-223)
+ * query f32 [m*ds][nq], codebook f32 [m][ds][256] -> lut f32 [m][nq][256]
+ * NEG_SQ_L2: lut = 2 q.c - |q|^2 - |c|^2 ; INNER: lut = q.c ; every dot/norm is an
+ * ascending-dimension fp32 fma chain (exactly what v_mfma_f32_32x32x2_f32 computes).
+ * ------------------------------------------------------------------------- */
+int tpq_adc_lut(const float* query, const float* codebook, float* lut, int m, int ds, int nq,
+                int metric, tpq_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * a-4  row-wise top-k (coarse probe select)
+ * replaces fn.Topk.__call__        torchpq/fn/Topk.py:43-67
+ *          Top1SelectCuda / Top32SelectCuda / TopkSelectCuda
+ *          (torchpq/kernels/cuda/top1_select.cu:542, top32_select.cu:484-636,
+ *           topk_select.cu:662-805)
+ * x f32 [rows][cols] -> vals f32 [rows][k] descending, idx i64 [rows][k];
+ * ties: smaller column first.  1 <= k <= min(cols, 1024).
+ * ------------------------------------------------------------------------- */
+int tpq_topk_select(const float* x, float* vals, int64_t* idx, int rows, int cols, int k,
+                    tpq_stream_t stream);
+
+/* a-5  smart probing          torchpq/index/IVFPQIndex.py:499-512
+ * topk_sims f32 [rows][n_probe] -> n_probe_list i64 [rows] in [0, n_probe]
+ * p = softmax(-sqrt(|s|)/T); H = -sum(p*log2(p)/log2(n_probe)); out = ceil(H*n_probe) */
+int tpq_smart_probing(const float* topk_sims, int64_t* n_probe_list, int rows, int n_probe,
+                      float temperature, tpq_stream_t stream);
+
+/* a-7  address -> id           torchpq/container/BaseContainer.py:58-65 */
+int tpq_get_id_by_address(const int64_t* address2id, int64_t capacity, const int64_t* address,
+                          int64_t* ids, int64_t n, tpq_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * a-8  k-means assign / PQ encode: batched arg-max similarity
+ * replaces MaxSimCuda.__call__(A, B, dim=2, mode="tn")
+ *          torchpq/kernels/MaxSimCuda.py:184-238,296-340; kernel max_sim_tn
+ *          torchpq/kernels/cuda/max_sim.cu:182-309
+ * A f32 [l][d][m] (data), B f32 [l][d][n] (centroids)
+ *   -> vals f32 [l][m], inds i64 [l][m]  (arg-max over the n centroids)
+ * NEG_SQ_L2: sim = 2 a.b - |a|^2 - |b|^2, INNER: sim = a.b, dots = ascending-d fp32 fma
+ * chains on the fp32 MFMA.  Ties -> smallest centroid index (the reference's cross-block
+ * arg-max is a benign race, max_sim.cu:152-180).
+ * ------------------------------------------------------------------------- */
+int tpq_max_sim(const float* A, const float* B, float* vals, int64_t* inds, int l, int d, int m,
+                int n, int metric, tpq_stream_t stream);
+
+/* a-9  k-means update
+ * replaces ComputeCentroidsCuda.__call__  torchpq/kernels/ComputeCentroidsCuda.py:43-81
+ *          kernel compute_centroids       torchpq/kernels/cuda/compute_centroids.cu:10-86
+ * data f32 [l][d][n], labels i64 [l][n] -> centroids f32 [l][d][k]; empty cluster -> 0.
+ * workspace: tpq_compute_centroids_workspace_bytes(l, d, k) (zeroed by the call). */
+size_t tpq_compute_centroids_workspace_bytes(int l, int d, int k);
+int tpq_compute_centroids(const float* data, const int64_t* labels, float* centroids, int l, int d,
+                          int64_t n, int k, void* workspace, size_t workspace_bytes,
+                          tpq_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * a-12 / a-14  container placement
+ * tpq_get_ioa           replaces GetIOACuda            torchpq/kernels/cuda/get_ioa.cu:9-47
+ *   ioa[i] = number of j < i with labels[j] == labels[i] (input order).
+ *   workspace: tpq_get_ioa_workspace_bytes(n) bytes.
+ * tpq_get_write_address replaces GetWriteAddressV2Cuda torchpq/kernels/cuda/get_write_address_v2.cu:9-41
+ *   the ioa-th empty slot within [cell_start, cell_start+cell_capacity) of the label's cell, -1 if none.
+ * tpq_get_cell_by_address replaces GetDivByAddressV2Cuda torchpq/kernels/cuda/get_div_by_address_v2.cu:9-95
+ *   cell whose [start, start+capacity) contains the address, else -1 (cells ordered by start).
+ * ------------------------------------------------------------------------- */
+size_t tpq_get_ioa_workspace_bytes(int64_t n);
+int tpq_get_ioa(const int64_t* labels, int64_t* ioa, int64_t n, int64_t n_cells, void* workspace,
+                size_t workspace_bytes, tpq_stream_t stream);
+int tpq_get_write_address(const uint8_t* is_empty, const int64_t* cell_start,
+                          const int64_t* cell_capacity, const int64_t* labels, const int64_t* ioa,
+                          int64_t* write_address, int64_t n_slots, int64_t n_labels,
+                          tpq_stream_t stream);
+int tpq_get_cell_by_address(const int64_t* address, const int64_t* cell_start,
+                            const int64_t* cell_capacity, int64_t* cells, int64_t n_address,
+                            int64_t n_cells, tpq_stream_t stream);
+
+/* a-13  PQ decode   replaces PQDecodeCuda  torchpq/kernels/cuda/pq_decode.cu:8-53
+ * codebook f32 [m][ds][256], codes u8 [m][n] -> out f32 [m*ds][n] */
+int tpq_pq_decode(const float* codebook, const uint8_t* codes, float* out, int m, int ds, int64_t n,
+                  tpq_stream_t stream);
+
+/* codes u8 [m][n] scattered into _storage [m/4][n_slots][4] at address[i]
+ * (CellContainer.set_data_by_address, torchpq/container/CellContainer.py:213-239);
+ * when `packed` is non-NULL the scan-layout copy is updated in the same pass. */
+int tpq_scatter_codes(const uint8_t* codes, const int64_t* address, uint8_t* storage,
+                      uint8_t* packed, int m, int64_t n, int64_t n_slots, tpq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TORCHPQ_AMD_H_ */

@@ -1,0 +1,235 @@
+"""GPU: the drop-in IVFPQIndex (train / add / search / remove / state_dict) against the oracle."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import ivfpq_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def _index_from_fixture(fx, **kw):
+    from torchpq_amd.index import IVFPQIndex
+    idx = IVFPQIndex(d_vector=int(fx["d"]), n_subvectors=int(fx["m"]), n_cells=int(fx["n_cells"]),
+                     device=DEV, **kw)
+    sd = {k[3:]: torch.from_numpy(v.copy()) for k, v in fx.items() if k.startswith("sd.")}
+    idx.load_state_dict(sd)  # CPU tensors in, buffers land on the GPU
+    return idx
+
+
+def _expected_search(idx, x, k):
+    """Oracle search driven by the index's own coarse step (cells / n_probe_list), with the LUT in
+    the kernel's arithmetic (ascending-k fma chains == c_oracle.adc_lut): exact equality."""
+    xq = T(x)
+    _, cells, npl = idx.probe(xq)
+    cells, npl = N(cells), N(npl)
+    lut = c_oracle.adc_lut(x, N(idx.pq_codec.codebook), idx.distance)
+    cs, sz = N(idx._cell_start)[cells], N(idx._cell_size)[cells]
+    v, a = c_oracle.scan_topk(N(idx._storage), lut, N(idx._is_empty), cs, sz, npl, k)
+    return v, orc.get_id_by_address(N(idx._address2id), a), cells, npl
+
+
+@pytest.mark.parametrize("name", ["fx_tiny", "fx_m16"])
+@pytest.mark.parametrize("smart", [False, True])
+@pytest.mark.parametrize("packed", [False, True])
+def test_search_on_reference_trained_index(name, smart, packed, request):
+    fx = request.getfixturevalue(name)
+    idx = _index_from_fixture(fx)
+    assert idx.n_items == int(fx["n"]) and idx.max_id == int(fx["n"]) - 1
+    idx.n_probe = int(fx["n_probe"])
+    idx.use_smart_probing = smart
+    idx.use_packed_layout = packed
+    for k in fx["ks"]:
+        k = int(k)
+        v, i = idx.search(T(fx["queries"]), k=k)
+        ev, ei, cells, npl = _expected_search(idx, fx["queries"], k)
+        assert np.array_equal(N(v), ev)
+        assert np.array_equal(N(i), ei)
+        # against the reference-generated vectors: same cells, same ids, values within 1e-4
+        assert np.array_equal(cells, fx["ref_cells"])
+        if smart:
+            assert np.array_equal(npl, fx["ref_nprobe_list"])
+        gv, gi = fx[f"orc_vals_s{int(smart)}_k{k}"], fx[f"orc_ids_s{int(smart)}_k{k}"]
+        fin = np.isfinite(gv)
+        np.testing.assert_allclose(N(v)[fin], gv[fin], rtol=1e-4)
+        assert (N(i) == gi).mean() > 0.995  # LUT rounding may swap exact near-ties
+
+
+def test_train_add_search_end_to_end_recall():
+    from torchpq_amd.index import IVFPQIndex
+    rng = np.random.default_rng(0)
+    d, n, nq = 64, 20000, 200
+    centers = rng.standard_normal((d, 50)) * 4
+    base = (centers[:, rng.integers(0, 50, n)] + rng.standard_normal((d, n))).astype(np.float32)
+    queries = (base[:, rng.choice(n, nq, replace=False)] + 0.05 * rng.standard_normal((d, nq))).astype(np.float32)
+    np.random.seed(0)
+    idx = IVFPQIndex(d_vector=d, n_subvectors=16, n_cells=64, initial_size=64, device=DEV)
+    xb = T(base)
+    before = xb.clone()
+    idx.train(xb)
+    assert torch.equal(xb, before), "train must not mutate its input"
+    ids = idx.add(xb)
+    assert torch.equal(ids, torch.arange(n, device=DEV))
+    assert idx.n_items == n and idx.max_id == n - 1
+    assert int(N(idx._cell_size).sum()) == n
+    # inverted-list invariants
+    st, sz, cap = N(idx._cell_start), N(idx._cell_size), N(idx._cell_capacity)
+    assert np.array_equal(st, np.cumsum(cap) - cap) and np.all(sz <= cap)
+    ie = N(idx._is_empty)
+    for c in range(64):
+        assert np.all(ie[st[c]:st[c] + sz[c]] == 0) and np.all(ie[st[c] + sz[c]:st[c] + cap[c]] == 1)
+    # codes stored == encode(x) and each vector sits in its nearest cell
+    adr = idx.get_address_by_id(ids)
+    assert torch.equal(idx.get_data_by_address(adr), idx.encode(xb))
+    assert torch.equal(idx.get_cell_by_address(adr), idx.vq_codec.encode(xb))
+    _, cells_or = c_oracle.max_sim(base[None], N(idx.vq_codec.codebook)[None], "euclidean", "expanded")
+    assert np.array_equal(N(idx.vq_codec.encode(xb)), cells_or[0])
+
+    idx.n_probe = 16
+    idx.use_smart_probing = False
+    v, i = idx.search(T(queries), k=10)
+    ev, ei, _, _ = _expected_search(idx, queries, 10)
+    assert np.array_equal(N(v), ev) and np.array_equal(N(i), ei)
+    # recall@10 of the true nearest neighbour (exact search on the raw vectors)
+    gt = np.argmin(((queries.T[:, None, :] - base.T[None, :, :]) ** 2).sum(-1), axis=1)
+    recall = np.mean([gt[q] in N(i)[q] for q in range(nq)])
+    assert recall > 0.9, recall
+    # returned values are -|q - decode(code)|^2 of the returned ids
+    recon = N(idx.decode(idx.get_data_by_address(idx.get_address_by_id(i[:, 0].contiguous()))))
+    exact = -((queries - recon) ** 2).sum(0)
+    np.testing.assert_allclose(N(v)[:, 0], exact, rtol=1e-3, atol=1e-3)
+
+
+def test_state_dict_roundtrip_and_growth():
+    from torchpq_amd.index import IVFPQIndex
+    rng = np.random.default_rng(1)
+    d, n = 32, 5000
+    base = np.abs(rng.standard_normal((d, n)) * 20).astype(np.float32)
+    np.random.seed(1)
+    idx = IVFPQIndex(d_vector=d, n_subvectors=8, n_cells=16, initial_size=8, expand_mode="double",
+                     device=DEV)
+    idx.train(T(base))
+    custom = torch.arange(n, device=DEV) * 3 + 11
+    idx.add(T(base[:, :3000]), ids=custom[:3000])      # forces many expansions
+    idx.add(T(base[:, 3000:]), ids=custom[3000:])
+    assert idx.n_items == n and idx.max_id == int(custom.max())
+    idx.n_probe = 4
+    q = T(base[:, :50] + 1.0)
+    v1, i1 = idx.search(q, k=20)
+    buf = io.BytesIO()
+    torch.save(idx.state_dict(), buf)
+    buf.seek(0)
+    sd = torch.load(buf, map_location="cpu")
+    assert set(sd) == {"_address2id", "_storage", "_cell_start", "_cell_size", "_cell_capacity",
+                       "_is_empty", "vq_codec._is_trained", "vq_codec.kmeans.centroids",
+                       "pq_codec._is_trained", "pq_codec.kmeans.centroids"}  # reference keys
+    assert sd["_storage"].shape[0] == 2 and sd["_storage"].shape[2] == 4
+    assert sd["vq_codec.kmeans.centroids"].shape == (d, 16)
+    assert sd["pq_codec.kmeans.centroids"].shape == (8, 4, 256)
+    idx2 = IVFPQIndex(d_vector=d, n_subvectors=8, n_cells=16, device=DEV)
+    idx2.load_state_dict(sd)
+    idx2.n_probe = 4
+    v2, i2 = idx2.search(q, k=20)
+    assert torch.equal(v1, v2) and torch.equal(i1, i2)
+    assert idx2.max_id == idx.max_id and idx2.n_items == n
+    # placement parity with the oracle container for the same codes / cells
+    codes, cells = N(idx.encode(T(base))), N(idx.vq_codec.encode(T(base)))
+    st = orc.ContainerState(8, 16, 8)
+    st.add(codes[:, :3000], cells[:3000], N(custom[:3000]))
+    st.add(codes[:, 3000:], cells[3000:], N(custom[3000:]))
+    assert np.array_equal(N(idx._storage), st.storage)
+    assert np.array_equal(N(idx._address2id), st.address2id)
+    assert np.array_equal(N(idx._is_empty), st.is_empty)
+    assert np.array_equal(N(idx._cell_start), st.cell_start)
+    assert np.array_equal(N(idx._cell_capacity), st.cell_capacity)
+
+
+def test_container_add_sequences_match_reference(fx_container):
+    from torchpq_amd.container import CellContainer
+    fx = fx_container
+    for case in (0, 1):
+        double, step = fx[f"c{case}_mode"]
+        c = CellContainer(code_size=8, n_cells=5, dtype="uint8", device=DEV, initial_size=4,
+                          expand_step_size=int(step), expand_mode="double" if double else "step",
+                          use_inverse_id_mapping=True, contiguous_size=4)
+        for b in range(4):
+            ids_in = fx[f"c{case}_b{b}_ids_in"]
+            ids, adr = c.add(T(fx[f"c{case}_b{b}_codes"]), T(fx[f"c{case}_b{b}_cells"]),
+                             ids=T(ids_in) if ids_in.size else None, return_address=True)
+            assert np.array_equal(N(ids), fx[f"c{case}_b{b}_ref_ids"])
+            assert np.array_equal(N(adr), fx[f"c{case}_b{b}_ref_adr"])
+            for k in ["_storage", "_cell_start", "_cell_size", "_cell_capacity", "_is_empty",
+                      "_address2id"]:
+                assert np.array_equal(N(getattr(c, k)), fx[f"c{case}_b{b}_sd{k}"]), (case, b, k)
+            assert c.max_id == int(fx[f"c{case}_b{b}_max_id"])
+        probe = T(fx[f"c{case}_probe_adr"])
+        assert np.array_equal(N(c.get_cell_by_address(probe)), fx[f"c{case}_ref_cell_of_adr"])
+        assert np.array_equal(N(c.get_id_by_address(probe)), fx[f"c{case}_ref_id_of_adr"])
+        assert np.array_equal(N(c.get_data_by_address(probe)), fx[f"c{case}_ref_data_of_adr"])
+
+
+def test_remove_keeps_cells_dense_and_results_exact(fx_m16):
+    idx = _index_from_fixture(fx_m16)
+    idx.n_probe = int(fx_m16["n_probe"])
+    idx.use_smart_probing = False
+    rng = np.random.default_rng(2)
+    victims = torch.from_numpy(rng.choice(int(fx_m16["n"]), 700, replace=False)).to(DEV)
+    n0 = idx.n_items
+    idx.remove(ids=victims)
+    assert idx.n_items == n0 - 700
+    st, sz, cap, ie = N(idx._cell_start), N(idx._cell_size), N(idx._cell_capacity), N(idx._is_empty)
+    a2i = N(idx._address2id)
+    for c in range(st.size):
+        assert np.all(ie[st[c]:st[c] + sz[c]] == 0) and np.all(ie[st[c] + sz[c]:st[c] + cap[c]] == 1)
+        assert np.all(a2i[st[c] + sz[c]:st[c] + cap[c]] == -1)
+    assert np.all(N(idx.get_address_by_id(victims)) == -1)
+    left = np.setdiff1d(np.arange(int(fx_m16["n"])), N(victims))
+    assert np.array_equal(np.sort(a2i[a2i >= 0]), left)
+    v, i = idx.search(T(fx_m16["queries"]), k=10)
+    ev, ei, _, _ = _expected_search(idx, fx_m16["queries"], 10)
+    assert np.array_equal(N(v), ev) and np.array_equal(N(i), ei)
+    assert not np.isin(N(i), N(victims)).any()
+    # removed ids can be added back and found again
+    back = T(fx_m16["base"][:, N(victims)[:50]])
+    idx.add(back, ids=victims[:50])
+    assert np.all(N(idx.get_address_by_id(victims[:50])) >= 0)
+
+
+def test_api_asserts_and_cosine():
+    from torchpq_amd.index import IVFPQIndex
+    with pytest.raises(AssertionError):
+        IVFPQIndex(d_vector=30, n_subvectors=8, device=DEV)  # d % m != 0
+    with pytest.raises(NotImplementedError):
+        IVFPQIndex(d_vector=32, n_subvectors=8, pq_use_residual=True, device=DEV)
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((32, 3000)).astype(np.float32)
+    np.random.seed(3)
+    idx = IVFPQIndex(d_vector=32, n_subvectors=8, n_cells=8, distance="cosine", device=DEV)
+    with pytest.raises(AssertionError):
+        idx.search(T(base[:, :4]), k=1)  # not trained
+    idx.train(T(base))
+    idx.add(T(base))
+    with pytest.raises(AssertionError):
+        idx.search(T(base[:31, :4]), k=1)
+    with pytest.raises(AssertionError):
+        idx.search(T(base[:, :4]), k=2000)
+    with pytest.raises(AssertionError):
+        idx.vq_codec_max_iter = 3  # already trained
+    idx.n_probe = 8
+    v, i = idx.search(T(base[:, :100]), k=5)
+    assert N(v).max() <= 1.0 + 1e-3 and (N(i)[:, 0] == np.arange(100)).mean() > 0.8
+    xn = base[:, :100] / (np.linalg.norm(base[:, :100], axis=0, keepdims=True) + 1e-9)
+    ev, ei, _, _ = _expected_search(idx, xn.astype(np.float32), 5)
+    np.testing.assert_allclose(N(v), ev, rtol=1e-4, atol=1e-6)

@@ -1,0 +1,329 @@
+"""GPU parity: every C-ABI entry point (through torchpq_amd.kernels) against the oracle.
+
+Bit-exact for integer / byte / index work and for the fp32 values whose summation order the
+reference fixes (scan, LUT, max_sim); fp32 tolerance 1e-4 relative (BASELINE.json) elsewhere.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import ivfpq_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def K():
+    import torchpq_amd.kernels as k
+    from torchpq_amd import _lib
+    _lib.load()  # fail loudly if libtorchpq_amd.so is missing
+    return k
+
+
+def _sd(fx, key):
+    return fx["sd." + key]
+
+
+# ---------------------------------------------------------------------------------------------
+# list scan
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["fx_tiny", "fx_m16"])
+@pytest.mark.parametrize("layout", ["ref", "packed"])
+def test_scan_matches_golden(K, name, layout, request):
+    fx = request.getfixturevalue(name)
+    m = int(fx["m"])
+    scan = K.IVFPQTopkHip(m=m)
+    storage = T(_sd(fx, "_storage"))
+    packed = K.PackCodesHip()(storage) if layout == "packed" else None
+    lut = T(fx["ref_lut"])
+    a2i = T(_sd(fx, "_address2id"))
+    cs = T(_sd(fx, "_cell_start")[fx["ref_cells"]])
+    sz = T(_sd(fx, "_cell_size")[fx["ref_cells"]])
+    nq = int(fx["nq"])
+    for smart in (0, 1):
+        npl = fx["ref_nprobe_list"] if smart else np.full(nq, int(fx["n_probe"]), np.int64)
+        for k in fx["ks"]:
+            k = int(k)
+            for n_split in (1, 3):
+                v, a, i = scan.topk(storage, lut, T(_sd(fx, "_is_empty")), cs, sz, T(npl),
+                                    n_candidates=k, packed=packed, address2id=a2i, n_split=n_split)
+                assert np.array_equal(N(v), fx[f"orc_vals_s{smart}_k{k}"]), (smart, k, n_split)
+                assert np.array_equal(N(a), fx[f"orc_addr_s{smart}_k{k}"]), (smart, k, n_split)
+                assert np.array_equal(N(i), fx[f"orc_ids_s{smart}_k{k}"]), (smart, k, n_split)
+
+
+def _random_index(rng, m, n_cells, mean_size, n_tomb=0, dup_frac=0.0):
+    """Ragged cells (some empty) with slack, random codes; optional tombstones / duplicate codes."""
+    sizes = rng.poisson(mean_size, n_cells).astype(np.int64)
+    sizes[rng.random(n_cells) < 0.1] = 0
+    caps = sizes + rng.integers(0, 9, n_cells)
+    start = np.cumsum(caps) - caps
+    cap = int(caps.sum()) + 5
+    storage = rng.integers(0, 256, (m // 4, cap, 4), dtype=np.uint8)
+    if dup_frac > 0:  # exact ties: copy one code vector over a fraction of the slots
+        dup = rng.random(cap) < dup_frac
+        storage[:, dup, :] = storage[:, :1, :]
+    is_empty = np.ones(cap, np.uint8)
+    for c in range(n_cells):
+        is_empty[start[c]:start[c] + sizes[c]] = 0
+    if n_tomb:
+        occ = np.nonzero(is_empty == 0)[0]
+        is_empty[rng.choice(occ, min(n_tomb, occ.size), replace=False)] = 1
+    a2i = np.where(is_empty == 0, np.arange(cap) * 7 + 3, -1).astype(np.int64)
+    return storage, is_empty, start, sizes, a2i
+
+
+@pytest.mark.parametrize("m,k,n_probe,n_split,layout,tomb,dup", [
+    (8, 1, 4, 1, "ref", 0, 0.0),
+    (8, 10, 6, 2, "packed", 40, 0.0),
+    (16, 64, 8, 1, "packed", 0, 0.3),
+    (16, 100, 8, 5, "ref", 25, 0.2),
+    (32, 128, 16, 1, "packed", 0, 0.0),
+    (64, 100, 12, 1, "packed", 0, 0.0),
+    (64, 100, 12, 4, "ref", 0, 0.05),
+    (64, 200, 12, 2, "packed", 17, 0.0),
+    (64, 1024, 24, 1, "packed", 0, 0.0),
+    (120, 100, 10, 1, "packed", 0, 0.0),
+    (120, 33, 10, 3, "ref", 9, 0.0),
+    (24, 7, 5, 1, "ref", 0, 0.0),      # m without a packed kernel: reference-layout path
+    (12, 300, 9, 2, "ref", 0, 0.1),
+])
+def test_scan_random_vs_oracle(K, m, k, n_probe, n_split, layout, tomb, dup):
+    rng = np.random.default_rng(hash((m, k, n_probe, n_split)) % 2**32)
+    n_cells, nq = 40, 37
+    storage, is_empty, start, sizes, a2i = _random_index(rng, m, n_cells, 150, tomb, dup)
+    lut = (rng.standard_normal((m, nq, 256)) * 100).astype(np.float32)
+    cells = np.stack([rng.permutation(n_cells)[:n_probe] for _ in range(nq)])
+    cells[3, 1] = cells[3, 0]  # repeated cell right after itself: skipped (ivfpq_topk.cu:864-866)
+    npl = rng.integers(0, n_probe + 1, nq).astype(np.int64)
+    npl[:5] = n_probe
+    cs, sz = start[cells], sizes[cells]
+    ev, ea = c_oracle.scan_topk(storage, lut, is_empty, cs, sz, npl, k)
+    eid = orc.get_id_by_address(a2i, ea)
+    scan = K.IVFPQTopkHip(m=m)
+    st = T(storage)
+    packed = K.PackCodesHip()(st) if layout == "packed" else None
+    v, a, i = scan.topk(st, T(lut), T(is_empty), T(cs), T(sz), T(npl), n_candidates=k,
+                        packed=packed, address2id=T(a2i), n_split=n_split)
+    assert np.array_equal(N(v), ev)
+    assert np.array_equal(N(a), ea)
+    assert np.array_equal(N(i), eid)
+    if tomb == 0:  # no tombstones -> is_empty may be omitted
+        v2, a2 = scan.topk(st, T(lut), None, T(cs), T(sz), T(npl), n_candidates=k, packed=packed,
+                           n_split=n_split)
+        assert np.array_equal(N(v2), ev) and np.array_equal(N(a2), ea)
+
+
+def test_scan_empty_and_degenerate(K):
+    rng = np.random.default_rng(5)
+    m = 16
+    storage, is_empty, start, sizes, a2i = _random_index(rng, m, 8, 30)
+    scan = K.IVFPQTopkHip(m=m)
+    lut = T(rng.standard_normal((m, 4, 256)).astype(np.float32))
+    cells = np.tile(np.arange(3), (4, 1))
+    sz = sizes[cells].copy()
+    sz[0] = 0  # query 0 scans nothing
+    npl = np.array([3, 0, 3, 1], np.int64)
+    v, a = scan.topk(T(storage), lut, T(is_empty), T(start[cells]), T(sz), T(npl), n_candidates=5)
+    v, a = N(v), N(a)
+    assert np.all(np.isneginf(v[0])) and np.all(a[0] == -1)
+    assert np.all(np.isneginf(v[1])) and np.all(a[1] == -1)
+    ev, ea = c_oracle.scan_topk(storage, N(lut), is_empty, start[cells], sz, npl, 5)
+    assert np.array_equal(v, ev) and np.array_equal(a, ea)
+    # zero queries
+    v0, a0 = scan.topk(T(storage), lut[:, :0].contiguous(), None, T(start[cells][:0]),
+                       T(sz[:0]), T(npl[:0]), n_candidates=5)
+    assert v0.shape == (0, 5) and a0.shape == (0, 5)
+
+
+def test_scan_argument_errors(K):
+    from torchpq_amd._lib import TorchPQAmdError, load, ptr
+    lib = load()
+    x = torch.zeros(16, device=DEV)
+    rc = lib.tpq_ivfpq_scan_topk(ptr(x), ptr(x), None, ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), None,
+                                 None, 10, 1, 1, 6, 5, 1, None, 0, None)  # m % 4 != 0
+    assert rc == -1 and b"multiple of 4" in lib.tpq_last_error()
+    rc = lib.tpq_ivfpq_scan_topk(ptr(x), ptr(x), None, ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), None,
+                                 None, 10, 1, 1, 8, 2000, 1, None, 0, None)  # k > 1024
+    assert rc == -1
+    rc = lib.tpq_ivfpq_scan_topk(ptr(x), ptr(x), None, ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), None,
+                                 None, 10, 1, 1, 8, 5, 4, None, 0, None)  # split without workspace
+    assert rc == -3
+    with pytest.raises(TorchPQAmdError):
+        K.IVFPQTopkHip(m=8).topk(torch.zeros(2, 4, 4, dtype=torch.uint8), torch.zeros(8, 1, 256),
+                                 None, torch.zeros(1, 1, dtype=torch.long),
+                                 torch.zeros(1, 1, dtype=torch.long),
+                                 torch.zeros(1, dtype=torch.long), n_candidates=1)  # CPU tensors
+
+
+def test_pack_is_a_per_slot_permutation(K):
+    rng = np.random.default_rng(9)
+    for m in (8, 16, 24, 64, 120):
+        storage = rng.integers(0, 256, (m // 4, 300, 4), dtype=np.uint8)
+        packed = N(K.PackCodesHip()(T(storage)))
+        w = packed.shape[2]
+        codes = storage.transpose(0, 2, 1).reshape(m, 300)         # [m, slot]
+        pk = packed.transpose(0, 2, 1).reshape(m, 300)             # [position, slot]
+        assert np.array_equal(np.sort(codes, axis=0), np.sort(pk, axis=0))
+        assert w == (16 if m % 16 == 0 else 8 if m % 8 == 0 else 4)
+
+
+# ---------------------------------------------------------------------------------------------
+# LUT, select, smart probing
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,ds,nq", [(8, 4, 16), (64, 2, 100), (120, 8, 33), (16, 1, 5), (4, 7, 70)])
+@pytest.mark.parametrize("distance", ["euclidean", "cosine"])
+def test_adc_lut_bit_exact_vs_c_oracle(K, m, ds, nq, distance):
+    rng = np.random.default_rng(m * 100 + ds)
+    cb = (rng.standard_normal((m, ds, 256)) * 30).astype(np.float32)
+    q = (rng.standard_normal((m * ds, nq)) * 30).astype(np.float32)
+    got = N(K.AdcLutHip()(T(q), T(cb), distance))
+    exp = c_oracle.adc_lut(q, cb, distance)
+    assert np.array_equal(got, exp)
+    ref_formula = orc.adc_lut(q, cb, distance)  # reference formula, BLAS summation order
+    np.testing.assert_allclose(got, ref_formula, rtol=1e-4, atol=1e-4 * np.abs(ref_formula).max())
+
+
+def test_adc_lut_matches_reference_golden(K, fx_tiny, fx_m16):
+    for fx in (fx_tiny, fx_m16):
+        got = N(K.AdcLutHip()(T(fx["queries"]), T(_sd(fx, "pq_codec.kmeans.centroids"))))
+        ref = fx["ref_lut"]
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-6 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("rows,cols,k", [(5, 7, 1), (33, 1024, 32), (10, 300, 64), (9, 1000, 100),
+                                         (4, 16384, 64), (3, 70, 70), (2, 5000, 1024), (17, 64, 8)])
+def test_topk_select_exact(K, rows, cols, k):
+    rng = np.random.default_rng(rows * cols + k)
+    x = rng.standard_normal((rows, cols)).astype(np.float32)
+    x[:, ::3] = np.round(x[:, ::3], 1)  # plenty of exact ties
+    v, i = K.TopkSelectHip()(T(x), k=k)
+    ev, ei = orc.topk_desc(x, k)
+    assert np.array_equal(N(v), ev)
+    assert np.array_equal(N(i), ei)
+
+
+def test_topk_select_matches_reference_golden(K, fx_m16):
+    v, i = K.TopkSelectHip()(T(fx_m16["ref_sims"]), k=int(fx_m16["n_probe"]))
+    assert np.array_equal(N(v), fx_m16["ref_topk_sims"])
+    assert np.array_equal(N(i), fx_m16["ref_cells"])  # no ties in this fixture
+
+
+def test_smart_probing(K, fx_tiny, fx_m16):
+    for fx in (fx_tiny, fx_m16):
+        got = N(K.SmartProbingHip()(T(fx["ref_topk_sims"]), 30.0))
+        assert np.array_equal(got, fx["ref_nprobe_list"])
+    rng = np.random.default_rng(0)
+    s = -np.abs(rng.standard_normal((500, 32)).astype(np.float32)) * 5e4
+    s = -np.sort(-s, axis=1)
+    got = N(K.SmartProbingHip()(T(s), 30.0))
+    exp = orc.smart_probing(s, 32, 30.0)
+    # ceil() of an fp32 entropy: a last-ulp difference in exp/log2 can flip a value sitting
+    # exactly on an integer; allow |diff| <= 1 on < 0.5 % of the rows
+    assert np.abs(got - exp).max() <= 1 and (got != exp).mean() < 0.005
+    assert got.min() >= 1 and got.max() <= 32
+
+
+# ---------------------------------------------------------------------------------------------
+# k-means kernels
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("l,d,m,n", [(1, 128, 300, 64), (3, 2, 1000, 256), (2, 8, 257, 256),
+                                     (1, 33, 129, 300), (4, 7, 64, 5), (1, 64, 500, 1024)])
+@pytest.mark.parametrize("distance", ["euclidean", "inner"])
+def test_max_sim_bit_exact_vs_c_oracle(K, l, d, m, n, distance):
+    rng = np.random.default_rng(l * 1000 + d * 10 + n)
+    A = (rng.standard_normal((l, d, m)) * 10).astype(np.float32)
+    B = (rng.standard_normal((l, d, n)) * 10).astype(np.float32)
+    B[:, :, n // 2] = B[:, :, 0]  # duplicate centroid: tie -> smallest index
+    v, i = K.MaxSimHip(distance=distance)(T(A), T(B), dim=2, mode="tn")
+    ev, ei = c_oracle.max_sim(A, B, distance, "expanded")
+    assert np.array_equal(N(i), ei)
+    assert np.array_equal(N(v), ev)
+    if l == 1:  # 2-D call form used by KMeans
+        v2, i2 = K.MaxSimHip(distance=distance)(T(A[0]), T(B[0]), dim=1, mode="tn")
+        assert np.array_equal(N(i2), ei[0]) and np.array_equal(N(v2), ev[0])
+
+
+def test_max_sim_and_centroids_match_reference_golden(K, fx_kmeans):
+    fx = fx_kmeans
+    v, lab = K.MaxSimHip()(T(fx["data"]), T(fx["init"]), dim=2, mode="tn")
+    lab, v = N(lab), N(v)
+    same = lab[:, :-1] == fx["ref_labels"]
+    assert same.mean() > 0.999
+    gap = fx["ref_sims_top2gap"][:, :-1]
+    assert np.all(gap[~same] <= 1e-3 * np.abs(fx["ref_maxsims"][~same]) + 1e-3)
+    np.testing.assert_allclose(v[:, :-1][same], fx["ref_maxsims"][same], rtol=1e-4, atol=1e-2)
+    cen = N(K.ComputeCentroidsHip()(T(fx["data"]), T(fx["labels_for_update"]), k=fx["init"].shape[2]))
+    np.testing.assert_allclose(cen, fx["ref_centroids"], rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("l,d,n,k", [(1, 5, 1000, 7), (3, 40, 9000, 256), (2, 17, 100, 1024)])
+def test_compute_centroids(K, l, d, n, k):
+    rng = np.random.default_rng(n + k)
+    data = rng.standard_normal((l, d, n)).astype(np.float32)
+    labels = rng.integers(0, max(1, k - 2), (l, n)).astype(np.int64)  # last clusters stay empty
+    got = N(K.ComputeCentroidsHip()(T(data), T(labels), k=k))
+    exp = orc.compute_centroids(data, labels, k)
+    np.testing.assert_allclose(got, exp, rtol=1e-5, atol=1e-5)
+    assert np.all(got[:, :, k - 1] == 0)  # empty cluster -> 0 (compute_centroids.cu:82)
+
+
+# ---------------------------------------------------------------------------------------------
+# container helpers
+# ---------------------------------------------------------------------------------------------
+def test_get_ioa(K):
+    rng = np.random.default_rng(3)
+    for n, n_cells in [(1, 4), (1000, 5), (50000, 1024), (4097, 16384)]:
+        cells = rng.integers(0, n_cells, n).astype(np.int64)
+        got = N(K.GetIOAHip()(T(cells), n_cells=n_cells))
+        assert np.array_equal(got, orc.get_ioa(cells))
+
+
+def test_get_write_address_and_cell_by_address(K):
+    rng = np.random.default_rng(4)
+    n_cells = 9
+    cap = rng.integers(0, 200, n_cells).astype(np.int64)
+    cap[2] = 0
+    start = np.cumsum(cap) - cap
+    total = int(cap.sum())
+    is_empty = (rng.random(total) < 0.6).astype(np.uint8)
+    cells = rng.integers(0, n_cells, 400).astype(np.int64)
+    ioa = orc.get_ioa(cells)
+    got = N(K.GetWriteAddressHip()(T(is_empty), T(start), T(cap), T(cells), T(ioa)))
+    assert np.array_equal(got, orc.get_write_address(is_empty, start, cap, cells, ioa))
+    adr = np.arange(-3, total + 3).astype(np.int64)
+    got = N(K.GetCellByAddressHip()(T(adr), T(start), T(start + cap)))
+    assert np.array_equal(got, orc.get_cell_by_address(adr, start, cap))
+
+
+def test_pq_decode_and_scatter(K, fx_tiny):
+    cb = _sd(fx_tiny, "pq_codec.kmeans.centroids")
+    got = N(K.PQDecodeHip()(T(cb), T(fx_tiny["ref_decode_codes"])))
+    assert np.array_equal(got, fx_tiny["ref_decode"])
+    rng = np.random.default_rng(8)
+    m, cap, n = 16, 500, 120
+    storage = np.zeros((m // 4, cap, 4), np.uint8)
+    codes = rng.integers(0, 256, (m, n), dtype=np.uint8)
+    adr = rng.choice(cap, n, replace=False).astype(np.int64)
+    adr[5] = -1
+    adr[6] = cap + 4
+    st = T(storage)
+    pk = K.PackCodesHip()(st)
+    K.ScatterCodesHip()(T(codes), T(adr), st, pk)
+    orc.codes_to_storage(codes, adr, storage)
+    assert np.array_equal(N(st), storage)
+    assert np.array_equal(N(pk), N(K.PackCodesHip()(st)))  # incremental == rebuilt
+    a2i = rng.integers(-1, 50, cap).astype(np.int64)
+    probe = rng.integers(-5, cap + 5, (7, 9)).astype(np.int64)
+    assert np.array_equal(N(K.GetIdByAddressHip()(T(a2i), T(probe))), orc.get_id_by_address(a2i, probe))

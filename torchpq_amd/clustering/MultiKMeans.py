@@ -1,0 +1,145 @@
+"""Batched Lloyd k-means on the GPU (mirrors torchpq/clustering/MultiKMeans.py:13-496).
+
+Assign = tpq_max_sim (fp32 MFMA), update = tpq_compute_centroids; the Python below is only
+the Lloyd driver of the reference (fit :415-453, initialize_centroids :270-289).
+"""
+from time import time
+
+import numpy as np
+import torch
+
+from .. import metric
+from ..CustomModule import CustomModule
+from ..kernels import ComputeCentroidsHip, MaxSimHip
+
+
+class MultiKMeans(CustomModule):
+    """Run ``l`` independent k-means problems in parallel.
+
+    data: [l, d_vector, n_data]; centroids: [l, d_vector, n_clusters]
+    distance: 'euclidean' | 'cosine' | 'inner'
+    """
+
+    def __init__(self, n_clusters, n_redo=1, max_iter=100, tol=1e-4, distance="euclidean",
+                 init_mode="random", verbose=0, sm_size=None):
+        super().__init__()
+        assert distance in ("euclidean", "cosine", "inner"), \
+            "only euclidean / cosine / inner have a kernel branch (MultiKMeans.py:82-113)"
+        assert init_mode in ("random", "kmeans++")
+        self.n_redo = n_redo
+        self.n_clusters = n_clusters
+        self.max_iter = max_iter
+        self.tol = tol
+        self.verbose = verbose
+        self.distance = distance
+        self.init_mode = init_mode
+        self.register_buffer("centroids", None)
+        self.max_sim_hip = MaxSimHip(dim=2, distance=distance)
+        self.compute_centroids_hip = ComputeCentroidsHip()
+
+    # -- similarity helpers (reference: cos_sim :155-181, euc_sim :184-209, sim :211-223) ------
+    @staticmethod
+    def calculate_error(a, b):
+        return (a - b).pow(2).sum()
+
+    @staticmethod
+    def calculate_inertia(a):
+        return (-a).mean()
+
+    @staticmethod
+    def cos_sim(a, b, normalize=True, inplace=False):
+        return metric.cosine_similarity(a, b, normalize=normalize)
+
+    @staticmethod
+    def euc_sim(a, b, inplace=False):
+        return metric.negative_squared_l2_distance(a, b)
+
+    def sim(self, a, b, inplace=False, normalize=True):
+        """[l, d, m] x [l, d, n] -> [l, m, n]; never mutates its inputs (the reference's
+        inplace=True path replaces data by |data|, KMeans.py:194-207)."""
+        if self.distance == "euclidean":
+            return self.euc_sim(a, b)
+        if self.distance == "cosine":
+            return self.cos_sim(a, b, normalize=normalize)
+        return self.cos_sim(a, b, normalize=False)
+
+    # -- Lloyd pieces ---------------------------------------------------------------------------
+    def initialize_centroids(self, data):
+        """random: the same np.random.choice index set for every sub-problem (:277-283)."""
+        l, d, n = data.shape
+        if self.init_mode == "random":
+            index = np.random.choice(n, size=[self.n_clusters], replace=False)
+            index = torch.from_numpy(index).to(data.device)
+            centroids = data[:, :, index].clone()
+        else:
+            centroids = self.kmeanspp(data)
+        return centroids
+
+    def kmeanspp(self, data):
+        """Farthest-point seeding as in the reference (:225-268): the next centroid is the point
+        with the smallest maximum similarity to the centroids chosen so far."""
+        l, d, n = data.shape
+        centroids = torch.zeros(l, d, self.n_clusters, device=data.device, dtype=data.dtype)
+        centroids[:, :, 0] = data[:, :, np.random.randint(n)]
+        arange = torch.arange(l, device=data.device)
+        for i in range(1, self.n_clusters):
+            vals, _ = self.get_labels(data, centroids[:, :, :i].contiguous())
+            index = vals.argmin(dim=-1)
+            centroids[:, :, i] = data[arange, :, index]
+        return centroids
+
+    def get_labels(self, data, centroids):
+        """(max_sims [l, n], labels [l, n] int64)"""
+        if self.distance == "cosine":
+            data = data / (data.norm(dim=-2, keepdim=True) + 1e-8)
+            centroids = centroids / (centroids.norm(dim=-2, keepdim=True) + 1e-8)
+        return self.max_sim_hip(data, centroids, dim=2, mode="tn")
+
+    def compute_centroids(self, data, labels):
+        return self.compute_centroids_hip(data, labels, k=self.n_clusters)
+
+    def fit(self, data, centroids=None):
+        """Lloyd iterations; returns labels [l, n_data] of the best redo."""
+        assert data.is_contiguous(), "use .contiguous()"
+        best = None
+        tm = time()
+        for i in range(self.n_redo):
+            if centroids is None:
+                centroids = self.initialize_centroids(data)
+            labels = maxsims = error = None
+            for j in range(self.max_iter):
+                maxsims, labels = self.get_labels(data, centroids)
+                new_centroids = self.compute_centroids(data, labels)
+                error = self.calculate_error(centroids, new_centroids)
+                centroids = new_centroids
+                if self.verbose >= 3:
+                    self.print_message(
+                        f"----iteration {j} of {i}th redo, error={error.item()}, "
+                        f"inertia={self.calculate_inertia(maxsims).item()}", 3)
+                if error <= self.tol:  # one host sync per iteration, as in the reference (:437)
+                    break
+            inertia = self.calculate_inertia(maxsims)
+            if best is None or inertia < best[0]:
+                best = (inertia, centroids, labels)
+            centroids = None
+        self.register_buffer("centroids", best[1])
+        self.print_message(
+            f"finished {self.n_redo} redos in {round(time() - tm, 4)} sec, final_inertia: {best[0]}", 1)
+        return best[2]
+
+    def predict(self, query):
+        assert self.centroids is not None, "kmeans is not trained"
+        return self.get_labels(query, self.centroids)[1]
+
+    def topk(self, query, k=128):
+        """top-k closest centroids per query (:467-496): GEMM + row select."""
+        assert self.centroids is not None, "kmeans is not trained"
+        assert k <= self.n_clusters, "k is larger than number of clusters"
+        if k == 1:
+            v, i = self.get_labels(query, self.centroids)
+            return v[..., None], i[..., None]
+        from ..fn import Topk
+        sims = self.sim(query, self.centroids)
+        l, m, n = sims.shape
+        v, i = Topk()(sims.reshape(l * m, n).contiguous(), k=k, dim=1)
+        return v.reshape(l, m, k), i.reshape(l, m, k)

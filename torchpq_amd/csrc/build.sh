@@ -1,0 +1,22 @@
+#!/bin/bash
+# Builds libtorchpq_amd.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="${HERE}/../libtorchpq_amd.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math
+       -Wall -Wno-unused-function -DNDEBUG)
+mkdir -p "${HERE}/build"
+pids=()
+for src in api.cpp scan.hip pack.hip select.hip lut.hip kmeans.hip container.hip; do
+  obj="${HERE}/build/${src%.*}.o"
+  if [[ ! -f "$obj" || "$obj" -ot "${HERE}/${src}" || "$obj" -ot "${HERE}/common.h" \
+        || "$obj" -ot "${HERE}/wave_topk.h" || "$obj" -ot "${HERE}/scan_layout.h" \
+        || "$obj" -ot "${HERE}/../../include/torchpq_amd.h" || "${FORCE:-0}" == "1" ]]; then
+    ( "$HIPCC" "${FLAGS[@]}" -x hip -c "${HERE}/${src}" -o "$obj" ${EXTRA_FLAGS:-} ) &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${HERE}"/build/*.o
+echo "built $OUT"

@@ -1,0 +1,213 @@
+// Inverted-list bookkeeping kernels (CellContainer.add / remove helpers) and PQ decode.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+namespace tpq {
+
+// ---- get_ioa -------------------------------------------------------------------------------
+// ioa[i] = #{ j < i : labels[j] == labels[i] }.  The reference (get_ioa.cu:9-47) gives every
+// unique label one thread that walks ALL n labels -- O(n * n_unique).  Here: stable radix sort
+// of (label, position) [rocPRIM], then rank inside each run of equal labels -- O(n).
+struct IoaWs {
+  int* keys_in;
+  int* keys_out;
+  int* pos_in;
+  int* pos_out;
+  int* run_start;
+  void* temp;
+  size_t temp_bytes;
+};
+
+__global__ __launch_bounds__(256) void ioa_prepare_kernel(const int64_t* __restrict__ labels,
+                                                         int* __restrict__ keys,
+                                                         int* __restrict__ pos, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = (int)labels[i];
+  pos[i] = (int)i;
+}
+
+__global__ __launch_bounds__(256) void ioa_heads_kernel(const int* __restrict__ keys,
+                                                       int* __restrict__ heads, int64_t n) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  heads[r] = (r == 0 || keys[r] != keys[r - 1]) ? (int)r : 0;
+}
+
+__global__ __launch_bounds__(256) void ioa_rank_kernel(const int* __restrict__ pos,
+                                                      const int* __restrict__ run_start,
+                                                      int64_t* __restrict__ ioa, int64_t n) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  ioa[pos[r]] = (int64_t)((int)r - run_start[r]);
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t ioa_temp_bytes(int64_t n) {
+  size_t sort_b = 0, scan_b = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, sort_b, (int*)nullptr, (int*)nullptr, (int*)nullptr,
+                            (int*)nullptr, (size_t)n, 0, 32, (hipStream_t)0, false);
+  (void)rocprim::inclusive_scan(nullptr, scan_b, (int*)nullptr, (int*)nullptr, (size_t)n,
+                          rocprim::maximum<int>(), (hipStream_t)0, false);
+  return sort_b > scan_b ? sort_b : scan_b;
+}
+
+// ---- get_write_address ---------------------------------------------------------------------
+// the ioa-th empty slot inside [start, start+capacity): one wave per label, 64 slots per step
+__global__ __launch_bounds__(256) void write_address_kernel(const uint8_t* __restrict__ is_empty,
+                                                           const int64_t* __restrict__ cell_start,
+                                                           const int64_t* __restrict__ cell_cap,
+                                                           const int64_t* __restrict__ labels,
+                                                           const int64_t* __restrict__ ioa,
+                                                           int64_t* __restrict__ out, int64_t n_slots,
+                                                           int64_t n_labels) {
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (w >= n_labels) return;
+  const int64_t lab = labels[w];
+  int64_t want = ioa[w];
+  const int64_t st = cell_start[lab];
+  int64_t end = st + cell_cap[lab];
+  if (end > n_slots) end = n_slots;
+  int64_t found = -1;
+  for (int64_t base = st; base < end; base += 64) {
+    const int64_t a = base + lane;
+    const bool e = (a < end) && (is_empty[a] == 1);
+    const unsigned long long mask = __ballot(e);
+    const int cnt = __popcll(mask);
+    if (want < cnt) {
+      // position of the (want+1)-th set bit
+      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+      const unsigned long long hit = __ballot(e && rank == (int)want);
+      found = base + (__ffsll((long long)hit) - 1);
+      break;
+    }
+    want -= cnt;
+  }
+  if (lane == 0) out[w] = found;
+}
+
+// ---- get_cell_by_address -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cell_by_address_kernel(const int64_t* __restrict__ adr,
+                                                             const int64_t* __restrict__ cell_start,
+                                                             const int64_t* __restrict__ cell_cap,
+                                                             int64_t* __restrict__ out, int64_t n,
+                                                             int64_t n_cells) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t a = adr[i];
+  int64_t lo = 0, hi = n_cells;  // last cell with start <= a
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (cell_start[mid] <= a) lo = mid + 1; else hi = mid;
+  }
+  // among cells sharing a start only the last can have capacity > 0, and upper_bound-1 is it
+  const int64_t c = lo - 1;
+  out[i] = (c >= 0 && a < cell_start[c] + cell_cap[c]) ? c : -1;
+}
+
+// ---- pq_decode -----------------------------------------------------------------------------
+// out[(j*ds+e)*n + i] = codebook[(j*ds+e)*256 + codes[j*n+i]]; grid (ceil(n/256), m)
+__global__ __launch_bounds__(256) void pq_decode_kernel(const float* __restrict__ codebook,
+                                                       const uint8_t* __restrict__ codes,
+                                                       float* __restrict__ out, int ds, int64_t n) {
+  const int j = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = codes[(int64_t)j * n + i];
+  for (int e = 0; e < ds; ++e)
+    out[((int64_t)j * ds + e) * n + i] = codebook[((int64_t)j * ds + e) * 256 + c];
+}
+
+}  // namespace tpq
+
+using namespace tpq;
+
+extern "C" size_t tpq_get_ioa_workspace_bytes(int64_t n) {
+  if (n <= 0) return 0;
+  return 5 * align256((size_t)n * sizeof(int)) + align256(ioa_temp_bytes(n));
+}
+
+extern "C" int tpq_get_ioa(const int64_t* labels, int64_t* ioa, int64_t n, int64_t n_cells,
+                           void* workspace, size_t workspace_bytes, tpq_stream_t stream) {
+  TPQ_REQUIRE(labels && ioa, "get_ioa: null pointer");
+  TPQ_REQUIRE(n >= 0 && n < 0x7fffffffLL, "get_ioa: n=%lld out of range", (long long)n);
+  TPQ_REQUIRE(n_cells >= 1 && n_cells < 0x7fffffffLL, "get_ioa: n_cells out of range");
+  if (n == 0) return TPQ_OK;
+  const size_t need = tpq_get_ioa_workspace_bytes(n);
+  if (!workspace || workspace_bytes < need) {
+    set_error("get_ioa: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return TPQ_ERR_WORKSPACE;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  char* p = reinterpret_cast<char*>(workspace);
+  const size_t arr = align256((size_t)n * sizeof(int));
+  int* keys_in = reinterpret_cast<int*>(p);
+  int* keys_out = reinterpret_cast<int*>(p + arr);
+  int* pos_in = reinterpret_cast<int*>(p + 2 * arr);
+  int* pos_out = reinterpret_cast<int*>(p + 3 * arr);
+  int* run_start = reinterpret_cast<int*>(p + 4 * arr);
+  void* temp = p + 5 * arr;
+  size_t temp_bytes = ioa_temp_bytes(n);
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(ioa_prepare_kernel, dim3(grid), dim3(256), 0, st, labels, keys_in, pos_in, n);
+  TPQ_LAUNCH_CHECK("ioa_prepare_kernel");
+  int bits = 1;
+  while (bits < 32 && (1LL << bits) < n_cells) ++bits;
+  int rc = check_hip(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, pos_in, pos_out,
+                                               (size_t)n, 0, bits, st, false),
+                     "get_ioa radix_sort_pairs");
+  if (rc) return rc;
+  hipLaunchKernelGGL(ioa_heads_kernel, dim3(grid), dim3(256), 0, st, keys_out, keys_in, n);
+  TPQ_LAUNCH_CHECK("ioa_heads_kernel");
+  temp_bytes = ioa_temp_bytes(n);
+  rc = check_hip(rocprim::inclusive_scan(temp, temp_bytes, keys_in, run_start, (size_t)n,
+                                         rocprim::maximum<int>(), st, false),
+                 "get_ioa inclusive_scan");
+  if (rc) return rc;
+  hipLaunchKernelGGL(ioa_rank_kernel, dim3(grid), dim3(256), 0, st, pos_out, run_start, ioa, n);
+  TPQ_LAUNCH_CHECK("ioa_rank_kernel");
+  return TPQ_OK;
+}
+
+extern "C" int tpq_get_write_address(const uint8_t* is_empty, const int64_t* cell_start,
+                                     const int64_t* cell_capacity, const int64_t* labels,
+                                     const int64_t* ioa, int64_t* write_address, int64_t n_slots,
+                                     int64_t n_labels, tpq_stream_t stream) {
+  TPQ_REQUIRE(is_empty && cell_start && cell_capacity && labels && ioa && write_address,
+              "get_write_address: null pointer");
+  if (n_labels <= 0) return TPQ_OK;
+  hipLaunchKernelGGL(write_address_kernel, dim3((unsigned)((n_labels + 3) / 4)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), is_empty, cell_start, cell_capacity,
+                     labels, ioa, write_address, n_slots, n_labels);
+  TPQ_LAUNCH_CHECK("write_address_kernel");
+  return TPQ_OK;
+}
+
+extern "C" int tpq_get_cell_by_address(const int64_t* address, const int64_t* cell_start,
+                                       const int64_t* cell_capacity, int64_t* cells,
+                                       int64_t n_address, int64_t n_cells, tpq_stream_t stream) {
+  TPQ_REQUIRE(address && cell_start && cell_capacity && cells, "get_cell_by_address: null pointer");
+  if (n_address <= 0) return TPQ_OK;
+  hipLaunchKernelGGL(cell_by_address_kernel, dim3((unsigned)((n_address + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), address, cell_start, cell_capacity, cells,
+                     n_address, n_cells);
+  TPQ_LAUNCH_CHECK("cell_by_address_kernel");
+  return TPQ_OK;
+}
+
+extern "C" int tpq_pq_decode(const float* codebook, const uint8_t* codes, float* out, int m, int ds,
+                             int64_t n, tpq_stream_t stream) {
+  TPQ_REQUIRE(codebook && codes && out, "pq_decode: null pointer");
+  TPQ_REQUIRE(m >= 1 && m <= 65535 && ds >= 1, "pq_decode: bad shape m=%d ds=%d", m, ds);
+  if (n <= 0) return TPQ_OK;
+  hipLaunchKernelGGL(pq_decode_kernel, dim3((unsigned)((n + 255) / 256), m), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), codebook, codes, out, ds, n);
+  TPQ_LAUNCH_CHECK("pq_decode_kernel");
+  return TPQ_OK;
+}

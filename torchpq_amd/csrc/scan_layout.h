@@ -1,0 +1,131 @@
+// The MI355X "scan layout" of PQ codes and of the per-query LUT in LDS.
+//
+// Problem: the list scan does m LDS look-ups per slot with a data-dependent (random) code
+// byte as index.  With the natural LUT[j][256] layout all 32 lanes of a half-wave look up the
+// same sub-quantizer j at once, so their banks (= c % 32) are random: ~3.5 LDS cycles per
+// ds_read_b32 instead of 1 (MI355X_MICROARCH: ds_read_b32 = 2 x 32 lanes, bank = dword % 32).
+//
+// Fix: make the lanes of a half-wave look up 32 DIFFERENT sub-quantizers at the same step and
+// lay the LUT out as [code][sub-quantizer] so the bank is the sub-quantizer index:
+//   * sub-quantizers are grouped in power-of-two blocks (greedy 64,...,64,32,16,8,4);
+//     block (base b, size B) stores entry (j, c) at dword  b*256 + c*B + (j-b);
+//   * the slot with address s keeps, at byte position p (b <= p < b+B), the code of
+//     sub-quantizer  j = b + ((p-b) XOR (s mod B));
+//   * lanes hold consecutive slots, so at step p lane s reads dword c*B + ((p-b)^(s%B)):
+//     bank = ((p-b) ^ s) % 32 for B >= 32 -- 32 distinct banks for 32 consecutive s.
+//     (B = 16/8/4 tails of an m that is not a multiple of 32 get bank = (c%(32/B))*B + ...,
+//     i.e. at most a 32/B-way conflict on a fraction of the steps.)
+// The bytes per slot are unchanged (m), only their order; packed shape [m/W][n_slots][W] with
+// W = 16/8/4 so that one lane loads W contiguous bytes and a wave 64*W contiguous bytes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tpq {
+namespace scan_layout {
+
+__host__ __device__ constexpr int chunk_width(int m) { return (m % 16 == 0) ? 16 : ((m % 8 == 0) ? 8 : 4); }
+
+struct Block {
+  int base, size;
+};
+
+// block containing sub-quantizer / position x (0 <= x < m)
+__host__ __device__ constexpr Block block_of(int m, int x) {
+  const int n64 = m / 64;
+  if (x < n64 * 64) return Block{(x / 64) * 64, 64};
+  int b = n64 * 64;
+  const int rem = m - b;
+  for (int B = 32; B >= 4; B >>= 1) {
+    if (rem & B) {
+      if (x < b + B) return Block{b, B};
+      b += B;
+    }
+  }
+  return Block{b, 4};
+}
+
+// LDS dword of LUT entry (sub-quantizer j, code c)
+__host__ __device__ constexpr int lut_dword(int m, int j, int c) {
+  const Block k = block_of(m, j);
+  return k.base * 256 + c * k.size + (j - k.base);
+}
+
+// sub-quantizer stored at byte position p of the slot with address s (an involution in p)
+__host__ __device__ constexpr int subq_at(int m, int p, int64_t s) {
+  const Block k = block_of(m, p);
+  return k.base + ((p - k.base) ^ (int)(s & (k.size - 1)));
+}
+
+// byte offset of position p of slot s inside the packed array
+__host__ __device__ constexpr int64_t packed_offset(int m, int64_t n_slots, int p, int64_t s) {
+  const int W = chunk_width(m);
+  return ((int64_t)(p / W) * n_slots + s) * W + (p % W);
+}
+
+template <int W>
+struct ChunkT;
+template <>
+struct ChunkT<16> {
+  using type = uint4;
+};
+template <>
+struct ChunkT<8> {
+  using type = uint2;
+};
+template <>
+struct ChunkT<4> {
+  using type = uint32_t;
+};
+
+template <int M>
+struct Layout {
+  static constexpr int kW = chunk_width(M);
+  static constexpr int kChunks = M / kW;
+  using chunk_t = typename ChunkT<kW>::type;
+
+  __device__ static __forceinline__ void load(const uint8_t* __restrict__ packed, int64_t n_slots,
+                                              int s, chunk_t (&w)[kChunks]) {
+    const chunk_t* __restrict__ src = reinterpret_cast<const chunk_t*>(packed);
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) w[c] = src[(int64_t)c * n_slots + s];
+  }
+
+  __device__ static __forceinline__ uint32_t word(const chunk_t (&w)[kChunks], int d) {
+    // d = dword index inside the slot (compile-time after unrolling)
+    if constexpr (kW == 16) {
+      const uint4& x = w[d >> 2];
+      return (d & 3) == 0 ? x.x : (d & 3) == 1 ? x.y : (d & 3) == 2 ? x.z : x.w;
+    } else if constexpr (kW == 8) {
+      const uint2& x = w[d >> 1];
+      return (d & 1) == 0 ? x.x : x.y;
+    } else {
+      return w[d];
+    }
+  }
+
+  // sum over byte positions p ascending of LUT(subq_at(p, s), byte_p)  -- permuted order
+  __device__ static __forceinline__ float accumulate(const chunk_t (&w)[kChunks], int s,
+                                                     const float* __restrict__ lut) {
+    float v = 0.f;
+#pragma unroll
+    for (int p = 0; p < M; ++p) {
+      constexpr_block<M> kb(p);
+      const uint32_t wd = word(w, p >> 2);
+      const unsigned c = (wd >> (8 * (p & 3))) & 255u;
+      const int lane_part = (p - kb.base) ^ (s & (kb.size - 1));
+      v += lut[kb.base * 256 + (int)c * kb.size + lane_part];
+    }
+    return v;
+  }
+
+  template <int MM>
+  struct constexpr_block {
+    int base, size;
+    __device__ __forceinline__ constexpr explicit constexpr_block(int p)
+        : base(block_of(MM, p).base), size(block_of(MM, p).size) {}
+  };
+};
+
+}  // namespace scan_layout
+}  // namespace tpq

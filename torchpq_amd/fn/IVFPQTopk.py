@@ -1,0 +1,26 @@
+"""List-scan dispatch (mirrors torchpq/fn/IVFPQTopk.py:4-104).  The reference keeps four CUDA
+kernels (k = 1, <= 256, <= 512, <= 1024); the HIP kernel is templated on the number of
+64-candidate registers per wave and picked inside the C ABI."""
+from ..kernels import IVFPQTopkHip
+
+
+class IVFPQTopk:
+    def __init__(self, n_subvectors, contiguous_size=4, sm_size=None):
+        self.n_subvectors = n_subvectors
+        self.contiguous_size = contiguous_size
+        self._scan = IVFPQTopkHip(m=n_subvectors, n_cs=contiguous_size)
+
+    def topk(self, data, precomputed, cell_start, cell_size, is_empty, n_probe_list, k=256,
+             packed=None, address2id=None):
+        assert 0 < k <= 1024
+        return self._scan.topk(data=data, precomputed=precomputed, is_empty=is_empty,
+                               cell_start=cell_start, cell_size=cell_size,
+                               n_probe_list=n_probe_list, n_candidates=k, packed=packed,
+                               address2id=address2id)
+
+    def topk_residual(self, *a, **k):
+        raise NotImplementedError(
+            "residual PQ search (ivfpq_topk_residual, ivfpq_topk.cu:973-1037) is SURVEY 8(f) "
+            "rank 3: not built yet")
+
+    topk_residual_precomputed = topk_residual

@@ -1,0 +1,255 @@
+"""IVFPQIndex: drop-in for torchpq.index.IVFPQIndex (reference index/IVFPQIndex.py:12-524).
+
+Same constructor, methods, properties, asserts, tensor layouts ([d_vector, n] fp32 in, ids
+int64 out, values descending with (-inf, -1) padding) and state_dict keys.  Everything below
+the Python API runs in hand-written HIP kernels for gfx950 (libtorchpq_amd.so); the only
+library math is the coarse query x cell-centroid GEMM (rocBLAS via torch.matmul, as the
+reference uses cuBLAS).  Not built: pq_use_residual=True.
+"""
+import torch
+
+from .. import metric, util
+from ..codec import PQCodec, VQCodec
+from ..container import CellContainer
+from ..fn import IVFPQTopk, Topk
+from ..kernels import SmartProbingHip
+
+
+class IVFPQIndex(CellContainer):
+    def __init__(self, d_vector, n_subvectors=8, n_cells=128, initial_size=None,
+                 expand_step_size=128, expand_mode="double", distance="euclidean",
+                 device="cuda:0", pq_use_residual=False, verbose=0):
+        if torch.device(device).type == "cuda":
+            assert torch.cuda.is_available(), "cuda is not available"
+            assert n_subvectors <= util.max_subvectors()
+        assert d_vector % n_subvectors == 0
+        assert n_subvectors % 4 == 0, "codes are stored 4 sub-quantizers per word (contiguous_size=4)"
+        assert distance in ("euclidean", "cosine"), \
+            "euclidean and cosine work end to end (MultiKMeans.py:82-113)"
+        if pq_use_residual:
+            raise NotImplementedError(
+                "pq_use_residual=True (ivfpq_topk_residual*, ivfpq_topk.cu:973-1208) is not built "
+                "yet -- SURVEY 8(f) rank 3")
+        super().__init__(code_size=n_subvectors, n_cells=n_cells, dtype="uint8", device=device,
+                         initial_size=initial_size, expand_step_size=expand_step_size,
+                         expand_mode=expand_mode, use_inverse_id_mapping=True, contiguous_size=4,
+                         verbose=verbose)
+        self.d_vector = d_vector
+        self.n_subvectors = n_subvectors
+        self.d_subvector = d_vector // n_subvectors
+        self.distance = distance
+        self.verbose = verbose
+        self.pq_use_residual = pq_use_residual
+        self.n_probe = 1
+        self._use_precomputed = False
+        self._precomputed_part2 = None
+        self._use_cublas = True
+        self._use_smart_probing = True
+        self._smart_probing_temperature = 30.0
+        self._use_tensor_core = False
+        self._fp16_scale_mode = "a"
+        self.use_packed_layout = True   # MI355X scan layout (bank-conflict-free LDS look-ups)
+        self.max_query_batch = 32768    # bounds the [m, nq, 256] LUT (m=64: 2 GiB per batch)
+
+        self.vq_codec = VQCodec(n_clusters=n_cells, n_redo=1, max_iter=15, tol=1e-4,
+                                distance="euclidean", init_mode="random", verbose=verbose)
+        self.pq_codec = PQCodec(d_vector=d_vector, n_subvectors=n_subvectors, n_clusters=256,
+                                distance=distance, verbose=verbose)
+        self._ivfpq_topk = IVFPQTopk(n_subvectors=n_subvectors, contiguous_size=self.contiguous_size)
+        self._topk = Topk()
+        self._smart_probing = SmartProbingHip()
+        self.to(device)
+
+    # ---- knobs (reference :89-232) ---------------------------------------------------------------
+    @property
+    def use_cublas(self):
+        return self._use_cublas
+
+    @use_cublas.setter
+    def use_cublas(self, value):
+        assert type(value) is bool
+        self._use_cublas = value
+
+    @property
+    def use_tensor_core(self):
+        return self._use_tensor_core
+
+    @use_tensor_core.setter
+    def use_tensor_core(self, value):
+        assert type(value) is bool
+        assert self.use_cublas
+        # fp16 matrix-core coarse GEMM breaks the 1e-4 distance tolerance; fp32 is always used
+        self._use_tensor_core = False
+        if value:
+            self.print_message("warning: reduced-precision coarse GEMM is not used on MI355X", 1)
+
+    @property
+    def fp16_scale_mode(self):
+        return self._fp16_scale_mode
+
+    @fp16_scale_mode.setter
+    def fp16_scale_mode(self, value):
+        assert value in ["a", "b", "both", "none"]
+        self._fp16_scale_mode = value
+
+    @property
+    def use_smart_probing(self):
+        return self._use_smart_probing
+
+    @use_smart_probing.setter
+    def use_smart_probing(self, value):
+        assert type(value) is bool
+        self._use_smart_probing = value
+
+    @property
+    def smart_probing_temperature(self):
+        return self._smart_probing_temperature
+
+    @smart_probing_temperature.setter
+    def smart_probing_temperature(self, value):
+        assert value > 0
+        assert self.use_smart_probing, "set use_smart_probing to True first"
+        self._smart_probing_temperature = value
+
+    @property
+    def use_precomputed(self):
+        return self._use_precomputed
+
+    @use_precomputed.setter
+    def use_precomputed(self, value):
+        assert type(value) is bool
+        if value:
+            assert self.pq_use_residual, " `use_precomputed=True` is only valid when `pq_use_residual` is True"
+        self._use_precomputed = value
+
+    def _codec_knob(codec, attr, typed):
+        def getter(self):
+            return getattr(getattr(self, codec).kmeans, attr)
+
+        def setter(self, value):
+            if typed:
+                assert type(value) is int
+                assert value > 0
+            assert not getattr(self, codec).is_trained, f"{codec} is already trained"
+            setattr(getattr(self, codec).kmeans, attr, value)
+        return property(getter, setter)
+
+    vq_codec_max_iter = _codec_knob("vq_codec", "max_iter", True)
+    vq_codec_n_redo = _codec_knob("vq_codec", "n_redo", True)
+    vq_codec_tolerance = _codec_knob("vq_codec", "tol", False)
+    pq_codec_max_iter = _codec_knob("pq_codec", "max_iter", True)
+    pq_codec_n_redo = _codec_knob("pq_codec", "n_redo", True)
+    pq_codec_tolerance = _codec_knob("pq_codec", "tol", False)
+    del _codec_knob
+
+    def _after_load_state_dict(self):
+        self.to(self.device)
+        super()._after_load_state_dict()
+
+    # ---- train / encode / add (reference :234-364) ------------------------------------------------
+    def train(self, x, force_retrain=False):
+        """x [d_vector, n_data] f32: coarse k-means (n_cells) then 256-centroid PQ codebooks."""
+        if self.vq_codec.is_trained and self.pq_codec.is_trained and not force_retrain:
+            self.print_message("index is already trained", 1)
+            return
+        assert len(x.shape) == 2
+        assert x.shape[0] == self.d_vector
+        x = x.to(self.device)
+        if self.distance == "cosine":
+            x = util.normalize(x, dim=0)
+        x = x.contiguous()
+        self.print_message("start training VQ codec...", 1)
+        self.vq_codec.train(x)
+        self.print_message("start training PQ codec...", 1)
+        self.pq_codec.train(x)
+        self.print_message("index is trained successfully!", 1)
+
+    def encode(self, x):
+        """x [d_vector, n] f32 -> PQ codes [n_subvectors, n] uint8"""
+        assert len(x.shape) == 2
+        assert x.shape[0] == self.d_vector
+        x = x.to(self.device)
+        if self.distance == "cosine":
+            x = util.normalize(x)
+        return self.pq_codec.encode(x.contiguous())
+
+    def decode(self, x):
+        """codes [n_subvectors, n] uint8 -> [d_vector, n] f32"""
+        assert len(x.shape) == 2
+        assert x.shape[0] == self.n_subvectors
+        return self.pq_codec.decode(x.to(self.device))
+
+    def add(self, x, ids=None, return_address=False):
+        """x [d_vector, n] f32, optional ids [n] int64 (default arange + max_id + 1);
+        returns ids (and the slot addresses if return_address)."""
+        assert len(x.shape) == 2
+        assert x.shape[0] == self.d_vector
+        x = x.to(self.device)
+        if self.distance == "cosine":
+            x = util.normalize(x)
+        x = x.contiguous()
+        assigned_cells = self.vq_codec.encode(x)
+        codes = self.pq_codec.encode(x)
+        return super().add(codes, cells=assigned_cells, ids=ids, return_address=return_address)
+
+    # ---- search (reference :407-524) ---------------------------------------------------------------
+    def search_cells(self, x, cells, base_sims=None, n_probe_list=None, k=1, return_address=False):
+        """Scan the given cells [n_query, n_probe] for each query; (values, ids[, address])."""
+        n_query = x.shape[1]
+        if n_probe_list is None:
+            n_probe_list = torch.full((n_query,), cells.shape[1], device=self.device, dtype=torch.long)
+        cell_start = self._cell_start[cells]
+        cell_size = self._cell_size[cells]
+        precomputed = self.pq_codec.precompute_adc(x)
+        packed = None
+        if self.use_packed_layout:
+            from ..kernels import PACKED_M
+            if self.n_subvectors in PACKED_M:
+                packed = self.packed_storage()
+        topk_val, topk_address, topk_ids = self._ivfpq_topk.topk(
+            data=self._storage, precomputed=precomputed, cell_start=cell_start,
+            cell_size=cell_size, is_empty=self._is_empty if self._has_holes else None,
+            n_probe_list=n_probe_list, k=k, packed=packed, address2id=self._address2id)
+        if return_address:
+            return topk_val, topk_ids, topk_address
+        return topk_val, topk_ids
+
+    def probe(self, x):
+        """Coarse step: (topk_sims, cells [n_query, n_probe], n_probe_list [n_query])."""
+        vq_codebook = self.vq_codec.codebook
+        if self.use_cublas:
+            sims = metric.negative_squared_l2_distance(x, vq_codebook).contiguous()
+            topk_sims, cells = self._topk(sims, k=self.n_probe, dim=1)
+        else:
+            topk_sims, cells = self.vq_codec.kmeans.topk(x, k=self.n_probe)
+        if self.use_smart_probing and self.n_probe > 1:
+            n_probe_list = self._smart_probing(topk_sims, self.smart_probing_temperature)
+        else:
+            n_probe_list = torch.full((x.shape[1],), self.n_probe, device=self.device,
+                                      dtype=torch.long)
+        return topk_sims, cells, n_probe_list
+
+    def search(self, x, k=1, return_address=False):
+        """x [d_vector, n_query] f32 -> (values f32 [n_query, k] descending, ids int64 [n_query, k]);
+        values are -squared-L2 (euclidean) or cosine similarity of the PQ reconstruction.
+        `return_address` is accepted and ignored, as in the reference (:521)."""
+        assert len(x.shape) == 2
+        assert x.shape[0] == self.d_vector
+        assert 0 < k <= 1024
+        assert self.vq_codec.is_trained and self.pq_codec.is_trained, "index is not trained"
+        assert 1 <= self.n_probe <= self.n_cells
+        x = x.to(self.device)
+        if self.distance == "cosine":
+            x = util.normalize(x, dim=0)
+        n_query = x.shape[1]
+        vals, ids = [], []
+        for q0 in range(0, max(n_query, 1), self.max_query_batch):
+            xb = x[:, q0:q0 + self.max_query_batch].contiguous()
+            topk_sims, cells, n_probe_list = self.probe(xb)
+            v, i = self.search_cells(x=xb, cells=cells, base_sims=topk_sims,
+                                     n_probe_list=n_probe_list, k=k, return_address=False)
+            vals.append(v)
+            ids.append(i)
+        if len(vals) == 1:
+            return vals[0], ids[0]
+        return torch.cat(vals, 0), torch.cat(ids, 0)

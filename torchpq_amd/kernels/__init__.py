@@ -1,0 +1,396 @@
+"""Kernel wrappers: torch tensors in, torch tensors out, HIP underneath.
+
+Each class mirrors one CuPy RawKernel wrapper of the reference (torchpq/kernels/*Cuda.py):
+same call signature and argument meaning, same asserts, outputs allocated with torch and
+owned by the caller, launches asynchronous on the CURRENT torch stream, never synchronising.
+There is no CPU path: tensors must live on the GPU.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .. import _lib
+from .._lib import check, load, ptr, require_gpu, stream_ptr
+
+__all__ = [
+    "IVFPQTopkHip", "IVFPQTop1Hip", "AdcLutHip", "TopkSelectHip", "Top1SelectHip",
+    "Top32SelectHip", "SmartProbingHip", "MaxSimHip", "ComputeCentroidsHip", "GetIOAHip",
+    "GetWriteAddressHip", "GetCellByAddressHip", "GetIdByAddressHip", "PQDecodeHip",
+    "ScatterCodesHip", "PackCodesHip", "packed_chunk_width", "PACKED_M",
+]
+
+PACKED_M = (8, 16, 32, 64, 120)  # n_subvectors with an instantiated packed-layout scan kernel
+
+
+def packed_chunk_width(m):
+    return 16 if m % 16 == 0 else (8 if m % 8 == 0 else 4)
+
+
+def _next_power_of_2(x):
+    return 1 if x == 0 else 2 ** math.ceil(math.log2(x))
+
+
+class IVFPQTopkHip:
+    """IVF list scan + top-k.  Mirrors IVFPQTopkCuda (kernels/IVFPQTopkCuda.py:9-142);
+    ``tpb``/``stack_capacity``/``sm_size`` are accepted for signature compatibility and
+    ignored (the workgroup shape is fixed by the gfx950 kernel)."""
+
+    def __init__(self, m=8, k=256, tpb=256, n_cs=4, stack_capacity=2, sm_size=None):
+        assert k == 256  # 8-bit PQ only (IVFPQTopkCuda.py:21)
+        assert n_cs == 4
+        assert m % n_cs == 0
+        self.m = m
+        self.k = k
+        self.tpb = tpb
+        self.n_cs = n_cs
+        self.n_cus = None
+        # measurement hook (bench.py): when a list, every call appends a (start, stop) pair of
+        # timing events recorded on the launch stream around the scan kernel(s)
+        self.record_events = None
+
+    def _n_split(self, n_query, device):
+        """Workgroups per query so that small batches still fill the chip (256 CUs x 2)."""
+        if self.n_cus is None:
+            self.n_cus = torch.cuda.get_device_properties(device).multi_processor_count
+        target = 2 * self.n_cus
+        if n_query >= target:
+            return 1
+        return max(1, min(64, target // max(n_query, 1)))
+
+    def topk(self, data, precomputed, is_empty, cell_start, cell_size, n_probe_list,
+             n_candidates=None, packed=None, address2id=None, n_split=None):
+        """
+          data: [m // 4, n_data, 4] uint8           (CellContainer._storage)
+          precomputed: [m, n_query, 256] float32    (PQCodec.precompute_adc)
+          is_empty: [n_data] uint8, or None when no slot inside a cell is a tombstone
+          cell_start / cell_size: [n_query, max_n_probe] int64
+          n_probe_list: [n_query] int64
+          n_candidates: k of the top-k (<= 1024)
+          packed: optional scan-layout copy of `data` (enables the bank-conflict-free kernel)
+          address2id: optional [n_data] int64; when given a third tensor (ids) is returned
+        returns (values [n_query, k] descending, address [n_query, k][, ids])
+        """
+        n_data = data.shape[1]
+        n_query, n_probe = cell_start.shape
+        assert precomputed.shape == (self.m, n_query, self.k)
+        assert data.shape[0] == self.m // self.n_cs
+        assert data.shape[2] == self.n_cs
+        assert cell_size.shape[1] == n_probe
+        assert data.dtype == torch.uint8
+        assert precomputed.dtype == torch.float32
+        assert cell_start.dtype == cell_size.dtype == torch.int64
+        assert n_probe_list.shape == (n_query,)
+        assert n_probe_list.dtype == torch.int64
+        if is_empty is not None:
+            assert is_empty.shape[0] == n_data
+            assert is_empty.dtype == torch.uint8
+        if n_candidates is None:
+            n_candidates = self.tpb
+        assert 0 < n_candidates <= 1024
+        require_gpu(data, precomputed, is_empty, cell_start, cell_size, n_probe_list, packed,
+                    address2id)
+        device = data.device
+        k = n_candidates
+        values = torch.empty(n_query, k, device=device, dtype=torch.float32)
+        address = torch.empty(n_query, k, device=device, dtype=torch.int64)
+        ids = torch.empty(n_query, k, device=device, dtype=torch.int64) if address2id is not None else None
+        if n_query == 0:
+            return (values, address) if ids is None else (values, address, ids)
+        lib = load()
+        if n_split is None:
+            n_split = self._n_split(n_query, device)
+        ws_bytes = lib.tpq_ivfpq_scan_workspace_bytes(n_query, k, n_split)
+        ws = torch.empty(max(ws_bytes, 1), device=device, dtype=torch.uint8) if ws_bytes else None
+        ev = None
+        if self.record_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(torch.cuda.current_stream(device))
+        with torch.cuda.device(device):
+            if packed is not None and self.m in PACKED_M:
+                rc = lib.tpq_ivfpq_scan_topk_packed(
+                    ptr(packed), ptr(data), ptr(precomputed), ptr(is_empty), ptr(cell_start),
+                    ptr(cell_size), ptr(n_probe_list), ptr(values), ptr(address), ptr(address2id),
+                    ptr(ids), n_data, n_query, n_probe, self.m, k, n_split, ptr(ws), ws_bytes,
+                    stream_ptr(device))
+                check(rc, "tpq_ivfpq_scan_topk_packed")
+            else:
+                rc = lib.tpq_ivfpq_scan_topk(
+                    ptr(data), ptr(precomputed), ptr(is_empty), ptr(cell_start), ptr(cell_size),
+                    ptr(n_probe_list), ptr(values), ptr(address), ptr(address2id), ptr(ids), n_data,
+                    n_query, n_probe, self.m, k, n_split, ptr(ws), ws_bytes, stream_ptr(device))
+                check(rc, "tpq_ivfpq_scan_topk")
+        if ev is not None:
+            ev[1].record(torch.cuda.current_stream(device))
+            self.record_events.append(ev)
+        return (values, address) if ids is None else (values, address, ids)
+
+
+class IVFPQTop1Hip(IVFPQTopkHip):
+    """k = 1 variant (kernels/IVFPQTop1Cuda.py:86-140): same kernel family, list of one."""
+
+    def topk(self, *args, n_candidates=1, **kwargs):
+        return super().topk(*args, n_candidates=n_candidates, **kwargs)
+
+
+class AdcLutHip:
+    """PQCodec.precompute_adc on the fp32 matrix cores (codec/PQCodec.py:62-75)."""
+
+    def __call__(self, query, codebook, distance="euclidean"):
+        """query [d, n_query] f32, codebook [m, ds, 256] f32 -> [m, n_query, 256] f32"""
+        m, ds, k = codebook.shape
+        assert k == 256
+        assert query.shape[0] == m * ds
+        assert query.dtype == codebook.dtype == torch.float32
+        query = query.contiguous()
+        codebook = codebook.contiguous()
+        require_gpu(query, codebook)
+        nq = query.shape[1]
+        lut = torch.empty(m, nq, 256, device=query.device, dtype=torch.float32)
+        metric = _lib.METRIC_NEG_SQ_L2 if distance == "euclidean" else _lib.METRIC_INNER
+        with torch.cuda.device(query.device):
+            check(load().tpq_adc_lut(ptr(query), ptr(codebook), ptr(lut), m, ds, nq, metric,
+                                     stream_ptr(query.device)), "tpq_adc_lut")
+        return lut
+
+
+class TopkSelectHip:
+    """Row-wise top-k, values descending (kernels/TopkSelectCuda.py:52-84,
+    Top32SelectCuda.py:60-112, Top1SelectCuda.py)."""
+
+    def __init__(self, tpb=256, queue_capacity=4, buffer_size=4):
+        self.tpb = tpb
+
+    def __call__(self, x, k=1, dim=1):
+        assert len(x.shape) == 2
+        assert dim in (1, -1), "only support last dimention"
+        assert x.dtype == torch.float32
+        assert 1 <= k <= 1024 and k <= x.shape[1]
+        x = x.contiguous()
+        require_gpu(x)
+        rows, cols = x.shape
+        vals = torch.empty(rows, k, device=x.device, dtype=torch.float32)
+        inds = torch.empty(rows, k, device=x.device, dtype=torch.int64)
+        with torch.cuda.device(x.device):
+            check(load().tpq_topk_select(ptr(x), ptr(vals), ptr(inds), rows, cols, k,
+                                         stream_ptr(x.device)), "tpq_topk_select")
+        return vals, inds
+
+
+Top1SelectHip = TopkSelectHip
+Top32SelectHip = TopkSelectHip
+
+
+class SmartProbingHip:
+    """n_probe_list from the entropy of the coarse similarities (index/IVFPQIndex.py:499-512)."""
+
+    def __call__(self, topk_sims, temperature=30.0):
+        assert topk_sims.dtype == torch.float32 and len(topk_sims.shape) == 2
+        topk_sims = topk_sims.contiguous()
+        require_gpu(topk_sims)
+        rows, n_probe = topk_sims.shape
+        out = torch.empty(rows, device=topk_sims.device, dtype=torch.int64)
+        with torch.cuda.device(topk_sims.device):
+            check(load().tpq_smart_probing(ptr(topk_sims), ptr(out), rows, n_probe,
+                                           float(temperature), stream_ptr(topk_sims.device)),
+                  "tpq_smart_probing")
+        return out
+
+
+class MaxSimHip:
+    """Batched arg-max similarity, mode "tn" (kernels/MaxSimCuda.py:296-340): A [l, d, m] or
+    [d, m], B [l, d, n] or [d, n] -> (vals, inds) over the n columns of B."""
+
+    def __init__(self, dim=2, distance="euclidean", **_):
+        assert distance in ("euclidean", "inner", "cosine")
+        self.distance = distance
+        self.dim = dim
+
+    def __call__(self, A, B, dim=1, mode="tn"):
+        assert mode == "tn", "only the 'tn' layout ([.., d, m] x [.., d, n]) is on the IVFPQ path"
+        assert len(A.shape) == len(B.shape)
+        two_d = len(A.shape) == 2
+        if two_d:
+            A, B, dim = A[None], B[None], dim + 1
+        assert len(A.shape) == 3
+        assert dim == 2, "arg-max is taken over the columns of B (dim=2; dim=1 for 2-D inputs)"
+        assert A.shape[0] == B.shape[0] and A.shape[1] == B.shape[1]
+        assert A.dtype == B.dtype == torch.float32
+        A = A.contiguous()
+        B = B.contiguous()
+        require_gpu(A, B)
+        l, d, m = A.shape
+        n = B.shape[2]
+        vals = torch.empty(l, m, device=A.device, dtype=torch.float32)
+        inds = torch.empty(l, m, device=A.device, dtype=torch.int64)
+        metric = _lib.METRIC_NEG_SQ_L2 if self.distance == "euclidean" else _lib.METRIC_INNER
+        with torch.cuda.device(A.device):
+            check(load().tpq_max_sim(ptr(A), ptr(B), ptr(vals), ptr(inds), l, d, m, n, metric,
+                                     stream_ptr(A.device)), "tpq_max_sim")
+        if two_d:
+            vals, inds = vals[0], inds[0]
+        return vals, inds
+
+
+class ComputeCentroidsHip:
+    """K-means update (kernels/ComputeCentroidsCuda.py:43-81): data [l, d, n], labels [l, n]
+    -> centroids [l, d, k]; empty clusters -> 0."""
+
+    def __init__(self, de=1, dk=None, sm_size=None, **_):
+        pass
+
+    def __call__(self, data, labels, k, centroids=None):
+        l, d, n = data.shape
+        assert labels.shape == (l, n)
+        assert data.dtype == torch.float32 and labels.dtype == torch.int64
+        data = data.contiguous()
+        labels = labels.contiguous()
+        require_gpu(data, labels)
+        lib = load()
+        out = torch.empty(l, d, k, device=data.device, dtype=torch.float32)
+        ws_bytes = lib.tpq_compute_centroids_workspace_bytes(l, d, k)
+        ws = torch.empty(ws_bytes, device=data.device, dtype=torch.uint8)
+        with torch.cuda.device(data.device):
+            check(lib.tpq_compute_centroids(ptr(data), ptr(labels), ptr(out), l, d, n, k, ptr(ws),
+                                            ws_bytes, stream_ptr(data.device)),
+                  "tpq_compute_centroids")
+        return out
+
+
+class GetIOAHip:
+    """Index of appearance (kernels/GetIOACuda.py:36-63): ioa[i] = #{j < i: labels[j] == labels[i]}."""
+
+    def __init__(self, tpb=256):
+        pass
+
+    def __call__(self, labels, unique_labels=None, n_cells=None):
+        assert labels.dtype == torch.int64 and len(labels.shape) == 1
+        labels = labels.contiguous()
+        require_gpu(labels)
+        n = labels.shape[0]
+        ioa = torch.empty_like(labels)
+        if n == 0:
+            return ioa
+        if n_cells is None:
+            n_cells = 2 ** 31 - 2  # sort on all 31 key bits
+        lib = load()
+        ws_bytes = lib.tpq_get_ioa_workspace_bytes(n)
+        ws = torch.empty(ws_bytes, device=labels.device, dtype=torch.uint8)
+        with torch.cuda.device(labels.device):
+            check(lib.tpq_get_ioa(ptr(labels), ptr(ioa), n, int(n_cells), ptr(ws), ws_bytes,
+                                  stream_ptr(labels.device)), "tpq_get_ioa")
+        return ioa
+
+
+class GetWriteAddressHip:
+    """The ioa-th empty slot of each label's cell (kernels/GetWriteAddressV2Cuda.py:36-66)."""
+
+    def __init__(self, tpb=256):
+        pass
+
+    def __call__(self, is_empty, div_start, div_size, labels, ioa):
+        assert div_start.shape == div_size.shape
+        assert ioa.shape == labels.shape
+        require_gpu(is_empty, div_start, div_size, labels, ioa)
+        n_slots = is_empty.shape[0]
+        n_labels = labels.shape[0]
+        out = torch.empty_like(labels)
+        with torch.cuda.device(labels.device):
+            check(load().tpq_get_write_address(ptr(is_empty), ptr(div_start), ptr(div_size),
+                                               ptr(labels), ptr(ioa), ptr(out), n_slots, n_labels,
+                                               stream_ptr(labels.device)), "tpq_get_write_address")
+        return out
+
+
+class GetCellByAddressHip:
+    """address -> cell (kernels/GetDivByAddressV2Cuda.py:38-67); ``div_end`` = start + capacity."""
+
+    def __init__(self, ta=4, tpb=256):
+        pass
+
+    def __call__(self, address, div_start, div_end):
+        assert div_start.shape[0] == div_end.shape[0]
+        address = address.contiguous()
+        cap = (div_end - div_start).contiguous()
+        div_start = div_start.contiguous()
+        require_gpu(address, div_start, cap)
+        out = torch.empty_like(address)
+        with torch.cuda.device(address.device):
+            check(load().tpq_get_cell_by_address(ptr(address), ptr(div_start), ptr(cap), ptr(out),
+                                                 address.shape[0], div_start.shape[0],
+                                                 stream_ptr(address.device)),
+                  "tpq_get_cell_by_address")
+        return out
+
+
+class GetIdByAddressHip:
+    """address -> id gather with -1 for invalid addresses (container/BaseContainer.py:58-65)."""
+
+    def __call__(self, address2id, address):
+        shape = address.shape
+        flat = address.contiguous().view(-1)
+        require_gpu(address2id, flat)
+        out = torch.empty_like(flat)
+        with torch.cuda.device(flat.device):
+            check(load().tpq_get_id_by_address(ptr(address2id), address2id.shape[0], ptr(flat),
+                                               ptr(out), flat.shape[0], stream_ptr(flat.device)),
+                  "tpq_get_id_by_address")
+        return out.view(shape)
+
+
+class PQDecodeHip:
+    """codes -> reconstruction (kernels/PQDecodeCuda.py:43-65)."""
+
+    def __init__(self, tm=2, td=8):
+        pass
+
+    def __call__(self, codebook, code):
+        m, d, k = codebook.shape
+        assert code.shape[0] == m and k == 256
+        assert code.dtype == torch.uint8
+        codebook = codebook.contiguous()
+        code = code.contiguous()
+        require_gpu(codebook, code)
+        n = code.shape[1]
+        out = torch.empty(m * d, n, device=codebook.device, dtype=torch.float32)
+        with torch.cuda.device(codebook.device):
+            check(load().tpq_pq_decode(ptr(codebook), ptr(code), ptr(out), m, d, n,
+                                       stream_ptr(codebook.device)), "tpq_pq_decode")
+        return out
+
+
+class ScatterCodesHip:
+    """codes [m, n] -> _storage [m/4, cap, 4] (and the scan-layout copy) at `address`
+    (CellContainer.set_data_by_address, container/CellContainer.py:213-239)."""
+
+    def __call__(self, codes, address, storage, packed=None):
+        m, n = codes.shape
+        assert storage.shape[0] * storage.shape[2] == m and storage.shape[2] == 4
+        assert address.shape[0] == n and address.dtype == torch.int64
+        codes = codes.contiguous()
+        address = address.contiguous()
+        require_gpu(codes, address, storage, packed)
+        with torch.cuda.device(codes.device):
+            check(load().tpq_scatter_codes(ptr(codes), ptr(address), ptr(storage), ptr(packed), m, n,
+                                           storage.shape[1], stream_ptr(codes.device)),
+                  "tpq_scatter_codes")
+
+
+class PackCodesHip:
+    """(Re)build the MI355X scan layout from _storage for slots [begin, end)."""
+
+    def __call__(self, storage, packed=None, begin=0, end=None):
+        g, cap, cs = storage.shape
+        assert cs == 4 and storage.dtype == torch.uint8
+        m = g * cs
+        w = packed_chunk_width(m)
+        if packed is None:
+            packed = torch.empty(m // w, cap, w, device=storage.device, dtype=torch.uint8)
+        assert packed.shape == (m // w, cap, w)
+        require_gpu(storage, packed)
+        end = cap if end is None else end
+        with torch.cuda.device(storage.device):
+            check(load().tpq_ivfpq_pack_codes(ptr(storage), ptr(packed), cap, m, begin, end,
+                                              stream_ptr(storage.device)), "tpq_ivfpq_pack_codes")
+        return packed
