@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void max_sim_kernel(const float* __restrict__ 
   for (int c0 = 0; c0 < n; c0 += kMsCent) {
     const int nc = (n - c0) < kMsCent ? (n - c0) : kMsCent;
     const int nt = (nc + 31) >> 5;
+    __syncthreads();  // every wave finished the previous chunk's epilogue (reads b2s)
     if (euclidean) {  // |b|^2 of this chunk's centroids, ascending-k fma chain
       const int c = c0 + threadIdx.x;
       float s = 0.f;
