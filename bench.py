@@ -31,23 +31,28 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 
 
-def sift_like(gen, d, n, centers, device):
+def sift_like(gen, d, n, centers, device, noise=30.0):
     """clamp(round(|center + noise|)) in [0, 218]: non-negative, integer-valued, clustered."""
     out = torch.empty(d, n, device=device, dtype=torch.float32)
     step = 1 << 18
     for b in range(0, n, step):
         e = min(n, b + step)
         a = torch.randint(0, centers.shape[1], (e - b,), generator=gen, device=device)
-        x = centers[:, a] + torch.randn(d, e - b, generator=gen, device=device) * 14.0
+        x = centers[:, a] + torch.randn(d, e - b, generator=gen, device=device) * noise
         out[:, b:e] = x.abs().round().clamp_(0, 218)
     return out
+
+
+def make_centers(gen, d, device):
+    # broad, overlapping mixture: k-means cells come out mildly unbalanced, as on real SIFT
+    return torch.randn(d, 256, generator=gen, device=device).abs() * 40.0
 
 
 def build_index(args, device):
     from torchpq_amd.index import IVFPQIndex
     gen = torch.Generator(device=device)
     gen.manual_seed(1234)
-    centers = torch.randn(args.d, 4096, generator=gen, device=device).abs() * 45.0
+    centers = make_centers(gen, args.d, device)
     base = sift_like(gen, args.d, args.n_base, centers, device)
     np.random.seed(1234)
     idx = IVFPQIndex(d_vector=args.d, n_subvectors=args.m, n_cells=args.n_cells,
@@ -136,7 +141,7 @@ def main():
     qgen.manual_seed(4321 + rank)
     cgen = torch.Generator(device=device)
     cgen.manual_seed(1234)
-    centers = torch.randn(args.d, 4096, generator=cgen, device=device).abs() * 45.0
+    centers = make_centers(cgen, args.d, device)
     queries = sift_like(qgen, args.d, args.nq, centers, device)
 
     scan = idx._ivfpq_topk._scan
@@ -173,7 +178,9 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                 "kernel": "scan_packed_kernel" if (args.layout == "packed") else "scan_ref_kernel",
                 "kernel_ms": round(scan_ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
-                "bytes_per_query": round(algo_bytes / args.nq, 1)}
+                "bytes_per_query": round(algo_bytes / args.nq, 1),
+                "cell_imbalance": round(float((idx._cell_size.double() ** 2).sum().item()) * args.n_cells
+                                        / float(idx._cell_size.sum().item()) ** 2, 3)}
 
     out = {
         "metric": "queries/sec + recall@100, SIFT1M IVFPQ d=128 m=64 nprobe=32",

@@ -26,8 +26,8 @@ def test_argument_validation_without_a_gpu():
     assert rc == -1 and "null pointer" in _lib.last_error()
     rc = lib.tpq_ivfpq_pack_codes(None, None, 10, 8, 0, 10, None)
     assert rc == -1
-    assert lib.tpq_ivfpq_scan_workspace_bytes(100, 100, 1) == 0
-    assert lib.tpq_ivfpq_scan_workspace_bytes(100, 100, 4) == 100 * 4 * 128 * 8
+    assert lib.tpq_ivfpq_scan_workspace_bytes(100, 100, 1) == 2 * 512  # flags + error bounds
+    assert lib.tpq_ivfpq_scan_workspace_bytes(100, 100, 4) == 2 * 512 + 100 * 4 * 128 * 8
     assert lib.tpq_compute_centroids_workspace_bytes(2, 3, 5) == (2 * 3 * 5 + 2 * 5) * 4
 
 

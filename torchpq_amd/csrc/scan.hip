@@ -46,6 +46,9 @@ struct ScanArgs {
   int64_t* out_ids;
   float* ws_vals;  // [nq][n_split][64R]
   int* ws_idx;
+  int* flags;             // [nq] packed path: 1 = candidate band overflowed, redo exactly
+  float* ws_delta;        // [nq] packed path: fast-vs-exact error bound of the query
+  const int* only_flagged;  // reference kernel: when set, only queries with a non-zero flag run
   int64_t n_slots;
   int nq, max_nprobe, m, k, n_split;
 };
@@ -190,6 +193,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_ref_kernel(ScanArgs a) {
 
   const int q = blockIdx.x / a.n_split;
   const int part = blockIdx.x - q * a.n_split;
+  if (a.only_flagged && a.only_flagged[q] == 0) return;  // exact redo of flagged queries only
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   int n_probe = (int)a.n_probe_list[q];
@@ -262,33 +266,18 @@ __global__ __launch_bounds__(kScanThreads) void scan_ref_kernel(ScanArgs a) {
 }
 
 // ---- packed-layout kernel ------------------------------------------------------------------
-// LUT in LDS in block order: sub-quantizer block (base b, size B in {64,32,16,8,4}) occupies
-// bytes [b*1024, (b+B)*1024): entry (j, c) at b*1024 + (c*B + (j-b))*4.  A slot at address s
-// stores, at position p of block b, the code of sub-quantizer j = b + ((p-b) ^ (s & (B-1))),
-// so lane (slot s) step p reads dword c*B + ((p-b) ^ (s&(B-1))): its bank differs from every
-// other lane of the half-wave (consecutive s).
-
-struct RefineExact {
-  const uint32_t* codes32;
-  int64_t n_slots;
-  int G;
-  const float* lut;  // packed-order LUT in LDS
-  int m;
-  __device__ __forceinline__ float operator()(float /*v*/, int idx, bool active) const {
-    if (!active) return -INFINITY;
-    float v = 0.f;
-    int j = 0;
-    for (int g = 0; g < G; ++g) {
-      const uint32_t w = codes32[(int64_t)g * n_slots + idx];
-#pragma unroll
-      for (int u = 0; u < 4; ++u, ++j) {
-        const unsigned c = (w >> (8 * u)) & 255u;
-        v += lut[scan_layout::lut_dword(m, j, c)];
-      }
-    }
-    return v;
-  }
-};
+// LUT in LDS in block order (scan_layout.h): entry (j, c) at dword lut_dword(M, j, c); the slot at
+// address s stores at byte position p the code of sub-quantizer subq_at(M, p, s), so lane (slot s)
+// step p reads a bank that differs from every other lane of its half-wave.
+//
+// The permuted order changes the fp32 summation order, so the streamed value f ("fast") is
+// used for SELECTION only: with |f - e| <= delta (e = the reference's ascending-order value),
+// every element of the exact top-k has f >= F_k - 2*delta (F_k = k-th best fast value).  The
+// lists keep the best 64R > k candidates by f; at the end of the query the survivors are
+// re-evaluated exactly (ascending j, from the packed bytes), re-ranked by (e desc, address
+// asc) and the best k written -- bit-identical to the reference-layout kernel.  If more than
+// 64R candidates crowd into the 2*delta band (pathological ties) the query is flagged and
+// redone by scan_ref_kernel.
 
 __device__ __forceinline__ void stage_lut_blocked(const ScanArgs& a, int q, float* lut) {
   // thread handles (j, 4 consecutive c): 16-byte global load, 4 scalar LDS stores.
@@ -307,20 +296,106 @@ __device__ __forceinline__ void stage_lut_blocked(const ScanArgs& a, int q, floa
   }
 }
 
+template <int M>
+struct LdsLut {
+  const float* lut;
+  __device__ __forceinline__ float operator()(int j, unsigned c) const {
+    return lut[scan_layout::lut_dword(M, j, (int)c)];
+  }
+};
+struct GlobalLut {
+  const float* lut;  // [m][nq][256]
+  int nq, q;
+  __device__ __forceinline__ float operator()(int j, unsigned c) const {
+    return lut[((int64_t)j * nq + q) * 256 + c];
+  }
+};
+
+// Exact (ascending-j) value of slot `idx` from its PACKED bytes: the lane un-permutes its slot
+// into sub-quantizer order through a private LDS row (stride M/4+1 dwords: conflict-free), then
+// sums LUT entries in the reference's order.
+template <int M, class LutFn>
+__device__ __forceinline__ float exact_from_packed(const uint8_t* __restrict__ packed,
+                                                   int64_t n_slots, int idx, bool active,
+                                                   uint32_t* scratch, const LutFn& lutfn) {
+  using L = scan_layout::Layout<M>;
+  constexpr int G = M / 4;
+  uint32_t* row = scratch + lane_id() * (G + 1);
+  if (active) {
+    typename L::chunk_t w[L::kChunks];
+    L::load(packed, n_slots, idx, w);
+#pragma unroll
+    for (int d = 0; d < G; ++d) {
+      const scan_layout::BlockAt<M> kb(4 * d);
+      const int sb = idx & (kb.size - 1);
+      const uint32_t x = (uint32_t)(sb & 3);
+      const uint32_t sel = 0x03020100u ^ (x * 0x01010101u);  // out.byte[k] = in.byte[k ^ x]
+      const uint32_t wd = L::word(w, d);
+      const int dst = (kb.base >> 2) + ((d - (kb.base >> 2)) ^ (sb >> 2));
+      row[dst] = __builtin_amdgcn_perm(wd, wd, sel);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  float v = 0.f;
+  if (active) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const uint32_t wd = row[g];
+      v += lutfn(4 * g + 0, wd & 255u);
+      v += lutfn(4 * g + 1, (wd >> 8) & 255u);
+      v += lutfn(4 * g + 2, (wd >> 16) & 255u);
+      v += lutfn(4 * g + 3, wd >> 24);
+    }
+  }
+  return active ? v : -INFINITY;
+}
+
+// wave-level: exact re-evaluation + re-ranking of the surviving candidates, output, overflow flag
+template <int R, int M, class LutFn>
+__device__ __forceinline__ void refine_and_write(const ScanArgs& a, int q, const WaveTopK<R>& fast,
+                                                 float delta2, uint32_t* scratch,
+                                                 const LutFn& lutfn) {
+  const float fk = fast.kth_value(a.k);
+  const float flast = readlane_f(fast.v[R - 1], 63);
+  const int ilast = readlane_i(fast.i[R - 1], 63);
+  const bool overflow = (ilast != kPadIdx) && !(flast < fk - delta2);
+  WaveTopK<R> ex;
+  ex.init();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int idx = fast.i[r];
+    const bool active = idx != kPadIdx;
+    const float e = exact_from_packed<M>(a.packed, a.n_slots, idx, active, scratch, lutfn);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    ex.insert_unsorted(e, active ? idx : kPadIdx);
+  }
+  write_final<R>(a, q, ex);
+  if (lane_id() == 0) a.flags[q] = overflow ? 1 : 0;
+}
+
+constexpr int packed_aux_bytes(int R, int M) {
+  const int lists = 4 * R * 64 * 8;             // 4 lists live at a time in the tree merge
+  const int scratch = 64 * (M / 4 + 1) * 4;     // un-permute rows of the final refinement
+  return lists > scratch ? lists : scratch;
+}
+
+// 2 workgroups per CU (LDS: 2 x (64 KiB LUT + ~14 KiB)) need <= 128 VGPRs: 4 waves per SIMD
 template <int R, int M>
-__global__ __launch_bounds__(kScanThreads) void scan_packed_kernel(ScanArgs a, float margin_rel) {
+__global__ __launch_bounds__(kScanThreads, ((R <= 4 && M <= 64) ? 4 : 2)) void scan_packed_kernel(ScanArgs a,
+                                                                                    float delta_rel) {
   using L = scan_layout::Layout<M>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int lut_bytes = M * 1024;
-  constexpr int list_bytes = kScanWaves * R * 64 * 8;
-  constexpr int region0 = lut_bytes > list_bytes ? lut_bytes : list_bytes;
+  constexpr int aux_bytes = packed_aux_bytes(R, M);
   float* lut = reinterpret_cast<float*>(smem);
-  float* qv_all = reinterpret_cast<float*>(smem + region0);
-  int* qi_all = reinterpret_cast<int*>(smem + region0 + kScanWaves * 256);
-  int* ptab = reinterpret_cast<int*>(smem + region0 + kScanWaves * 512);
+  char* aux = smem + lut_bytes;  // merge lists, then refinement scratch
+  float* qv_all = reinterpret_cast<float*>(smem + lut_bytes + aux_bytes);
+  int* qi_all = reinterpret_cast<int*>(smem + lut_bytes + aux_bytes + kScanWaves * 256);
+  int* ptab = reinterpret_cast<int*>(smem + lut_bytes + aux_bytes + kScanWaves * 512);
   ProbeTable tab{ptab, ptab + a.max_nprobe, ptab + 2 * a.max_nprobe};
   unsigned* tau_key = reinterpret_cast<unsigned*>(ptab + 3 * a.max_nprobe + 1);
-  float* red = reinterpret_cast<float*>(tau_key + 1);  // [kScanWaves] abs-max reduction
+  float* red = reinterpret_cast<float*>(tau_key + 1);  // [kScanWaves] reduction scratch
+  float* wave_q = red + kScanWaves;                    // [kScanWaves] each wave's r-th best
 
   const int q = blockIdx.x / a.n_split;
   const int part = blockIdx.x - q * a.n_split;
@@ -332,59 +407,132 @@ __global__ __launch_bounds__(kScanThreads) void scan_packed_kernel(ScanArgs a, f
   if (wave == 0) {
     build_probe_table(a, q, n_probe, tab);
     if (lane == 0) *tau_key = f2key(-INFINITY);
+    if (lane < kScanWaves) wave_q[lane] = -INFINITY;
   }
   stage_lut_blocked(a, q, lut);
   __syncthreads();
 
-  // Error bound of the permuted-order fp32 sum against the ascending-order one:
-  // |fast - exact| <= 2 (M-1) eps * sum_j max_c |LUT[j][c]|  (eps = 2^-24).  The filter admits
-  // everything within that margin of the threshold; survivors are re-evaluated exactly.
-  float amax = 0.f;
-  for (int i = threadIdx.x; i < M * 256; i += kScanThreads) amax = fmaxf(amax, fabsf(lut[i]));
+  // delta >= |fast - exact|: both are fp32 sums of the same M terms in different orders, each
+  // within (M-1) u * sum|x_i| of the real sum (u = 2^-24), and sum|x_i| <= sum_j max_c|LUT[j][c]|.
+  float part_sum = 0.f;
+  for (int j = wave; j < M; j += kScanWaves) {
+    float mx = 0.f;
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d, 64));
-  if (lane == 0) red[wave] = amax;
+    for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fabsf(lut[scan_layout::lut_dword(M, j, lane * 4 + u)]));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    part_sum += mx;
+  }
+  if (lane == 0) red[wave] = part_sum;
   __syncthreads();
-  amax = red[0];
+  float bound = 0.f;
 #pragma unroll
-  for (int w = 1; w < kScanWaves; ++w) amax = fmaxf(amax, red[w]);
-  const float margin = margin_rel * (float)M * amax;
+  for (int w = 0; w < kScanWaves; ++w) bound += red[w];
+  const float delta2 = 2.f * delta_rel * bound;  // 2*delta: width of the candidate band
 
   WaveSelector<R> sel;
   sel.init(qv_all + wave * 64, qi_all + wave * 64, a.k);
-  RefineExact refine{reinterpret_cast<const uint32_t*>(a.codes), a.n_slots, M / 4, lut, M};
+  NoRefine refine;
 
   const int total_tiles = tab.tile_begin[n_probe];
   const int t_begin = (int)(((int64_t)total_tiles * part) / a.n_split);
   const int t_end = (int)(((int64_t)total_tiles * (part + 1)) / a.n_split);
 
-  typename L::chunk_t w[L::kChunks];
+  // Workgroup-shared admission threshold.  Two valid lower bounds of the final k-th best:
+  //  (a) any wave's own k-th best (tau_key, atomic max);
+  //  (b) min over the 8 waves of each wave's r-th best, r = ceil(k/8): the 8 lists then hold
+  //      >= 8r >= k candidates at or above it.  Tiles are dealt round-robin to the waves, so
+  //      (b) tracks the true k-th best closely and keeps the pass rate near k*ln(N/k)/N.
+  const int r_share = (a.k + kScanWaves - 1) / kScanWaves;
+  auto refresh_tau = [&]() {
+    float t = key2f(*reinterpret_cast<volatile unsigned*>(tau_key));
+    float qmin = reinterpret_cast<volatile float*>(wave_q)[0];
+#pragma unroll
+    for (int w = 1; w < kScanWaves; ++w) qmin = fminf(qmin, reinterpret_cast<volatile float*>(wave_q)[w]);
+    sel.tau = fmaxf(sel.tau, fmaxf(t, qmin));
+  };
+  auto publish = [&](float tau_before) {
+    if (lane == 0) {
+      if (sel.tau > tau_before) atomicMax(tau_key, f2key(sel.tau));
+      wave_q[wave] = sel.top.kth_value(r_share);
+    }
+  };
+
+  struct Tile {
+    int s;
+    bool valid;
+  };
   int p = 0;
-  for (int T = t_begin + wave; T < t_end; T += kScanWaves) {
+  auto locate = [&](int T) -> Tile {
     while (T >= tab.tile_begin[p + 1]) ++p;
     const int off = ((T - tab.tile_begin[p]) << 6) + lane;
-    const bool valid = off < tab.size[p];
-    const int s = tab.start[p] + off;
+    return Tile{tab.start[p] + off, off < tab.size[p]};
+  };
+  auto consume = [&](const typename L::chunk_t(&w)[L::kChunks], const Tile& t) {
     float v = 0.f;
-    bool live = valid;
-    if (valid) {
-      if (a.is_empty) live = (a.is_empty[s] == 0);
-      L::load(a.packed, a.n_slots, s, w);
-      v = L::accumulate(w, s, lut);
+    bool live = t.valid;
+    if (t.valid) {
+      if (a.is_empty) live = (a.is_empty[t.s] == 0);
+      v = L::accumulate(w, t.s, lut);
     }
-    const float tau_s = key2f(*reinterpret_cast<volatile unsigned*>(tau_key));
-    sel.tau = fmaxf(sel.tau, tau_s);
+    refresh_tau();
     const float tau_before = sel.tau;
-    sel.push(live && (v >= sel.tau - margin), v, s, refine);
-    if (sel.tau > tau_before && lane == 0) atomicMax(tau_key, f2key(sel.tau));
+    const int flushes_before = sel.n_flush;
+    sel.push(live && (v >= sel.tau - delta2), v, t.s, refine);
+    if (sel.n_flush != flushes_before) publish(tau_before);
+  };
+
+  // software pipeline: the codes of tile T+8 are in flight while tile T is being consumed
+  typename L::chunk_t w0[L::kChunks], w1[L::kChunks];
+  Tile m0{0, false}, m1{0, false};
+  int T = t_begin + wave;
+  if (T < t_end) {
+    m0 = locate(T);
+    if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
+  }
+  while (T < t_end) {
+    int Tn = T + kScanWaves;
+    if (Tn < t_end) {
+      m1 = locate(Tn);
+      if (m1.valid) L::load(a.packed, a.n_slots, m1.s, w1);
+    }
+    consume(w0, m0);
+    T = Tn;
+    if (T >= t_end) break;
+    Tn = T + kScanWaves;
+    if (Tn < t_end) {
+      m0 = locate(Tn);
+      if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
+    }
+    consume(w1, m1);
+    T = Tn;
   }
   {
     const float tau_before = sel.tau;
     sel.flush(refine);
-    if (sel.tau > tau_before && lane == 0) atomicMax(tau_key, f2key(sel.tau));
+    publish(tau_before);
   }
-  finish_query<R>(a, q, part, sel.top, reinterpret_cast<float*>(smem),
-                  reinterpret_cast<int*>(smem + kScanWaves * R * 64 * 4));
+
+  // tree merge of the 8 per-wave lists (by fast value); the LUT stays live for the refinement
+  float* lv = reinterpret_cast<float*>(aux);
+  int* li = reinterpret_cast<int*>(aux + 4 * R * 64 * 4);
+  for (int stride = 1; stride < kScanWaves; stride <<= 1) {
+    const int slot = wave / (2 * stride);
+    __syncthreads();
+    if ((wave & (2 * stride - 1)) == stride) store_list<R>(sel.top, lv + slot * R * 64, li + slot * R * 64);
+    __syncthreads();
+    if ((wave & (2 * stride - 1)) == 0) merge_list<R>(sel.top, lv + slot * R * 64, li + slot * R * 64);
+  }
+  __syncthreads();
+  if (wave == 0) {
+    if (a.n_split == 1) {
+      refine_and_write<R, M>(a, q, sel.top, delta2, reinterpret_cast<uint32_t*>(aux), LdsLut<M>{lut});
+    } else {
+      const int64_t o = ((int64_t)q * a.n_split + part) * (R * 64);
+      store_list<R>(sel.top, a.ws_vals + o, a.ws_idx + o);
+      if (part == 0 && lane == 0) a.ws_delta[q] = delta2;
+    }
+  }
 }
 
 // ---- split merge ---------------------------------------------------------------------------
@@ -392,6 +540,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_packed_kernel(ScanArgs a, f
 template <int R>
 __global__ __launch_bounds__(64) void scan_merge_kernel(ScanArgs a) {
   const int q = blockIdx.x;
+  if (a.only_flagged && a.only_flagged[q] == 0) return;
   WaveTopK<R> top;
   top.init();
   for (int part = 0; part < a.n_split; ++part) {
@@ -401,21 +550,41 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(ScanArgs a) {
   write_final<R>(a, q, top);
 }
 
-// ---- host side -----------------------------------------------------------------------------
-
-static int list_regs(int k) {
-  int r = (k + 63) / 64;
-  int p = 1;
-  while (p < r) p <<= 1;
-  return p;  // 1, 2, 4, 8, 16
+// packed path: merge the parts' fast lists, then refine exactly (LUT read from global memory)
+template <int R, int M>
+__global__ __launch_bounds__(64) void scan_merge_refine_kernel(ScanArgs a) {
+  __shared__ uint32_t scratch[64 * (M / 4 + 1)];
+  const int q = blockIdx.x;
+  WaveTopK<R> top;
+  top.init();
+  for (int part = 0; part < a.n_split; ++part) {
+    const int64_t o = ((int64_t)q * a.n_split + part) * (R * 64);
+    merge_list<R>(top, a.ws_vals + o, a.ws_idx + o);
+  }
+  refine_and_write<R, M>(a, q, top, a.ws_delta[q], scratch, GlobalLut{a.lut, a.nq, q});
 }
 
-static size_t scan_lds_bytes(int m, int R, int max_nprobe) {
+// ---- host side -----------------------------------------------------------------------------
+
+static int pow2_ceil(int r) {
+  int p = 1;
+  while (p < r) p <<= 1;
+  return p;
+}
+static int list_regs(int k) { return pow2_ceil((k + 63) / 64); }  // 1, 2, 4, 8, 16
+constexpr int kBandSlack = 8;  // spare list entries the packed path wants beyond k
+static int list_regs_packed(int k) { return pow2_ceil((k + kBandSlack + 63) / 64); }
+
+static size_t scan_lds_bytes_ref(int m, int R, int max_nprobe) {
   const int lut_bytes = m * 1024;
   const int list_bytes = kScanWaves * R * 64 * 8;
   const int region0 = lut_bytes > list_bytes ? lut_bytes : list_bytes;
-  size_t b = (size_t)region0 + kScanWaves * 512 + (size_t)(3 * max_nprobe + 1) * 4 + 4 +
-             kScanWaves * 4;
+  size_t b = (size_t)region0 + kScanWaves * 512 + (size_t)(3 * max_nprobe + 1) * 4 + 4;
+  return (b + 15) & ~(size_t)15;
+}
+static size_t scan_lds_bytes_packed(int m, int R, int max_nprobe) {
+  size_t b = (size_t)m * 1024 + packed_aux_bytes(R, m) + kScanWaves * 512 +
+             (size_t)(3 * max_nprobe + 1) * 4 + 4 + 2 * kScanWaves * 4;
   return (b + 15) & ~(size_t)15;
 }
 
@@ -430,7 +599,25 @@ static int set_lds(K kernel, size_t bytes, const char* name) {
                    name);
 }
 
-static int validate(const ScanArgs& a, const void* ws, size_t ws_bytes) {
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// workspace: [flags nq*4][delta nq*4][split lists nq*n_split*64R*8]
+static size_t ws_bytes_for(int nq, int R, int n_split) {
+  size_t b = 2 * align256((size_t)nq * 4);
+  if (n_split > 1) b += (size_t)nq * n_split * R * 64 * 8;
+  return b;
+}
+
+static void fill_ws(ScanArgs& a, void* workspace, int R) {
+  char* p = reinterpret_cast<char*>(workspace);
+  a.flags = reinterpret_cast<int*>(p);
+  a.ws_delta = reinterpret_cast<float*>(p + align256((size_t)a.nq * 4));
+  char* lists = p + 2 * align256((size_t)a.nq * 4);
+  a.ws_vals = reinterpret_cast<float*>(lists);
+  a.ws_idx = reinterpret_cast<int*>(lists + (size_t)a.nq * a.n_split * R * 64 * 4);
+}
+
+static int validate(const ScanArgs& a) {
   TPQ_REQUIRE(a.codes && a.lut && a.cell_start && a.cell_size && a.n_probe_list && a.out_vals &&
                   a.out_addr,
               "ivfpq_scan: null pointer argument");
@@ -443,19 +630,20 @@ static int validate(const ScanArgs& a, const void* ws, size_t ws_bytes) {
   TPQ_REQUIRE(a.n_split >= 1 && a.n_split <= 1024, "ivfpq_scan: n_split=%d out of range", a.n_split);
   TPQ_REQUIRE((a.out_ids == nullptr) || (a.address2id != nullptr),
               "ivfpq_scan: out_ids given without address2id");
-  if (a.n_split > 1) {
-    const size_t need = tpq_ivfpq_scan_workspace_bytes(a.nq, a.k, a.n_split);
-    if (!ws || ws_bytes < need) {
-      set_error("ivfpq_scan: workspace too small (%zu < %zu)", ws_bytes, need);
-      return TPQ_ERR_WORKSPACE;
-    }
+  return TPQ_OK;
+}
+
+static int need_ws(const void* ws, size_t have, size_t need, const char* who) {
+  if (need && (!ws || have < need)) {
+    set_error("%s: workspace too small (%zu < %zu)", who, have, need);
+    return TPQ_ERR_WORKSPACE;
   }
   return TPQ_OK;
 }
 
 template <int R>
 static int launch_ref(ScanArgs a, hipStream_t st) {
-  const size_t lds = scan_lds_bytes(a.m, R, a.max_nprobe);
+  const size_t lds = scan_lds_bytes_ref(a.m, R, a.max_nprobe);
   int rc = set_lds(scan_ref_kernel<R>, lds, "scan_ref_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(scan_ref_kernel<R>, dim3((unsigned)a.nq * a.n_split), dim3(kScanThreads), lds,
@@ -468,18 +656,29 @@ static int launch_ref(ScanArgs a, hipStream_t st) {
   return TPQ_OK;
 }
 
+static int dispatch_ref(const ScanArgs& a, int R, hipStream_t st) {
+  switch (R) {
+    case 1: return launch_ref<1>(a, st);
+    case 2: return launch_ref<2>(a, st);
+    case 4: return launch_ref<4>(a, st);
+    case 8: return launch_ref<8>(a, st);
+    default: return launch_ref<16>(a, st);
+  }
+}
+
 template <int R, int M>
 static int launch_packed(ScanArgs a, hipStream_t st) {
-  const size_t lds = scan_lds_bytes(M, R, a.max_nprobe);
+  const size_t lds = scan_lds_bytes_packed(M, R, a.max_nprobe);
   int rc = set_lds(scan_packed_kernel<R, M>, lds, "scan_packed_kernel");
   if (rc) return rc;
-  const float margin_rel = 2.0f * 5.9604645e-8f * (float)(M - 1);
+  // delta = 1.05 * 2 (M-1) u * sum_j max|LUT_j|,  u = 2^-24
+  const float delta_rel = 1.05f * 2.0f * 5.9604645e-8f * (float)(M - 1);
   hipLaunchKernelGGL((scan_packed_kernel<R, M>), dim3((unsigned)a.nq * a.n_split),
-                     dim3(kScanThreads), lds, st, a, margin_rel);
+                     dim3(kScanThreads), lds, st, a, delta_rel);
   TPQ_LAUNCH_CHECK("scan_packed_kernel");
   if (a.n_split > 1) {
-    hipLaunchKernelGGL(scan_merge_kernel<R>, dim3(a.nq), dim3(64), 0, st, a);
-    TPQ_LAUNCH_CHECK("scan_merge_kernel");
+    hipLaunchKernelGGL((scan_merge_refine_kernel<R, M>), dim3(a.nq), dim3(64), 0, st, a);
+    TPQ_LAUNCH_CHECK("scan_merge_refine_kernel");
   }
   return TPQ_OK;
 }
@@ -500,15 +699,9 @@ static int dispatch_packed(const ScanArgs& a, int R, hipStream_t st) {
 using namespace tpq;
 
 extern "C" size_t tpq_ivfpq_scan_workspace_bytes(int nq, int k, int n_split) {
-  if (n_split <= 1 || nq <= 0 || k <= 0) return 0;
-  return (size_t)nq * n_split * list_regs(k) * 64 * 8;
-}
-
-static void fill_ws(ScanArgs& a, void* workspace) {
-  const int R = list_regs(a.k);
-  a.ws_vals = reinterpret_cast<float*>(workspace);
-  a.ws_idx = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) +
-                                    (size_t)a.nq * a.n_split * R * 64 * 4);
+  if (nq <= 0 || k <= 0) return 0;
+  const int R = list_regs_packed(k) > list_regs(k) ? list_regs_packed(k) : list_regs(k);
+  return ws_bytes_for(nq, R > 16 ? 16 : R, n_split < 1 ? 1 : n_split);
 }
 
 extern "C" int tpq_ivfpq_scan_topk(const uint8_t* codes, const float* lut, const uint8_t* is_empty,
@@ -518,19 +711,18 @@ extern "C" int tpq_ivfpq_scan_topk(const uint8_t* codes, const float* lut, const
                                    int nq, int max_nprobe, int m, int k, int n_split,
                                    void* workspace, size_t workspace_bytes, tpq_stream_t stream) {
   ScanArgs a{codes, nullptr, lut, is_empty, cell_start, cell_size, n_probe_list, out_vals, out_addr,
-             address2id, out_ids, nullptr, nullptr, n_slots, nq, max_nprobe, m, k, n_split};
-  int rc = validate(a, workspace, workspace_bytes);
+             address2id, out_ids, nullptr, nullptr, nullptr, nullptr, nullptr, n_slots, nq,
+             max_nprobe, m, k, n_split};
+  int rc = validate(a);
   if (rc) return rc;
   if (nq == 0) return TPQ_OK;
-  fill_ws(a, workspace);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  switch (list_regs(k)) {
-    case 1: return launch_ref<1>(a, st);
-    case 2: return launch_ref<2>(a, st);
-    case 4: return launch_ref<4>(a, st);
-    case 8: return launch_ref<8>(a, st);
-    default: return launch_ref<16>(a, st);
+  const int R = list_regs(k);
+  if (n_split > 1) {
+    rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, R, n_split), "ivfpq_scan");
+    if (rc) return rc;
+    fill_ws(a, workspace, R);
   }
+  return dispatch_ref(a, R, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int tpq_ivfpq_scan_topk_packed(const uint8_t* packed, const uint8_t* codes,
@@ -542,23 +734,41 @@ extern "C" int tpq_ivfpq_scan_topk_packed(const uint8_t* packed, const uint8_t* 
                                           int m, int k, int n_split, void* workspace,
                                           size_t workspace_bytes, tpq_stream_t stream) {
   ScanArgs a{codes, packed, lut, is_empty, cell_start, cell_size, n_probe_list, out_vals, out_addr,
-             address2id, out_ids, nullptr, nullptr, n_slots, nq, max_nprobe, m, k, n_split};
-  int rc = validate(a, workspace, workspace_bytes);
+             address2id, out_ids, nullptr, nullptr, nullptr, nullptr, nullptr, n_slots, nq,
+             max_nprobe, m, k, n_split};
+  int rc = validate(a);
   if (rc) return rc;
   TPQ_REQUIRE(packed != nullptr, "ivfpq_scan_packed: null packed pointer");
   if (nq == 0) return TPQ_OK;
-  fill_ws(a, workspace);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int R = list_regs(k);
+  const int R = list_regs_packed(k);
+  if (R > 16) {  // k within kBandSlack of 1024: no room for the candidate band, scan exactly
+    const int Rr = list_regs(k);
+    if (n_split > 1) {
+      rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, Rr, n_split), "ivfpq_scan_packed");
+      if (rc) return rc;
+      fill_ws(a, workspace, Rr);
+    }
+    return dispatch_ref(a, Rr, st);
+  }
+  rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, R, n_split), "ivfpq_scan_packed");
+  if (rc) return rc;
+  fill_ws(a, workspace, R);
   switch (m) {
-    case 8: return dispatch_packed<8>(a, R, st);
-    case 16: return dispatch_packed<16>(a, R, st);
-    case 32: return dispatch_packed<32>(a, R, st);
-    case 64: return dispatch_packed<64>(a, R, st);
-    case 120: return dispatch_packed<120>(a, R, st);
+    case 8: rc = dispatch_packed<8>(a, R, st); break;
+    case 16: rc = dispatch_packed<16>(a, R, st); break;
+    case 32: rc = dispatch_packed<32>(a, R, st); break;
+    case 64: rc = dispatch_packed<64>(a, R, st); break;
+    case 120: rc = dispatch_packed<120>(a, R, st); break;
     default:
       set_error("ivfpq_scan_packed: no packed kernel instantiated for n_subvectors=%d "
                 "(available: 8, 16, 32, 64, 120); use tpq_ivfpq_scan_topk", m);
       return TPQ_ERR_UNSUPPORTED;
   }
+  if (rc) return rc;
+  // exact redo of the (normally zero) queries whose candidate band overflowed
+  ScanArgs b = a;
+  b.n_split = 1;
+  b.only_flagged = a.flags;
+  return dispatch_ref(b, list_regs(k), st);
 }

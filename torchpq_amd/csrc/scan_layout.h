@@ -63,6 +63,14 @@ __host__ __device__ constexpr int64_t packed_offset(int m, int64_t n_slots, int 
   return ((int64_t)(p / W) * n_slots + s) * W + (p % W);
 }
 
+// compile-time block lookup usable inside fully unrolled loops
+template <int M>
+struct BlockAt {
+  int base, size;
+  __host__ __device__ constexpr explicit BlockAt(int p)
+      : base(block_of(M, p).base), size(block_of(M, p).size) {}
+};
+
 template <int W>
 struct ChunkT;
 template <>
@@ -104,27 +112,31 @@ struct Layout {
     }
   }
 
-  // sum over byte positions p ascending of LUT(subq_at(p, s), byte_p)  -- permuted order
+  // sum over byte positions p ascending of LUT(subq_at(p, s), byte_p)  -- permuted order.
+  // 64-blocks (256 B per code row) build the LDS byte address with ONE v_perm_b32:
+  //   {0, 0, code byte, (s&63)<<2}  ^  (p<<2)   ==  code*256 + ((p ^ (s&63)) * 4)
+  // (2 VALU + 1 add per look-up, no per-position address registers kept live).
   __device__ static __forceinline__ float accumulate(const chunk_t (&w)[kChunks], int s,
                                                      const float* __restrict__ lut) {
     float v = 0.f;
+    const uint32_t lane64 = (uint32_t)(s & 63) << 2;
+    const char* __restrict__ lut_bytes = reinterpret_cast<const char*>(lut);
 #pragma unroll
     for (int p = 0; p < M; ++p) {
-      constexpr_block<M> kb(p);
+      const BlockAt<M> kb(p);
       const uint32_t wd = word(w, p >> 2);
-      const unsigned c = (wd >> (8 * (p & 3))) & 255u;
-      const int lane_part = (p - kb.base) ^ (s & (kb.size - 1));
-      v += lut[kb.base * 256 + (int)c * kb.size + lane_part];
+      if (kb.size == 64) {
+        const uint32_t sel = 0x0c0c0000u | ((4u + (uint32_t)(p & 3)) << 8);
+        const uint32_t a = __builtin_amdgcn_perm(wd, lane64, sel) ^ ((uint32_t)(p - kb.base) << 2);
+        v += *reinterpret_cast<const float*>(lut_bytes + kb.base * 1024 + a);
+      } else {
+        const unsigned c = (wd >> (8 * (p & 3))) & 255u;
+        const int lane_part = (p - kb.base) ^ (s & (kb.size - 1));
+        v += lut[kb.base * 256 + (int)c * kb.size + lane_part];
+      }
     }
     return v;
   }
-
-  template <int MM>
-  struct constexpr_block {
-    int base, size;
-    __device__ __forceinline__ constexpr explicit constexpr_block(int p)
-        : base(block_of(MM, p).base), size(block_of(MM, p).size) {}
-  };
 };
 
 }  // namespace scan_layout

@@ -176,6 +176,7 @@ struct WaveSelector {
   int qn;     // wave-uniform
   float tau;  // admission threshold: candidates with v < tau cannot reach the final top-k
   int k;
+  int n_flush;  // flushes so far (wave-uniform)
 
   __device__ __forceinline__ void init(float* qv_, int* qi_, int k_) {
     top.init();
@@ -184,6 +185,7 @@ struct WaveSelector {
     qn = 0;
     tau = -INFINITY;
     k = k_;
+    n_flush = 0;
   }
 
   template <class Refine>
@@ -196,6 +198,7 @@ struct WaveSelector {
     int bi = act ? qi[lane] : kPadIdx;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     qn = 0;
+    ++n_flush;
     bv = refine(bv, bi, act);
     if (!(bv >= tau)) {  // refined value fell under the threshold (or NaN): drop
       bv = -INFINITY;
