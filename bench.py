@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--n-probe", type=int, default=32)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--layout", choices=["packed", "ref"], default="packed")
-    ap.add_argument("--cpu-sample", type=int, default=256)
+    ap.add_argument("--cpu-sample", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -181,6 +181,18 @@ def main():
                 "bytes_per_query": round(algo_bytes / args.nq, 1),
                 "cell_imbalance": round(float((idx._cell_size.double() ** 2).sum().item()) * args.n_cells
                                         / float(idx._cell_size.sum().item()) ** 2, 3)}
+
+    # HBM-side bytes per launch come from a separate rocprofv3 --pmc pass over this same command
+    # (FETCH_SIZE, corrected as MI355X_MICROARCH.md prescribes); the committed summary is read back
+    prof = os.path.join(ROOT, "profiles", "r01_bench_scan_packed.json")
+    if args.layout == "packed" and os.path.exists(prof):
+        try:
+            pj = json.load(open(prof))
+            if abs(pj["algorithmic_bytes_per_launch"] - algo_bytes) <= 0.02 * algo_bytes:
+                roofline["traffic"] = round(pj["hbm_side_read_bytes_corrected"])
+                roofline["traffic_source"] = "profiles/r01_bench_scan_packed.json (rocprofv3 --pmc FETCH_SIZE x2)"
+        except Exception:
+            pass
 
     out = {
         "metric": "queries/sec + recall@100, SIFT1M IVFPQ d=128 m=64 nprobe=32",
