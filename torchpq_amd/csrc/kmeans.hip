@@ -120,16 +120,143 @@ __global__ __launch_bounds__(256) void max_sim_kernel(const float* __restrict__ 
   }
 }
 
+// ---- assign, codebook-sized problems (n <= 256 centroids, d <= 128): the PQ train/encode shape --
+// All centroids of sub-problem b are staged in LDS ONCE per block ([d][256] fp32, <= 128 KiB) and
+// the block then walks kMsTiles point tiles.  Per tile a wave pre-loads its whole data fragment
+// (DH = d/2 registers, loads issued back to back) before the MFMA loop, so the matrix pipe is fed
+// from registers + LDS only: 8 independent 32x32 accumulators, 8 ds_read_b32 per 8 MFMAs.
+constexpr int kMsTiles = 8;  // 128-point tiles per block
+
+template <int DH, bool euclidean>
+__global__ __launch_bounds__(256, (DH <= 32 ? 2 : 1)) void max_sim_codebook_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ vals,
+    int64_t* __restrict__ inds, int d, int m, int n) {
+  extern __shared__ __attribute__((aligned(16))) float msh[];
+  float* cs = msh;                   // [2*DH][256], zero beyond (d, n)
+  float* b2s = msh + 2 * DH * 256;   // [256]: |b|^2 (euclidean) or 0 (inner); padding columns
+                                     // c >= n hold +inf / -inf so that they can never win
+  const int b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l31 = lane & 31, half = lane >> 5;
+  const float* __restrict__ Ab = A + (int64_t)b * d * m;
+  const float* __restrict__ Bb = B + (int64_t)b * d * n;
+
+  for (int e = threadIdx.x; e < 2 * DH * 256; e += 256) {
+    const int k = e >> 8, c = e & 255;
+    cs[e] = (k < d && c < n) ? Bb[(int64_t)k * n + c] : 0.f;
+  }
+  __syncthreads();
+  {
+    const int c = threadIdx.x;
+    float s = 0.f;
+    if (euclidean) {
+      for (int k = 0; k < d; ++k) s = fmaf(cs[k * 256 + c], cs[k * 256 + c], s);
+      if (c >= n) s = INFINITY;
+    } else if (c >= n) {
+      s = -INFINITY;
+    }
+    b2s[c] = s;
+  }
+  __syncthreads();
+
+#pragma unroll 1
+  for (int t = 0; t < kMsTiles; ++t) {
+    const int tile = blockIdx.x * kMsTiles + t;
+    if (tile * 128 >= m) break;
+    const int i = tile * 128 + wave * 32 + l31;
+    const bool iv = i < m;
+    float xf[DH];
+#pragma unroll
+    for (int kk = 0; kk < DH; ++kk) {
+      const int k = 2 * kk + half;
+      xf[kk] = (iv && k < d) ? Ab[(int64_t)k * m + i] : 0.f;
+    }
+    float a2 = 0.f;
+    if (euclidean && iv)
+      for (int k = 0; k < d; ++k) {
+        const float x = Ab[(int64_t)k * m + i];
+        a2 = fmaf(x, x, a2);
+      }
+    // two passes of 4 centroid tiles: 64 accumulator registers instead of 128; the data fragment
+    // is re-used from registers, the LDS traffic is unchanged.  Within a lane the centroid index
+    // grows with (pass, tt, r), so "first maximum" == smallest index.
+    float best = -INFINITY;
+    int besti = 0;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      f32x16 acc[4];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < DH; ++kk) {
+        const float* crow = cs + (2 * kk + half) * 256 + pass * 128 + l31;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+          acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(crow[tt * 32], xf[kk], acc[tt], 0, 0, 0);
+        // keep the scheduler from hoisting every k-step's LDS reads to the top (register blow-up)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = pass * 128 + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float v;
+          if (euclidean) {
+            v = 2.f * acc[tt][r];
+            v = v - a2;
+            v = v - b2s[c];
+          } else {
+            v = acc[tt][r] + b2s[c];
+          }
+          const bool w = v > best;
+          best = w ? v : best;
+          besti = w ? c : besti;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // do not hoist all b2s reads above the compares
+      }
+    }
+    const float ov = __shfl_xor(best, 32, 64);
+    const int oi = __shfl_xor(besti, 32, 64);
+    if (ov > best || (ov == best && oi < besti)) {
+      best = ov;
+      besti = oi;
+    }
+    if (half == 0 && iv) {
+      vals[(int64_t)b * m + i] = best;
+      inds[(int64_t)b * m + i] = besti;
+    }
+  }
+}
+
+template <int DH>
+static int launch_codebook(const float* A, const float* B, float* vals, int64_t* inds, int l, int d,
+                           int m, int n, int euclid, hipStream_t st) {
+  const size_t lds = (size_t)(2 * DH * 256 + 256) * sizeof(float);
+  const dim3 grid((m + 128 * kMsTiles - 1) / (128 * kMsTiles), l);
+  auto go = [&](auto kernel) -> int {
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                       "max_sim_codebook_kernel attr");
+    if (rc) return rc;
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, A, B, vals, inds, d, m, n);
+    TPQ_LAUNCH_CHECK("max_sim_codebook_kernel");
+    return TPQ_OK;
+  };
+  return euclid ? go(max_sim_codebook_kernel<DH, true>) : go(max_sim_codebook_kernel<DH, false>);
+}
+
 // ---- update --------------------------------------------------------------------------------
-constexpr int kCcPoints = 4096;  // points per block
 constexpr int kCcDT = 16;        // dimensions per block
 
-// grid (ceil(n/kCcPoints), ceil(d/kCcDT), l); LDS: [kCcDT][k] sums + [k] counts
+// grid (ceil(n/points), ceil(d/kCcDT), l); LDS: [kCcDT][k] sums + [k] counts
 __global__ __launch_bounds__(256) void centroid_accum_kernel(const float* __restrict__ data,
                                                              const int64_t* __restrict__ labels,
                                                              float* __restrict__ sums,
                                                              float* __restrict__ counts, int d,
-                                                             int64_t n, int k) {
+                                                             int64_t n, int k, int64_t points) {
   extern __shared__ __attribute__((aligned(16))) float sh[];
   float* ssum = sh;               // [kCcDT][k]
   float* scnt = sh + kCcDT * k;   // [k]
@@ -138,15 +265,40 @@ __global__ __launch_bounds__(256) void centroid_accum_kernel(const float* __rest
   const int ne = (d - e0) < kCcDT ? (d - e0) : kCcDT;
   for (int t = threadIdx.x; t < (kCcDT + 1) * k; t += 256) sh[t] = 0.f;
   __syncthreads();
-  const int64_t i0 = (int64_t)blockIdx.x * kCcPoints;
-  const int64_t i1 = (i0 + kCcPoints) < n ? (i0 + kCcPoints) : n;
+  const int64_t i0 = (int64_t)blockIdx.x * points;
+  const int64_t i1 = (i0 + points) < n ? (i0 + points) : n;
   const bool count_here = (blockIdx.y == 0);
-  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-    const int64_t lab = labels[(int64_t)b * n + i];
-    if (lab < 0 || lab >= k) continue;
-    if (count_here) atomicAdd(&scnt[lab], 1.0f);
-    for (int e = 0; e < ne; ++e)
-      atomicAdd(&ssum[e * k + lab], data[((int64_t)b * d + e0 + e) * n + i]);
+  const float* __restrict__ drow = data + ((int64_t)b * d + e0) * n;
+  const int64_t* __restrict__ lrow = labels + (int64_t)b * n;
+  if (ne == kCcDT && (n & 3) == 0) {
+    // full 16-dimension tile, 4 points per thread: 16 independent 16-byte loads in flight per
+    // thread before the first LDS atomic (the scalar loop below is latency-bound: one 4-byte
+    // load per ds_add)
+    for (int64_t i = i0 + (int64_t)threadIdx.x * 4; i < i1; i += 256 * 4) {
+      float4 x[kCcDT];
+#pragma unroll
+      for (int e = 0; e < kCcDT; ++e) x[e] = *reinterpret_cast<const float4*>(drow + (int64_t)e * n + i);
+      const longlong2 la = *reinterpret_cast<const longlong2*>(lrow + i);
+      const longlong2 lb = *reinterpret_cast<const longlong2*>(lrow + i + 2);
+      const long long lab[4] = {la.x, la.y, lb.x, lb.y};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i + u >= i1 || lab[u] < 0 || lab[u] >= k) continue;
+        if (count_here) atomicAdd(&scnt[lab[u]], 1.0f);
+#pragma unroll
+        for (int e = 0; e < kCcDT; ++e) {
+          const float v = u == 0 ? x[e].x : u == 1 ? x[e].y : u == 2 ? x[e].z : x[e].w;
+          atomicAdd(&ssum[e * k + lab[u]], v);
+        }
+      }
+    }
+  } else {
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+      const int64_t lab = lrow[i];
+      if (lab < 0 || lab >= k) continue;
+      if (count_here) atomicAdd(&scnt[lab], 1.0f);
+      for (int e = 0; e < ne; ++e) atomicAdd(&ssum[e * k + lab], drow[(int64_t)e * n + i]);
+    }
   }
   __syncthreads();
   for (int t = threadIdx.x; t < ne * k; t += 256) {
@@ -183,9 +335,20 @@ extern "C" int tpq_max_sim(const float* A, const float* B, float* vals, int64_t*
   TPQ_REQUIRE(metric == TPQ_METRIC_NEG_SQ_L2 || metric == TPQ_METRIC_INNER, "max_sim: bad metric %d", metric);
   TPQ_REQUIRE(l <= 65535, "max_sim: batch l=%d exceeds grid.y", l);
   if (m == 0) return TPQ_OK;
-  hipLaunchKernelGGL(max_sim_kernel, dim3((m + 127) / 128, l), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), A, B, vals, inds, d, m, n,
-                     metric == TPQ_METRIC_NEG_SQ_L2 ? 1 : 0);
+  const int euclid = metric == TPQ_METRIC_NEG_SQ_L2 ? 1 : 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (n <= 256 && d <= 128) {  // PQ codebook shape: centroids resident in LDS
+    const int dh = (d + 1) / 2;
+    if (dh <= 1) return launch_codebook<1>(A, B, vals, inds, l, d, m, n, euclid, st);
+    if (dh <= 2) return launch_codebook<2>(A, B, vals, inds, l, d, m, n, euclid, st);
+    if (dh <= 4) return launch_codebook<4>(A, B, vals, inds, l, d, m, n, euclid, st);
+    if (dh <= 8) return launch_codebook<8>(A, B, vals, inds, l, d, m, n, euclid, st);
+    if (dh <= 16) return launch_codebook<16>(A, B, vals, inds, l, d, m, n, euclid, st);
+    if (dh <= 32) return launch_codebook<32>(A, B, vals, inds, l, d, m, n, euclid, st);
+    return launch_codebook<64>(A, B, vals, inds, l, d, m, n, euclid, st);
+  }
+  hipLaunchKernelGGL(max_sim_kernel, dim3((m + 127) / 128, l), dim3(256), 0, st, A, B, vals, inds,
+                     d, m, n, euclid);
   TPQ_LAUNCH_CHECK("max_sim_kernel");
   return TPQ_OK;
 }
@@ -220,9 +383,16 @@ extern "C" int tpq_compute_centroids(const float* data, const int64_t* labels, f
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                    "centroid_accum_kernel attr");
     if (rc) return rc;
-    hipLaunchKernelGGL(centroid_accum_kernel,
-                       dim3((unsigned)((n + kCcPoints - 1) / kCcPoints), (d + kCcDT - 1) / kCcDT, l),
-                       dim3(256), lds, st, data, labels, sums, counts, d, n, k);
+    // Each block flushes kCcDT*k global atomics, so blocks must own many points; aim for ~8 k
+    // blocks in total (>> 256 CUs) but never fewer than 4096 points per block.
+    const int dtiles = (d + kCcDT - 1) / kCcDT;
+    int64_t chunks = 8192 / ((int64_t)l * dtiles);
+    if (chunks < 1) chunks = 1;
+    int64_t points = (n + chunks - 1) / chunks;
+    if (points < 4096) points = 4096;
+    points = (points + 255) / 256 * 256;
+    hipLaunchKernelGGL(centroid_accum_kernel, dim3((unsigned)((n + points - 1) / points), dtiles, l),
+                       dim3(256), lds, st, data, labels, sums, counts, d, n, k, points);
     TPQ_LAUNCH_CHECK("centroid_accum_kernel");
   }
   const int64_t total = (int64_t)l * d * k;
