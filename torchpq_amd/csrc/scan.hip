@@ -279,13 +279,14 @@ __global__ __launch_bounds__(kScanThreads) void scan_ref_kernel(ScanArgs a) {
 // 64R candidates crowd into the 2*delta band (pathological ties) the query is flagged and
 // redone by scan_ref_kernel.
 
-__device__ __forceinline__ void stage_lut_blocked(const ScanArgs& a, int q, float* lut) {
+__device__ __forceinline__ void stage_lut_blocked(const ScanArgs& a, int q, float* lut,
+                                                  int n_threads) {
   // thread handles (j, 4 consecutive c): 16-byte global load, 4 scalar LDS stores.
   // Consecutive threads take consecutive j for the same c-group so that the LDS stores of a
   // half-wave land in distinct banks.
   const float4* __restrict__ src = reinterpret_cast<const float4*>(a.lut);
   const int m = a.m;
-  for (int i = threadIdx.x; i < m * 64; i += kScanThreads) {
+  for (int i = threadIdx.x; i < m * 64; i += n_threads) {
     const int c4 = i / m, j = i - c4 * m;
     const float4 x = src[((int64_t)j * a.nq + q) * 64 + c4];
     const int c = c4 * 4;
@@ -373,29 +374,34 @@ __device__ __forceinline__ void refine_and_write(const ScanArgs& a, int q, const
   if (lane_id() == 0) a.flags[q] = overflow ? 1 : 0;
 }
 
+// waves per workgroup: 8 while two workgroups share a CU (LUT <= 64 KiB); 16 when the LUT is so
+// large that only one workgroup fits (m > 64, e.g. GIST m=120: 120 KiB) -- same 16 waves per CU
+constexpr int packed_waves(int M) { return M <= 64 ? 8 : 16; }
+
 constexpr int packed_aux_bytes(int R, int M) {
-  const int lists = 4 * R * 64 * 8;             // 4 lists live at a time in the tree merge
+  const int lists = (packed_waves(M) / 2) * R * 64 * 8;  // lists live at a time in the tree merge
   const int scratch = 64 * (M / 4 + 1) * 4;     // un-permute rows of the final refinement
   return lists > scratch ? lists : scratch;
 }
 
 // 2 workgroups per CU (LDS: 2 x (64 KiB LUT + ~14 KiB)) need <= 128 VGPRs: 4 waves per SIMD
 template <int R, int M>
-__global__ __launch_bounds__(kScanThreads, ((R <= 4 && M <= 64) ? 4 : 2)) void scan_packed_kernel(ScanArgs a,
+__global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_packed_kernel(ScanArgs a,
                                                                                     float delta_rel) {
   using L = scan_layout::Layout<M>;
+  constexpr int NW = packed_waves(M);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int lut_bytes = M * 1024;
   constexpr int aux_bytes = packed_aux_bytes(R, M);
   float* lut = reinterpret_cast<float*>(smem);
   char* aux = smem + lut_bytes;  // merge lists, then refinement scratch
   float* qv_all = reinterpret_cast<float*>(smem + lut_bytes + aux_bytes);
-  int* qi_all = reinterpret_cast<int*>(smem + lut_bytes + aux_bytes + kScanWaves * 256);
-  int* ptab = reinterpret_cast<int*>(smem + lut_bytes + aux_bytes + kScanWaves * 512);
+  int* qi_all = reinterpret_cast<int*>(smem + lut_bytes + aux_bytes + NW * 256);
+  int* ptab = reinterpret_cast<int*>(smem + lut_bytes + aux_bytes + NW * 512);
   ProbeTable tab{ptab, ptab + a.max_nprobe, ptab + 2 * a.max_nprobe};
   unsigned* tau_key = reinterpret_cast<unsigned*>(ptab + 3 * a.max_nprobe + 1);
-  float* red = reinterpret_cast<float*>(tau_key + 1);  // [kScanWaves] reduction scratch
-  float* wave_q = red + kScanWaves;                    // [kScanWaves] each wave's r-th best
+  float* red = reinterpret_cast<float*>(tau_key + 1);  // [NW] reduction scratch
+  float* wave_q = red + NW;                    // [NW] each wave's r-th best
 
   const int q = blockIdx.x / a.n_split;
   const int part = blockIdx.x - q * a.n_split;
@@ -407,15 +413,15 @@ __global__ __launch_bounds__(kScanThreads, ((R <= 4 && M <= 64) ? 4 : 2)) void s
   if (wave == 0) {
     build_probe_table(a, q, n_probe, tab);
     if (lane == 0) *tau_key = f2key(-INFINITY);
-    if (lane < kScanWaves) wave_q[lane] = -INFINITY;
+    if (lane < NW) wave_q[lane] = -INFINITY;
   }
-  stage_lut_blocked(a, q, lut);
+  stage_lut_blocked(a, q, lut, NW * 64);
   __syncthreads();
 
   // delta >= |fast - exact|: both are fp32 sums of the same M terms in different orders, each
   // within (M-1) u * sum|x_i| of the real sum (u = 2^-24), and sum|x_i| <= sum_j max_c|LUT[j][c]|.
   float part_sum = 0.f;
-  for (int j = wave; j < M; j += kScanWaves) {
+  for (int j = wave; j < M; j += NW) {
     float mx = 0.f;
 #pragma unroll
     for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fabsf(lut[scan_layout::lut_dword(M, j, lane * 4 + u)]));
@@ -427,7 +433,7 @@ __global__ __launch_bounds__(kScanThreads, ((R <= 4 && M <= 64) ? 4 : 2)) void s
   __syncthreads();
   float bound = 0.f;
 #pragma unroll
-  for (int w = 0; w < kScanWaves; ++w) bound += red[w];
+  for (int w = 0; w < NW; ++w) bound += red[w];
   const float delta2 = 2.f * delta_rel * bound;  // 2*delta: width of the candidate band
 
   WaveSelector<R> sel;
@@ -443,12 +449,12 @@ __global__ __launch_bounds__(kScanThreads, ((R <= 4 && M <= 64) ? 4 : 2)) void s
   //  (b) min over the 8 waves of each wave's r-th best, r = ceil(k/8): the 8 lists then hold
   //      >= 8r >= k candidates at or above it.  Tiles are dealt round-robin to the waves, so
   //      (b) tracks the true k-th best closely and keeps the pass rate near k*ln(N/k)/N.
-  const int r_share = (a.k + kScanWaves - 1) / kScanWaves;
+  const int r_share = (a.k + NW - 1) / NW;
   auto refresh_tau = [&]() {
     float t = key2f(*reinterpret_cast<volatile unsigned*>(tau_key));
     float qmin = reinterpret_cast<volatile float*>(wave_q)[0];
 #pragma unroll
-    for (int w = 1; w < kScanWaves; ++w) qmin = fminf(qmin, reinterpret_cast<volatile float*>(wave_q)[w]);
+    for (int w = 1; w < NW; ++w) qmin = fminf(qmin, reinterpret_cast<volatile float*>(wave_q)[w]);
     sel.tau = fmaxf(sel.tau, fmaxf(t, qmin));
   };
   auto publish = [&](float tau_before) {
@@ -482,30 +488,40 @@ __global__ __launch_bounds__(kScanThreads, ((R <= 4 && M <= 64) ? 4 : 2)) void s
     if (sel.n_flush != flushes_before) publish(tau_before);
   };
 
-  // software pipeline: the codes of tile T+8 are in flight while tile T is being consumed
-  typename L::chunk_t w0[L::kChunks], w1[L::kChunks];
-  Tile m0{0, false}, m1{0, false};
-  int T = t_begin + wave;
-  if (T < t_end) {
-    m0 = locate(T);
-    if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
-  }
-  while (T < t_end) {
-    int Tn = T + kScanWaves;
-    if (Tn < t_end) {
-      m1 = locate(Tn);
-      if (m1.valid) L::load(a.packed, a.n_slots, m1.s, w1);
-    }
-    consume(w0, m0);
-    T = Tn;
-    if (T >= t_end) break;
-    Tn = T + kScanWaves;
-    if (Tn < t_end) {
-      m0 = locate(Tn);
+  // software pipeline: the codes of tile T+NW are in flight while tile T is being consumed
+  // (m <= 64; larger m runs 16 waves per workgroup under a 128-VGPR cap and relies on them)
+  if constexpr (M <= 64) {
+    typename L::chunk_t w0[L::kChunks], w1[L::kChunks];
+    Tile m0{0, false}, m1{0, false};
+    int T = t_begin + wave;
+    if (T < t_end) {
+      m0 = locate(T);
       if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
     }
-    consume(w1, m1);
-    T = Tn;
+    while (T < t_end) {
+      int Tn = T + NW;
+      if (Tn < t_end) {
+        m1 = locate(Tn);
+        if (m1.valid) L::load(a.packed, a.n_slots, m1.s, w1);
+      }
+      consume(w0, m0);
+      T = Tn;
+      if (T >= t_end) break;
+      Tn = T + NW;
+      if (Tn < t_end) {
+        m0 = locate(Tn);
+        if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
+      }
+      consume(w1, m1);
+      T = Tn;
+    }
+  } else {
+    typename L::chunk_t w0[L::kChunks];
+    for (int T = t_begin + wave; T < t_end; T += NW) {
+      const Tile m0 = locate(T);
+      if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
+      consume(w0, m0);
+    }
   }
   {
     const float tau_before = sel.tau;
@@ -515,8 +531,8 @@ __global__ __launch_bounds__(kScanThreads, ((R <= 4 && M <= 64) ? 4 : 2)) void s
 
   // tree merge of the 8 per-wave lists (by fast value); the LUT stays live for the refinement
   float* lv = reinterpret_cast<float*>(aux);
-  int* li = reinterpret_cast<int*>(aux + 4 * R * 64 * 4);
-  for (int stride = 1; stride < kScanWaves; stride <<= 1) {
+  int* li = reinterpret_cast<int*>(aux + (NW / 2) * R * 64 * 4);
+  for (int stride = 1; stride < NW; stride <<= 1) {
     const int slot = wave / (2 * stride);
     __syncthreads();
     if ((wave & (2 * stride - 1)) == stride) store_list<R>(sel.top, lv + slot * R * 64, li + slot * R * 64);
@@ -583,8 +599,9 @@ static size_t scan_lds_bytes_ref(int m, int R, int max_nprobe) {
   return (b + 15) & ~(size_t)15;
 }
 static size_t scan_lds_bytes_packed(int m, int R, int max_nprobe) {
-  size_t b = (size_t)m * 1024 + packed_aux_bytes(R, m) + kScanWaves * 512 +
-             (size_t)(3 * max_nprobe + 1) * 4 + 4 + 2 * kScanWaves * 4;
+  const int nw = packed_waves(m);
+  size_t b = (size_t)m * 1024 + packed_aux_bytes(R, m) + nw * 512 +
+             (size_t)(3 * max_nprobe + 1) * 4 + 4 + 2 * nw * 4;
   return (b + 15) & ~(size_t)15;
 }
 
@@ -674,7 +691,7 @@ static int launch_packed(ScanArgs a, hipStream_t st) {
   // delta = 1.05 * 2 (M-1) u * sum_j max|LUT_j|,  u = 2^-24
   const float delta_rel = 1.05f * 2.0f * 5.9604645e-8f * (float)(M - 1);
   hipLaunchKernelGGL((scan_packed_kernel<R, M>), dim3((unsigned)a.nq * a.n_split),
-                     dim3(kScanThreads), lds, st, a, delta_rel);
+                     dim3(packed_waves(M) * 64), lds, st, a, delta_rel);
   TPQ_LAUNCH_CHECK("scan_packed_kernel");
   if (a.n_split > 1) {
     hipLaunchKernelGGL((scan_merge_refine_kernel<R, M>), dim3(a.nq), dim3(64), 0, st, a);

@@ -54,7 +54,8 @@ class IVFPQTopkHip:
         """Workgroups per query so that small batches still fill the chip (256 CUs x 2)."""
         if self.n_cus is None:
             self.n_cus = torch.cuda.get_device_properties(device).multi_processor_count
-        target = 2 * self.n_cus
+        # two 8-wave workgroups per CU while the LUT is <= 64 KiB, one 16-wave workgroup above
+        target = (2 if self.m <= 64 else 1) * self.n_cus
         if n_query >= target:
             return 1
         return max(1, min(64, target // max(n_query, 1)))
