@@ -312,6 +312,102 @@ __global__ __launch_bounds__(256) void centroid_accum_kernel(const float* __rest
     }
 }
 
+// ---- update, codebook-sized problems (k <= 256) ---------------------------------------------
+// LDS float atomics are the trap here: ds_add_f32 retires ~0.38 lanes per clock per CU on gfx950
+// whatever the access pattern (tools/ubench/lds_atomic.hip: 168 cycles per wave instruction; int
+// atomics are 16x faster), which held the kernel above at 0.8 TB/s.  This kernel uses none:
+// each wave OWNS a 16-dimension slice of the block's 64-dimension tile and keeps private
+// accumulators acc[label][16] in LDS.  A 32-point half-tile is loaded coalesced (lane = point),
+// transposed through a small LDS stage, and then added 4 points per instruction with lanes =
+// (point group g, dimension e): plain ds_read / v_add / ds_write.  Two points of one instruction
+// that share a label are serialised by rank (rare: 4 points, 256 labels).
+constexpr int kCu2Dims = 16;    // dimensions per wave
+constexpr int kCu2Half = 32;    // points per staged half-tile
+
+__global__ __launch_bounds__(256, 2) void centroid_accum_codebook_kernel(
+    const float* __restrict__ data, const int64_t* __restrict__ labels, float* __restrict__ sums,
+    float* __restrict__ counts, int d, int64_t n, int k, int64_t points) {
+  __shared__ float acc_all[4 * 256 * kCu2Dims];                    // 64 KiB: [wave][label][16]
+  __shared__ float stage_all[4 * kCu2Dims * (kCu2Half + 1)];       // [wave][16][33]
+  __shared__ int lab_all[4 * kCu2Half];
+  __shared__ int cnt[256];
+  const int b = blockIdx.z;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int e0 = blockIdx.y * 64 + wave * kCu2Dims;               // first dimension of this wave
+  float* acc = acc_all + wave * 256 * kCu2Dims;
+  float* stage = stage_all + wave * kCu2Dims * (kCu2Half + 1);
+  int* labs = lab_all + wave * kCu2Half;
+  for (int t = lane; t < 256 * kCu2Dims; t += 64) acc[t] = 0.f;
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const bool count_here = (blockIdx.y == 0) && (wave == 0);
+  const int64_t i0 = (int64_t)blockIdx.x * points;
+  const int64_t i1 = (i0 + points) < n ? (i0 + points) : n;
+  const float* __restrict__ drow = data + ((int64_t)b * d + e0) * n;
+  const int64_t* __restrict__ lrow = labels + (int64_t)b * n;
+  const int pl = lane & 31, hl = lane >> 5;   // load phase: point pl, dimension parity hl
+  const int g = lane >> 4, e = lane & 15;     // add phase: point group g, dimension e
+  const bool wave_active = e0 < d;
+
+  if (wave_active) {
+    for (int64_t base = i0; base < i1; base += kCu2Half) {
+      // coalesced loads: lanes 0-31 take even dimensions, lanes 32-63 odd ones (8 loads per lane)
+      const int64_t i = base + pl;
+      const bool pv = i < i1;
+      float x[kCu2Dims / 2];
+#pragma unroll
+      for (int u = 0; u < kCu2Dims / 2; ++u) {
+        const int ee = 2 * u + hl;
+        x[u] = (pv && e0 + ee < d) ? drow[(int64_t)ee * n + i] : 0.f;
+      }
+      int lab = -1;
+      if (lane < kCu2Half && pv) {
+        const int64_t l64 = lrow[i];
+        lab = (l64 >= 0 && l64 < k) ? (int)l64 : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kCu2Dims / 2; ++u) stage[(2 * u + hl) * (kCu2Half + 1) + pl] = x[u];
+      if (lane < kCu2Half) {
+        labs[lane] = lab;
+        if (count_here && lab >= 0) atomicAdd(&cnt[lab], 1);  // integer LDS atomic: fast
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll 2
+      for (int t = 0; t < kCu2Half / 4; ++t) {
+        const int p = 4 * t + g;
+        const float v = stage[e * (kCu2Half + 1) + p];
+        const int l0 = labs[4 * t + 0], l1 = labs[4 * t + 1], l2 = labs[4 * t + 2], l3 = labs[4 * t + 3];
+        const int mine = g == 0 ? l0 : g == 1 ? l1 : g == 2 ? l2 : l3;
+        // rank = earlier groups of this instruction with the same label
+        const int rank = (g > 0 && l0 == mine) + (g > 1 && l1 == mine) + (g > 2 && l2 == mine);
+        const int maxdup = (l0 == l1) + (l0 == l2) + (l0 == l3) + (l1 == l2) + (l1 == l3) + (l2 == l3);
+        if (maxdup == 0) {  // wave-uniform (labels are the same values in every lane)
+          if (mine >= 0) acc[mine * kCu2Dims + e] += v;
+        } else {
+          for (int r = 0; r < 4; ++r) {
+            if (mine >= 0 && rank == r) acc[mine * kCu2Dims + e] += v;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+  }
+  __syncthreads();
+  if (wave_active) {
+    for (int t = lane; t < 256 * kCu2Dims; t += 64) {
+      const int lab = t >> 4, ee = t & 15;
+      const float v = acc[t];
+      if (lab < k && e0 + ee < d && v != 0.f)
+        unsafeAtomicAdd(&sums[((int64_t)b * d + e0 + ee) * k + lab], v);
+    }
+  }
+  if (blockIdx.y == 0 && threadIdx.x < k) {
+    const int c = cnt[threadIdx.x];
+    if (c) unsafeAtomicAdd(&counts[(int64_t)b * k + threadIdx.x], (float)c);
+  }
+}
+
 __global__ __launch_bounds__(256) void centroid_finalize_kernel(const float* __restrict__ sums,
                                                                const float* __restrict__ counts,
                                                                float* __restrict__ out, int d, int k,
@@ -383,6 +479,24 @@ extern "C" int tpq_compute_centroids(const float* data, const int64_t* labels, f
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                    "centroid_accum_kernel attr");
     if (rc) return rc;
+    if (k <= 256 && d >= 32) {  // wide PQ-codebook shape: atomic-free LDS accumulation
+      // (below 32 dimensions most of a wave's 16-dimension slice would idle: use the kernel below)
+      const int dt64 = (d + 63) / 64;
+      int64_t chunks = 2048 / ((int64_t)l * dt64);
+      if (chunks < 1) chunks = 1;
+      int64_t points = (n + chunks - 1) / chunks;
+      if (points < 2048) points = 2048;
+      points = (points + kCu2Half - 1) / kCu2Half * kCu2Half;
+      hipLaunchKernelGGL(centroid_accum_codebook_kernel,
+                         dim3((unsigned)((n + points - 1) / points), dt64, l), dim3(256), 0, st, data,
+                         labels, sums, counts, d, n, k, points);
+      TPQ_LAUNCH_CHECK("centroid_accum_codebook_kernel");
+      const int64_t total = (int64_t)l * d * k;
+      hipLaunchKernelGGL(centroid_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
+                         0, st, sums, counts, centroids, d, k, total);
+      TPQ_LAUNCH_CHECK("centroid_finalize_kernel");
+      return TPQ_OK;
+    }
     // Each block flushes kCcDT*k global atomics, so blocks must own many points; aim for ~8 k
     // blocks in total (>> 256 CUs) but never fewer than 4096 points per block.
     const int dtiles = (d + kCcDT - 1) / kCcDT;
