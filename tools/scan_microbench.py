@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--n-split", type=int, default=None)
     ap.add_argument("--neighbors", action="store_true",
                     help="queries probe a window of adjacent cells (correlated probe lists)")
+    ap.add_argument("--sort", action="store_true", help="with --neighbors: sort queries by first cell")
     ap.add_argument("--check", action="store_true")
     args = ap.parse_args()
     from torchpq_amd import kernels as K
@@ -43,6 +44,8 @@ def main():
     lut = torch.randn(m, args.nq, 256, generator=g, device=dev) * 50 - 300
     if args.neighbors:
         base = torch.randint(0, nc, (args.nq, 1), generator=g, device=dev)
+        if args.sort:
+            base = base.sort(0).values
         cells = (base + torch.arange(args.n_probe, device=dev)[None, :]) % nc
     else:
         cells = torch.rand(args.nq, nc, generator=g, device=dev).argsort(1)[:, :args.n_probe].contiguous()

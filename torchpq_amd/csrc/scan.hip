@@ -450,17 +450,17 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
   //      >= 8r >= k candidates at or above it.  Tiles are dealt round-robin to the waves, so
   //      (b) tracks the true k-th best closely and keeps the pass rate near k*ln(N/k)/N.
   const int r_share = (a.k + NW - 1) / NW;
+  // readers poll ONE word per tile; the (rare) publisher folds bound (b) into it
   auto refresh_tau = [&]() {
-    float t = key2f(*reinterpret_cast<volatile unsigned*>(tau_key));
-    float qmin = reinterpret_cast<volatile float*>(wave_q)[0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) qmin = fminf(qmin, reinterpret_cast<volatile float*>(wave_q)[w]);
-    sel.tau = fmaxf(sel.tau, fmaxf(t, qmin));
+    sel.tau = fmaxf(sel.tau, key2f(*reinterpret_cast<volatile unsigned*>(tau_key)));
   };
-  auto publish = [&](float tau_before) {
+  auto publish = [&](float /*tau_before*/) {
     if (lane == 0) {
-      if (sel.tau > tau_before) atomicMax(tau_key, f2key(sel.tau));
-      wave_q[wave] = sel.top.kth_value(r_share);
+      reinterpret_cast<volatile float*>(wave_q)[wave] = sel.top.kth_value(r_share);
+      float qmin = reinterpret_cast<volatile float*>(wave_q)[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) qmin = fminf(qmin, reinterpret_cast<volatile float*>(wave_q)[w]);
+      atomicMax(tau_key, f2key(fmaxf(sel.tau, qmin)));
     }
   };
 

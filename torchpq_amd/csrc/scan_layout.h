@@ -118,24 +118,42 @@ struct Layout {
   // (2 VALU + 1 add per look-up, no per-position address registers kept live).
   __device__ static __forceinline__ float accumulate(const chunk_t (&w)[kChunks], int s,
                                                      const float* __restrict__ lut) {
-    float v = 0.f;
-    const uint32_t lane64 = (uint32_t)(s & 63) << 2;
+    // The fast value is used for selection only, so its summation order is free: two
+    // interleaved partial sums (even / odd positions) halve the add chain and let the
+    // compiler use v_pk_add_f32.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc = {0.f, 0.f};
+    // lane constants of a 64-block: for each 16-position quarter h the low byte of the LDS
+    // address, ((h ^ s[5:4]) << 6) | (s[3:0] << 2); the per-position remainder (p & 15) << 2 is
+    // then an inline constant (<= 60) and the XOR fuses into one v_xad_u32.
+    uint32_t lane64[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+      lane64[h] = ((((uint32_t)h ^ ((uint32_t)(s >> 4) & 3u)) << 6) | (((uint32_t)s & 15u) << 2));
     const char* __restrict__ lut_bytes = reinterpret_cast<const char*>(lut);
 #pragma unroll
-    for (int p = 0; p < M; ++p) {
-      const BlockAt<M> kb(p);
-      const uint32_t wd = word(w, p >> 2);
-      if (kb.size == 64) {
-        const uint32_t sel = 0x0c0c0000u | ((4u + (uint32_t)(p & 3)) << 8);
-        const uint32_t a = __builtin_amdgcn_perm(wd, lane64, sel) ^ ((uint32_t)(p - kb.base) << 2);
-        v += *reinterpret_cast<const float*>(lut_bytes + kb.base * 1024 + a);
-      } else {
-        const unsigned c = (wd >> (8 * (p & 3))) & 255u;
-        const int lane_part = (p - kb.base) ^ (s & (kb.size - 1));
-        v += lut[kb.base * 256 + (int)c * kb.size + lane_part];
+    for (int p = 0; p < M; p += 2) {
+      float t[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int pp = p + u;
+        const BlockAt<M> kb(pp);
+        const uint32_t wd = word(w, pp >> 2);
+        if (kb.size == 64) {
+          const int rel = pp - kb.base;
+          const uint32_t sel = 0x0c0c0000u | ((4u + (uint32_t)(pp & 3)) << 8);
+          const uint32_t a = __builtin_amdgcn_perm(wd, lane64[rel >> 4], sel) ^ ((uint32_t)(rel & 15) << 2);
+          t[u] = *reinterpret_cast<const float*>(lut_bytes + kb.base * 1024 + a);
+        } else {
+          const unsigned c = (wd >> (8 * (pp & 3))) & 255u;
+          const int lane_part = (pp - kb.base) ^ (s & (kb.size - 1));
+          t[u] = lut[kb.base * 256 + (int)c * kb.size + lane_part];
+        }
       }
+      const f32x2 tv = {t[0], t[1]};
+      acc += tv;
     }
-    return v;
+    return acc.x + acc.y;
   }
 };
 
