@@ -61,13 +61,14 @@ const char* tpq_last_error(void);
  * out_ids                               BaseContainer.get_id_by_address(out_addr)
  *                                       (torchpq/container/BaseContainer.py:58-65)
  * n_split      workgroups per query (>=1); >1 needs workspace of
- *              tpq_ivfpq_scan_workspace_bytes(nq, k, n_split)
+ *              tpq_ivfpq_scan_workspace_bytes(nq, k, n_split, m) (the packed variant always
+ *              needs it: per-wave candidate lists are merged by a second kernel)
  *
  * value(slot) = 0.f; for j = 0..m-1 ascending: value += lut[j][q][code_j]  (fp32,
  * the order of consume_data, ivfpq_topk.cu:662-679).  Ordering: value descending,
  * exact ties by ascending address.  1 <= k <= 1024, m % 4 == 0, m <= 156.
  * ------------------------------------------------------------------------- */
-size_t tpq_ivfpq_scan_workspace_bytes(int nq, int k, int n_split);
+size_t tpq_ivfpq_scan_workspace_bytes(int nq, int k, int n_split, int m);
 
 int tpq_ivfpq_scan_topk(const uint8_t* codes, const float* lut, const uint8_t* is_empty,
                         const int64_t* cell_start, const int64_t* cell_size,

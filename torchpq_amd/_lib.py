@@ -22,7 +22,7 @@ _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 SIGNATURES = {
     "tpq_version": (_i, []),
     "tpq_last_error": (C.c_char_p, []),
-    "tpq_ivfpq_scan_workspace_bytes": (_sz, [_i, _i, _i]),
+    "tpq_ivfpq_scan_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "tpq_ivfpq_scan_topk": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i,
                                  _i, _i, _vp, _sz, _vp]),
     "tpq_ivfpq_pack_codes": (_i, [_vp, _vp, _i64, _i, _i64, _i64, _vp]),

@@ -93,13 +93,14 @@ __device__ __forceinline__ void build_probe_table(const ScanArgs& a, int q, int 
   if (lane == 0) t.tile_begin[n_probe] = running;
 }
 
+// lists travel as keys: `lv` holds the high words (value images), `li` the low words (~index)
 template <int R>
 __device__ __forceinline__ void store_list(const WaveTopK<R>& top, float* lv, int* li) {
   const int lane = lane_id();
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    lv[r * 64 + lane] = top.v[r];
-    li[r * 64 + lane] = top.i[r];
+    reinterpret_cast<unsigned*>(lv)[r * 64 + lane] = top.k[r].hi;
+    reinterpret_cast<unsigned*>(li)[r * 64 + lane] = top.k[r].lo;
   }
 }
 
@@ -107,7 +108,9 @@ template <int R>
 __device__ __forceinline__ void merge_list(WaveTopK<R>& top, const float* lv, const int* li) {
   const int lane = lane_id();
 #pragma unroll
-  for (int r = 0; r < R; ++r) top.insert_sorted(lv[r * 64 + lane], li[r * 64 + lane]);
+  for (int r = 0; r < R; ++r)
+    top.insert_sorted(Key{reinterpret_cast<const unsigned*>(lv)[r * 64 + lane],
+                          reinterpret_cast<const unsigned*>(li)[r * 64 + lane]});
 }
 
 template <int R>
@@ -117,10 +120,10 @@ __device__ __forceinline__ void write_final(const ScanArgs& a, int q, const Wave
   for (int r = 0; r < R; ++r) {
     const int e = r * 64 + lane;
     if (e < a.k) {
-      const int idx = top.i[r];
+      const int idx = key_index(top.k[r]);
       const bool pad = (idx == kPadIdx);
       const int64_t adr = pad ? -1 : (int64_t)idx;
-      a.out_vals[(int64_t)q * a.k + e] = pad ? -INFINITY : top.v[r];
+      a.out_vals[(int64_t)q * a.k + e] = pad ? -INFINITY : key_value(top.k[r]);
       a.out_addr[(int64_t)q * a.k + e] = adr;
       if (a.out_ids) a.out_ids[(int64_t)q * a.k + e] = pad ? -1 : a.address2id[adr];
     }
@@ -318,10 +321,11 @@ struct GlobalLut {
 template <int M, class LutFn>
 __device__ __forceinline__ float exact_from_packed(const uint8_t* __restrict__ packed,
                                                    int64_t n_slots, int idx, bool active,
-                                                   uint32_t* scratch, const LutFn& lutfn) {
+                                                   uint32_t* scratch, int row_id,
+                                                   const LutFn& lutfn) {
   using L = scan_layout::Layout<M>;
   constexpr int G = M / 4;
-  uint32_t* row = scratch + lane_id() * (G + 1);
+  uint32_t* row = scratch + row_id * (G + 1);
   if (active) {
     typename L::chunk_t w[L::kChunks];
     L::load(packed, n_slots, idx, w);
@@ -351,26 +355,16 @@ __device__ __forceinline__ float exact_from_packed(const uint8_t* __restrict__ p
   return active ? v : -INFINITY;
 }
 
-// wave-level: exact re-evaluation + re-ranking of the surviving candidates, output, overflow flag
-template <int R, int M, class LutFn>
-__device__ __forceinline__ void refine_and_write(const ScanArgs& a, int q, const WaveTopK<R>& fast,
-                                                 float delta2, uint32_t* scratch,
-                                                 const LutFn& lutfn) {
-  const float fk = fast.kth_value(a.k);
-  const float flast = readlane_f(fast.v[R - 1], 63);
-  const int ilast = readlane_i(fast.i[R - 1], 63);
-  const bool overflow = (ilast != kPadIdx) && !(flast < fk - delta2);
-  WaveTopK<R> ex;
-  ex.init();
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int idx = fast.i[r];
-    const bool active = idx != kPadIdx;
-    const float e = exact_from_packed<M>(a.packed, a.n_slots, idx, active, scratch, lutfn);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    ex.insert_unsorted(e, active ? idx : kPadIdx);
-  }
-  write_final<R>(a, q, ex);
+// phase 2, wave-level: the merged list already carries EXACT values; write the best k and raise
+// the overflow flag when the list is so full of near-ties that a member of the exact top-k may
+// have been evicted from a wave's list (see the header comment of this section)
+template <int R>
+__device__ __forceinline__ void finalize_and_write(const ScanArgs& a, int q, const WaveTopK<R>& top,
+                                                   float delta2) {
+  const float ek = top.kth_value(a.k);
+  const Key klast = readlane_key(top.k[R - 1], 63);
+  const bool overflow = (key_index(klast) != kPadIdx) && !(key_value(klast) < ek - delta2);
+  write_final<R>(a, q, top);
   if (lane_id() == 0) a.flags[q] = overflow ? 1 : 0;
 }
 
@@ -378,11 +372,8 @@ __device__ __forceinline__ void refine_and_write(const ScanArgs& a, int q, const
 // large that only one workgroup fits (m > 64, e.g. GIST m=120: 120 KiB) -- same 16 waves per CU
 constexpr int packed_waves(int M) { return M <= 64 ? 8 : 16; }
 
-constexpr int packed_aux_bytes(int R, int M) {
-  const int lists = (packed_waves(M) / 2) * R * 64 * 8;  // lists live at a time in the tree merge
-  const int scratch = 64 * (M / 4 + 1) * 4;     // un-permute rows of the final refinement
-  return lists > scratch ? lists : scratch;
-}
+// per-wave scratch of the end-of-query exact re-evaluation: 16 un-permute rows of M/4+1 dwords
+constexpr int packed_aux_bytes(int /*R*/, int M) { return packed_waves(M) * 16 * (M / 4 + 1) * 4; }
 
 // 2 workgroups per CU (LDS: 2 x (64 KiB LUT + ~14 KiB)) need <= 128 VGPRs: 4 waves per SIMD
 template <int R, int M>
@@ -394,7 +385,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
   constexpr int lut_bytes = M * 1024;
   constexpr int aux_bytes = packed_aux_bytes(R, M);
   float* lut = reinterpret_cast<float*>(smem);
-  char* aux = smem + lut_bytes;  // merge lists, then refinement scratch
+  uint32_t* scratch_all = reinterpret_cast<uint32_t*>(smem + lut_bytes);
   float* qv_all = reinterpret_cast<float*>(smem + lut_bytes + aux_bytes);
   int* qi_all = reinterpret_cast<int*>(smem + lut_bytes + aux_bytes + NW * 256);
   int* ptab = reinterpret_cast<int*>(smem + lut_bytes + aux_bytes + NW * 512);
@@ -438,6 +429,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
 
   WaveSelector<R> sel;
   sel.init(qv_all + wave * 64, qi_all + wave * 64, a.k);
+  sel.margin = delta2;
   NoRefine refine;
 
   const int total_tiles = tab.tile_begin[n_probe];
@@ -455,8 +447,11 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
     sel.tau = fmaxf(sel.tau, key2f(*reinterpret_cast<volatile unsigned*>(tau_key)));
   };
   auto publish = [&](float /*tau_before*/) {
+    // readlane must run with every lane active: inside `if (lane == 0)` the source lane is
+    // inactive and its register contents are undefined to the compiler
+    const float mine = sel.top.kth_value(r_share);
     if (lane == 0) {
-      reinterpret_cast<volatile float*>(wave_q)[wave] = sel.top.kth_value(r_share);
+      reinterpret_cast<volatile float*>(wave_q)[wave] = mine;
       float qmin = reinterpret_cast<volatile float*>(wave_q)[0];
 #pragma unroll
       for (int w = 1; w < NW; ++w) qmin = fminf(qmin, reinterpret_cast<volatile float*>(wave_q)[w]);
@@ -529,25 +524,37 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
     publish(tau_before);
   }
 
-  // tree merge of the 8 per-wave lists (by fast value); the LUT stays live for the refinement
-  float* lv = reinterpret_cast<float*>(aux);
-  int* li = reinterpret_cast<int*>(aux + (NW / 2) * R * 64 * 4);
-  for (int stride = 1; stride < NW; stride <<= 1) {
-    const int slot = wave / (2 * stride);
-    __syncthreads();
-    if ((wave & (2 * stride - 1)) == stride) store_list<R>(sel.top, lv + slot * R * 64, li + slot * R * 64);
-    __syncthreads();
-    if ((wave & (2 * stride - 1)) == 0) merge_list<R>(sel.top, lv + slot * R * 64, li + slot * R * 64);
-  }
-  __syncthreads();
-  if (wave == 0) {
-    if (a.n_split == 1) {
-      refine_and_write<R, M>(a, q, sel.top, delta2, reinterpret_cast<uint32_t*>(aux), LdsLut<M>{lut});
-    } else {
-      const int64_t o = ((int64_t)q * a.n_split + part) * (R * 64);
-      store_list<R>(sel.top, a.ws_vals + o, a.ws_idx + o);
-      if (part == 0 && lane == 0) a.ws_delta[q] = delta2;
+  // End of query, per wave and without any barrier: re-evaluate the surviving candidates of
+  // this wave's list exactly (ascending j, LUT still in LDS), re-rank them by exact value and
+  // dump the list; scan_merge_refine_kernel (one wave per query) merges the 8 x n_split lists.
+  // Only entries that can still reach the top-k (f >= shared threshold - 2*delta) are touched:
+  // with the quantile-shared threshold that is ~k/8 per wave, i.e. one 16-lane pass.
+  {
+    refresh_tau();
+    const float cut = sel.tau - delta2;
+    uint32_t* scratch = scratch_all + wave * 16 * (M / 4 + 1);
+    WaveTopK<R> ex;
+    ex.init();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int idx = key_index(sel.top.k[r]);
+      const bool want = (idx != kPadIdx) && (key_value(sel.top.k[r]) >= cut);
+      const unsigned long long wmask = __ballot(want);
+      if (wmask == 0ull) break;  // sorted by fast value: nothing further down qualifies either
+      float e = -INFINITY;
+      for (int pass = 0; pass < 4; ++pass) {
+        if (((wmask >> (16 * pass)) & 0xffffull) == 0ull) continue;  // wave-uniform
+        const bool mine = want && ((lane >> 4) == pass);
+        const float ep = exact_from_packed<M>(a.packed, a.n_slots, idx, mine, scratch, lane & 15,
+                                             LdsLut<M>{lut});
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        e = mine ? ep : e;
+      }
+      ex.insert_unsorted(want ? make_key(e, idx) : pad_key());
     }
+    const int64_t o = (((int64_t)q * a.n_split + part) * NW + wave) * (R * 64);
+    store_list<R>(ex, a.ws_vals + o, a.ws_idx + o);
+    if (part == 0 && wave == 0 && lane == 0) a.ws_delta[q] = delta2;
   }
 }
 
@@ -566,18 +573,40 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(ScanArgs a) {
   write_final<R>(a, q, top);
 }
 
-// packed path: merge the parts' fast lists, then refine exactly (LUT read from global memory)
+// packed path, phase 2: merge the per-wave lists of a query (exact values) and write the result
 template <int R, int M>
 __global__ __launch_bounds__(64) void scan_merge_refine_kernel(ScanArgs a) {
-  __shared__ uint32_t scratch[64 * (M / 4 + 1)];
   const int q = blockIdx.x;
+  const int lane = lane_id();
+  const int n_lists = a.n_split * packed_waves(M);  // a multiple of 8
   WaveTopK<R> top;
   top.init();
-  for (int part = 0; part < a.n_split; ++part) {
-    const int64_t o = ((int64_t)q * a.n_split + part) * (R * 64);
-    merge_list<R>(top, a.ws_vals + o, a.ws_idx + o);
+  // Rank-major order (every list's best 64 first): once those are in, most later chunks fail the
+  // wave-uniform early-exit test.  Loads are issued 8 chunks at a time, a group ahead of the
+  // merges, so the wave is not serialised on one global-load latency per chunk.
+  const float* __restrict__ bv = a.ws_vals + (int64_t)q * n_lists * (R * 64);
+  const int* __restrict__ bi = a.ws_idx + (int64_t)q * n_lists * (R * 64);
+  const int n_groups = (n_lists / 8) * R;  // group g: rank chunk g / (n_lists/8), lists 8*(g % ..)
+  auto load_group = [&](int g, Key (&kk)[8]) {
+    const int r = g / (n_lists / 8), l0 = (g % (n_lists / 8)) * 8;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t o = (int64_t)(l0 + u) * (R * 64) + r * 64 + lane;
+      kk[u] = Key{reinterpret_cast<const unsigned*>(bv)[o], reinterpret_cast<const unsigned*>(bi)[o]};
+    }
+  };
+  Key k0[8], k1[8];
+  load_group(0, k0);
+  for (int g = 0; g < n_groups; g += 2) {
+    if (g + 1 < n_groups) load_group(g + 1, k1);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) top.insert_sorted(k0[u]);
+    if (g + 1 >= n_groups) break;
+    if (g + 2 < n_groups) load_group(g + 2, k0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) top.insert_sorted(k1[u]);
   }
-  refine_and_write<R, M>(a, q, top, a.ws_delta[q], scratch, GlobalLut{a.lut, a.nq, q});
+  finalize_and_write<R>(a, q, top, a.ws_delta[q]);
 }
 
 // ---- host side -----------------------------------------------------------------------------
@@ -618,20 +647,19 @@ static int set_lds(K kernel, size_t bytes, const char* name) {
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// workspace: [flags nq*4][delta nq*4][split lists nq*n_split*64R*8]
-static size_t ws_bytes_for(int nq, int R, int n_split) {
-  size_t b = 2 * align256((size_t)nq * 4);
-  if (n_split > 1) b += (size_t)nq * n_split * R * 64 * 8;
-  return b;
+// workspace: [flags nq*4][delta nq*4][lists nq*n_lists*64R*8]; n_lists = n_split (reference
+// kernel, only when n_split > 1) or n_split * waves-per-workgroup (packed kernel, always)
+static size_t ws_bytes_for(int nq, int R, int n_lists) {
+  return 2 * align256((size_t)nq * 4) + (size_t)nq * n_lists * R * 64 * 8;
 }
 
-static void fill_ws(ScanArgs& a, void* workspace, int R) {
+static void fill_ws(ScanArgs& a, void* workspace, int R, int n_lists) {
   char* p = reinterpret_cast<char*>(workspace);
   a.flags = reinterpret_cast<int*>(p);
   a.ws_delta = reinterpret_cast<float*>(p + align256((size_t)a.nq * 4));
   char* lists = p + 2 * align256((size_t)a.nq * 4);
   a.ws_vals = reinterpret_cast<float*>(lists);
-  a.ws_idx = reinterpret_cast<int*>(lists + (size_t)a.nq * a.n_split * R * 64 * 4);
+  a.ws_idx = reinterpret_cast<int*>(lists + (size_t)a.nq * n_lists * R * 64 * 4);
 }
 
 static int validate(const ScanArgs& a) {
@@ -693,10 +721,8 @@ static int launch_packed(ScanArgs a, hipStream_t st) {
   hipLaunchKernelGGL((scan_packed_kernel<R, M>), dim3((unsigned)a.nq * a.n_split),
                      dim3(packed_waves(M) * 64), lds, st, a, delta_rel);
   TPQ_LAUNCH_CHECK("scan_packed_kernel");
-  if (a.n_split > 1) {
-    hipLaunchKernelGGL((scan_merge_refine_kernel<R, M>), dim3(a.nq), dim3(64), 0, st, a);
-    TPQ_LAUNCH_CHECK("scan_merge_refine_kernel");
-  }
+  hipLaunchKernelGGL((scan_merge_refine_kernel<R, M>), dim3(a.nq), dim3(64), 0, st, a);
+  TPQ_LAUNCH_CHECK("scan_merge_refine_kernel");
   return TPQ_OK;
 }
 
@@ -715,10 +741,12 @@ static int dispatch_packed(const ScanArgs& a, int R, hipStream_t st) {
 
 using namespace tpq;
 
-extern "C" size_t tpq_ivfpq_scan_workspace_bytes(int nq, int k, int n_split) {
+extern "C" size_t tpq_ivfpq_scan_workspace_bytes(int nq, int k, int n_split, int m) {
   if (nq <= 0 || k <= 0) return 0;
-  const int R = list_regs_packed(k) > list_regs(k) ? list_regs_packed(k) : list_regs(k);
-  return ws_bytes_for(nq, R > 16 ? 16 : R, n_split < 1 ? 1 : n_split);
+  if (n_split < 1) n_split = 1;
+  int R = list_regs_packed(k) > list_regs(k) ? list_regs_packed(k) : list_regs(k);
+  if (R > 16) R = 16;
+  return ws_bytes_for(nq, R, n_split * packed_waves(m));  // covers both kernels
 }
 
 extern "C" int tpq_ivfpq_scan_topk(const uint8_t* codes, const float* lut, const uint8_t* is_empty,
@@ -737,7 +765,7 @@ extern "C" int tpq_ivfpq_scan_topk(const uint8_t* codes, const float* lut, const
   if (n_split > 1) {
     rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, R, n_split), "ivfpq_scan");
     if (rc) return rc;
-    fill_ws(a, workspace, R);
+    fill_ws(a, workspace, R, n_split);
   }
   return dispatch_ref(a, R, reinterpret_cast<hipStream_t>(stream));
 }
@@ -764,13 +792,14 @@ extern "C" int tpq_ivfpq_scan_topk_packed(const uint8_t* packed, const uint8_t* 
     if (n_split > 1) {
       rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, Rr, n_split), "ivfpq_scan_packed");
       if (rc) return rc;
-      fill_ws(a, workspace, Rr);
+      fill_ws(a, workspace, Rr, n_split);
     }
     return dispatch_ref(a, Rr, st);
   }
-  rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, R, n_split), "ivfpq_scan_packed");
+  const int n_lists = n_split * packed_waves(m);
+  rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, R, n_lists), "ivfpq_scan_packed");
   if (rc) return rc;
-  fill_ws(a, workspace, R);
+  fill_ws(a, workspace, R, n_lists);
   switch (m) {
     case 8: rc = dispatch_packed<8>(a, R, st); break;
     case 16: rc = dispatch_packed<16>(a, R, st); break;

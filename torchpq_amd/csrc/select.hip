@@ -27,7 +27,7 @@ __global__ __launch_bounds__(kSelWaves * 64) void topk_select_kernel(const float
   for (int base = 0; base < cols; base += 64) {
     const int c = base + lane;
     const bool valid = c < cols;
-    const float v = valid ? xr[c] : -INFINITY;
+    const float v = valid ? xr[c] + 0.0f : -INFINITY;  // +0.f: -0.0 -> +0.0 (key order)
     sel.push(valid && (v >= sel.tau), v, c, refine);
   }
   sel.flush(refine);
@@ -35,9 +35,10 @@ __global__ __launch_bounds__(kSelWaves * 64) void topk_select_kernel(const float
   for (int r = 0; r < R; ++r) {
     const int e = r * 64 + lane;
     if (e < k) {
-      const bool pad = sel.top.i[r] == kPadIdx;
-      vals[(int64_t)row * k + e] = pad ? -INFINITY : sel.top.v[r];
-      idx[(int64_t)row * k + e] = pad ? -1 : (int64_t)sel.top.i[r];
+      const int ci = key_index(sel.top.k[r]);
+      const bool pad = ci == kPadIdx;
+      vals[(int64_t)row * k + e] = pad ? -INFINITY : key_value(sel.top.k[r]);
+      idx[(int64_t)row * k + e] = pad ? -1 : (int64_t)ci;
     }
   }
 }

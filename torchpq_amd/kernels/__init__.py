@@ -102,7 +102,7 @@ class IVFPQTopkHip:
         lib = load()
         if n_split is None:
             n_split = self._n_split(n_query, device)
-        ws_bytes = lib.tpq_ivfpq_scan_workspace_bytes(n_query, k, n_split)
+        ws_bytes = lib.tpq_ivfpq_scan_workspace_bytes(n_query, k, n_split, self.m)
         ws = torch.empty(max(ws_bytes, 1), device=device, dtype=torch.uint8) if ws_bytes else None
         ev = None
         if self.record_events is not None:
