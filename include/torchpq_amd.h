@@ -96,6 +96,28 @@ int tpq_ivfpq_scan_topk_packed(const uint8_t* packed, const uint8_t* codes, cons
                                tpq_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * SURVEY 8(f)-3  residual-PQ list scan (pq_use_residual=True)
+ * replaces IVFPQTopkCuda.topk_residual_precomputed  torchpq/kernels/IVFPQTopkCuda.py:212-283
+ *          (kernel ivfpq_topk_residual_precomputed, torchpq/kernels/cuda/ivfpq_topk.cu:1039-1208)
+ *      and IVFPQTopkCuda.topk_residual              torchpq/kernels/IVFPQTopkCuda.py:144-210
+ *          (kernel ivfpq_topk_residual, ivfpq_topk.cu:973-1037)
+ * value(slot of probe p) = base_sims[q][p]; then += LUT_p[j][code_j] for j ascending, with
+ *   LUT_p = part1[q] + part2[cells[q][p]]  (part1 f32 [nq][m][256], part2 f32 [n_cells][m][256])
+ *   or, when full_lut != NULL, LUT_p = full_lut[q][p]  (f32 [nq][max_nprobe][m][256]).
+ * Other arguments and the output contract are those of tpq_ivfpq_scan_topk.
+ * tpq_residual_part1: part1[q][j][c] = 2 * q_j . r_jc (index/IVFPQIndex.py:366-379).
+ * ------------------------------------------------------------------------- */
+int tpq_ivfpq_scan_topk_residual(const uint8_t* codes, const float* part1, const float* part2,
+                                 const float* full_lut, const int64_t* cells,
+                                 const float* base_sims, const uint8_t* is_empty,
+                                 const int64_t* cell_start, const int64_t* cell_size,
+                                 const int64_t* n_probe_list, float* out_vals, int64_t* out_addr,
+                                 const int64_t* address2id, int64_t* out_ids, int64_t n_slots,
+                                 int nq, int max_nprobe, int m, int k, tpq_stream_t stream);
+int tpq_residual_part1(const float* query, const float* codebook, float* part1, int m, int ds,
+                       int nq, tpq_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * a-3  ADC look-up table
  * replaces PQCodec.precompute_adc  torchpq/codec/PQCodec.py:62-75
  *          (-> MultiKMeans.sim/euc_sim, torchpq/clustering/MultiKMeans.py:184-223)

@@ -31,6 +31,7 @@ def lib():
             build()
         _lib = C.CDLL(_SO)
         _lib.oracle_scan_topk.restype = C.c_int64
+        _lib.oracle_scan_topk_residual.restype = C.c_int64
         _lib.oracle_adc_lut.restype = None
         _lib.oracle_max_sim.restype = None
     return _lib
@@ -64,6 +65,37 @@ def scan_topk(storage, lut, is_empty, cell_start, cell_size, n_probe_list, k,
         C.c_int(m), C.c_int(k), C.c_int(nt))
     if return_scanned:
         return vals, adr, int(scanned)
+    return vals, adr
+
+
+def scan_topk_residual(storage, part1, part2, cells, base_sims, is_empty, cell_start, cell_size,
+                       n_probe_list, k, full=None, n_threads=None):
+    storage = np.ascontiguousarray(storage, dtype=np.uint8)
+    g, n_slots, cs = storage.shape
+    m = g * cs
+    cell_start = np.ascontiguousarray(cell_start, dtype=np.int64)
+    cell_size = np.ascontiguousarray(cell_size, dtype=np.int64)
+    n_probe_list = np.ascontiguousarray(n_probe_list, dtype=np.int64)
+    base_sims = np.ascontiguousarray(base_sims, dtype=np.float32)
+    nq, max_np = cell_start.shape
+    p1 = p2 = fl = cl = None
+    if full is not None:
+        fl = np.ascontiguousarray(full, dtype=np.float32)
+        assert fl.shape == (nq, max_np, m, 256)
+    else:
+        p1 = np.ascontiguousarray(part1, dtype=np.float32)
+        p2 = np.ascontiguousarray(part2, dtype=np.float32)
+        cl = np.ascontiguousarray(cells, dtype=np.int64)
+        assert p1.shape == (nq, m, 256) and p2.shape[1:] == (m, 256)
+    ie = np.ascontiguousarray(is_empty, dtype=np.uint8) if is_empty is not None else None
+    vals = np.empty((nq, k), np.float32)
+    adr = np.empty((nq, k), np.int64)
+    nt = n_threads or os.cpu_count() or 1
+    P = lambda a: _p(a) if a is not None else None
+    lib().oracle_scan_topk_residual(
+        _p(storage), P(p1), P(p2), P(fl), P(cl), _p(base_sims), P(ie), _p(cell_start), _p(cell_size),
+        _p(n_probe_list), _p(vals), _p(adr), C.c_int64(n_slots), C.c_int(nq), C.c_int(max_np),
+        C.c_int(m), C.c_int(k), C.c_int(nt))
     return vals, adr
 
 

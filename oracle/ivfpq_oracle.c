@@ -108,6 +108,74 @@ int64_t oracle_scan_topk(const uint8_t *storage, const float *lut, const uint8_t
   return scanned_total;
 }
 
+/* residual-PQ scan: value = base_sims[q][p]; then += (part1[q][j][c] + part2[cell][j][c]) ascending j
+ * (ivfpq_topk.cu:1039-1208, LUT build :522-560) or += full[q][p][j][c] when `full` != NULL (:973-1037) */
+int64_t oracle_scan_topk_residual(const uint8_t *storage, const float *part1, const float *part2,
+                                  const float *full, const int64_t *cells, const float *base_sims,
+                                  const uint8_t *is_empty, const int64_t *cell_start,
+                                  const int64_t *cell_size, const int64_t *n_probe_list,
+                                  float *out_vals, int64_t *out_addr, int64_t n_slots, int nq,
+                                  int max_nprobe, int m, int k, int n_threads) {
+  int64_t scanned_total = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads) reduction(+ : scanned_total)
+  for (int q = 0; q < nq; q++) {
+    cand_t *heap = (cand_t *)malloc(sizeof(cand_t) * (size_t)k);
+    float *lut = (float *)malloc(sizeof(float) * (size_t)m * 256);
+    int hn = 0;
+    int np = (int)n_probe_list[q];
+    if (np > max_nprobe) np = max_nprobe;
+    int64_t prev_start = -1;
+    int have_prev = 0;
+    for (int p = 0; p < np; p++) {
+      int64_t st = cell_start[(int64_t)q * max_nprobe + p];
+      int64_t sz = cell_size[(int64_t)q * max_nprobe + p];
+      if (have_prev && st == prev_start) continue;
+      prev_start = st;
+      have_prev = 1;
+      if (sz <= 0) continue;
+      if (full) {
+        memcpy(lut, full + ((int64_t)q * max_nprobe + p) * m * 256, sizeof(float) * (size_t)m * 256);
+      } else {
+        const float *p1 = part1 + (int64_t)q * m * 256;
+        const float *p2 = part2 + cells[(int64_t)q * max_nprobe + p] * (int64_t)m * 256;
+        for (int e = 0; e < m * 256; e++) lut[e] = p1[e] + p2[e];
+      }
+      const float base = base_sims[(int64_t)q * max_nprobe + p];
+      for (int64_t s = st; s < st + sz; s++) {
+        if (is_empty && is_empty[s]) continue;
+        float v = base;
+        for (int j = 0; j < m; j++) {
+          uint8_t c = storage[((int64_t)(j >> 2) * n_slots + s) * 4 + (j & 3)];
+          v += lut[j * 256 + c];
+        }
+        scanned_total++;
+        cand_t cnd = {v, s};
+        if (hn < k) {
+          heap[hn++] = cnd;
+          if (hn == k)
+            for (int i = k / 2 - 1; i >= 0; i--) heap_sift_down(heap, k, i);
+        } else if (cand_better(&cnd, &heap[0])) {
+          heap[0] = cnd;
+          heap_sift_down(heap, k, 0);
+        }
+      }
+    }
+    qsort(heap, (size_t)hn, sizeof(cand_t), cand_cmp_desc);
+    for (int i = 0; i < k; i++) {
+      if (i < hn) {
+        out_vals[(int64_t)q * k + i] = heap[i].v;
+        out_addr[(int64_t)q * k + i] = heap[i].a;
+      } else {
+        out_vals[(int64_t)q * k + i] = -INFINITY;
+        out_addr[(int64_t)q * k + i] = -1;
+      }
+    }
+    free(heap);
+    free(lut);
+  }
+  return scanned_total;
+}
+
 /* LUT[j][q][c] = 2 q_j.c - |q_j|^2 - |c|^2 (euclidean) or q_j.c (inner);
  * dots and norms are ascending-k fmaf chains (what the fp32 MFMA path computes).
  * query f32 [m*ds][nq], codebook f32 [m][ds][256] -> lut f32 [m][nq][256] */

@@ -215,6 +215,80 @@ def scan_topk(storage, lut, is_empty, cell_start, cell_size, n_probe_list, k,
     return vals, adr
 
 
+def scan_topk_residual(storage, part1, part2, cells, base_sims, is_empty, cell_start, cell_size,
+                       n_probe_list, k, full=None):
+    """Residual-PQ list scan.  value(slot in probe p) = base_sims[q, p], then for j ascending
+    ``+= LUT_p[j][code_j]`` with ``LUT_p = part1[q] + part2[cells[q, p]]`` (one fp32 add per entry)
+    -- ivfpq_topk_residual_precomputed (kernels/cuda/ivfpq_topk.cu:1039-1208, LUT build
+    load_precomputed_v3 :522-560, accumulation start ``newPair.value = cBaseSim`` :1113) -- or,
+    when ``full`` [nq, n_probe, m, 256] is given, ``LUT_p = full[q, p]`` (ivfpq_topk_residual
+    :973-1037).  part1 [nq, m, 256], part2 [n_cells, m, 256]; logical indexing (the reference hands
+    its kernel permuted views)."""
+    nq = cell_start.shape[0]
+    vals = np.full((nq, k), NEG_INF, dtype=F32)
+    adr = np.full((nq, k), -1, dtype=np.int64)
+    g, cap, cs4 = storage.shape
+    m = g * cs4
+    for q in range(nq):
+        all_v, all_s = [], []
+        prev = None
+        for p in range(int(n_probe_list[q])):
+            st, sz = int(cell_start[q, p]), int(cell_size[q, p])
+            if prev is not None and st == prev:
+                prev = st
+                continue
+            prev = st
+            if sz <= 0:
+                continue
+            slots = np.arange(st, st + sz, dtype=np.int64)
+            if is_empty is not None:
+                slots = slots[is_empty[slots] == 0]
+            if slots.size == 0:
+                continue
+            if full is not None:
+                lut_p = full[q, p].astype(F32)
+            else:
+                lut_p = (part1[q].astype(F32) + part2[int(cells[q, p])].astype(F32)).astype(F32)
+            v = np.full(slots.shape[0], F32(base_sims[q, p]), dtype=F32)
+            for j in range(m):
+                c = storage[j // cs4, slots, j % cs4]
+                v = (v + lut_p[j, c]).astype(F32)
+            all_v.append(v)
+            all_s.append(slots)
+        if not all_v:
+            continue
+        v = np.concatenate(all_v)
+        sl = np.concatenate(all_s)
+        order = np.lexsort((sl, -v))[:k]
+        vals[q, :order.size] = v[order]
+        adr[q, :order.size] = sl[order]
+    return vals, adr
+
+
+def residual_part1(query, pq_codebook):
+    """part1[q, j, c] = 2 * q_j . r_jc  (IVFPQIndex.precomputed_adc_residual_precomputed,
+    index/IVFPQIndex.py:366-379), dots as ascending-dimension fma chains."""
+    m, ds, _ = pq_codebook.shape
+    d, nq = query.shape
+    qs = np.ascontiguousarray(query, dtype=F32).reshape(m, ds, nq)
+    out = np.zeros((nq, m, 256), dtype=F32)
+    for e in range(ds):
+        out = _fma(qs[:, e, :].T[:, :, None], pq_codebook[None, :, e, :], out)
+    return (F32(2) * out).astype(F32)
+
+
+def residual_part2(vq_codebook, pq_codebook):
+    """part2[cell, j, c] = -2 * c_j . r_jc - |r_jc|^2  (IVFPQIndex.precompute_part2,
+    index/IVFPQIndex.py:160-170); fp32, BLAS summation order -> compare with tolerance."""
+    m, ds, _ = pq_codebook.shape
+    n_cells = vq_codebook.shape[1]
+    vq = np.ascontiguousarray(vq_codebook, dtype=F32).reshape(m, ds, n_cells)
+    prod = np.einsum("jdn,jdc->jnc", vq, pq_codebook).astype(F32)
+    nrm = (pq_codebook * pq_codebook).sum(axis=1, dtype=F32)  # [m, 256]
+    out = (prod * F32(-2) - nrm[:, None, :]).astype(F32)
+    return np.ascontiguousarray(out.transpose(1, 0, 2))
+
+
 def get_id_by_address(address2id, address):
     """BaseContainer.get_id_by_address (container/BaseContainer.py:58-65)."""
     mask = (address >= 0) & (address < address2id.shape[0])

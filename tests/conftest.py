@@ -37,3 +37,8 @@ def fx_container():
 @pytest.fixture(scope="session")
 def fx_kmeans():
     return load_golden("fx_kmeans")
+
+
+@pytest.fixture(scope="session")
+def fx_residual():
+    return load_golden("fx_residual")

@@ -187,6 +187,50 @@ def fx_kmeans(torch, tq):
     print("fx_kmeans ok")
 
 
+def fx_residual(torch, tq):
+    """pq_use_residual=True: reference train/add on CPU, reference part1/part2/full tables
+    (IVFPQIndex.py:160-170, 366-405); scan results from the oracle (no CPU scan in the reference)."""
+    d, m, n_cells, n, nq, n_probe = 32, 8, 16, 3000, 12, 4
+    rng = np.random.default_rng(5)
+    base = sift_like(rng, d, n)
+    np.random.seed(5)
+    idx = tq.index.IVFPQIndex(d_vector=d, n_subvectors=m, n_cells=n_cells, initial_size=256,
+                              device="cpu", pq_use_residual=True)
+    idx.train(torch.from_numpy(base.copy()))
+    idx.add(torch.from_numpy(base.copy()))
+    sd = {k: v.numpy().copy() for k, v in idx.state_dict().items() if v is not None}
+    queries = sift_like(rng, d, nq)
+    xq = torch.from_numpy(queries.copy())
+    sims = tq.metric.negative_squared_l2_distance(xq.clone(), idx.vq_codec.codebook.clone())
+    topk_sims, cells = sims.topk(n_probe, dim=1)
+    part1, part2 = idx.precomputed_adc_residual_precomputed(xq.clone())
+    full = idx.precomputed_adc_residual(xq.clone(), cells)
+    part1, part2, full = (np.ascontiguousarray(t.numpy()) for t in (part1, part2, full))
+    out = dict(d=d, m=m, n_cells=n_cells, n=n, nq=nq, n_probe=n_probe, base=base, queries=queries,
+               ref_topk_sims=topk_sims.numpy(), ref_cells=cells.numpy(), ref_part1=part1,
+               ref_part2=part2, ref_full=full)
+    for k, v in sd.items():
+        out["sd." + k] = v
+    # value identity through reference functions: base + sum_j LUT == -|q - (centroid + decode)|^2
+    cap = idx._storage.shape[1]
+    codes_all = idx.get_data_by_address(torch.arange(cap))
+    cell_of_slot = idx.get_cell_by_address(torch.arange(cap)).clamp(min=0)
+    recon = idx.decode((codes_all, cell_of_slot)).numpy()
+    out["ref_adc_exact"] = tq.metric.negative_squared_l2_distance(
+        xq.clone(), torch.from_numpy(recon.copy())).numpy()
+    cs, sz = sd["_cell_start"][out["ref_cells"]], sd["_cell_size"][out["ref_cells"]]
+    npl = np.full(nq, n_probe, np.int64)
+    for k in (1, 10, 100):
+        v, a = orc.scan_topk_residual(sd["_storage"], part1, part2, out["ref_cells"],
+                                      out["ref_topk_sims"], sd["_is_empty"], cs, sz, npl, k)
+        out[f"orc_vals_k{k}"], out[f"orc_addr_k{k}"] = v, a
+        v2, a2 = orc.scan_topk_residual(sd["_storage"], None, None, None, out["ref_topk_sims"],
+                                        sd["_is_empty"], cs, sz, npl, k, full=full)
+        out[f"orc_full_vals_k{k}"], out[f"orc_full_addr_k{k}"] = v2, a2
+    np.savez_compressed(os.path.join(OUT, "fx_residual.npz"), **out)
+    print("fx_residual ok", int(sd["_cell_size"].sum()))
+
+
 def main():
     tq = import_reference()
     import torch
@@ -197,6 +241,7 @@ def main():
              seed=2, n_probe=8, ks=[10])
     fx_container(torch, tq)
     fx_kmeans(torch, tq)
+    fx_residual(torch, tq)
 
 
 if __name__ == "__main__":

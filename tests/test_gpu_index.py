@@ -211,8 +211,6 @@ def test_api_asserts_and_cosine():
     from torchpq_amd.index import IVFPQIndex
     with pytest.raises(AssertionError):
         IVFPQIndex(d_vector=30, n_subvectors=8, device=DEV)  # d % m != 0
-    with pytest.raises(NotImplementedError):
-        IVFPQIndex(d_vector=32, n_subvectors=8, pq_use_residual=True, device=DEV)
     rng = np.random.default_rng(3)
     base = rng.standard_normal((32, 3000)).astype(np.float32)
     np.random.seed(3)
@@ -233,3 +231,55 @@ def test_api_asserts_and_cosine():
     xn = base[:, :100] / (np.linalg.norm(base[:, :100], axis=0, keepdims=True) + 1e-9)
     ev, ei, _, _ = _expected_search(idx, xn.astype(np.float32), 5)
     np.testing.assert_allclose(N(v), ev, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("use_precomputed", [True, False])
+def test_residual_index_end_to_end(use_precomputed):
+    """pq_use_residual=True: train / add / encode / decode / search against the oracle."""
+    from torchpq_amd.index import IVFPQIndex
+    rng = np.random.default_rng(6)
+    d, n, nq, k = 32, 6000, 40, 10
+    centers = rng.standard_normal((d, 30)) * 4
+    base = (centers[:, rng.integers(0, 30, n)] + rng.standard_normal((d, n))).astype(np.float32)
+    queries = (base[:, :nq] + 0.05 * rng.standard_normal((d, nq))).astype(np.float32)
+    np.random.seed(6)
+    idx = IVFPQIndex(d_vector=d, n_subvectors=8, n_cells=16, initial_size=512, device=DEV,
+                     pq_use_residual=True)
+    assert idx.use_precomputed
+    xb = T(base)
+    keep = xb.clone()
+    idx.train(xb)
+    assert torch.equal(xb, keep)
+    idx.add(xb)
+    idx.use_precomputed = use_precomputed
+    pq_code, vq_code = idx.encode(xb)
+    adr = idx.get_address_by_id(torch.arange(n, device=DEV))
+    assert torch.equal(idx.get_data_by_address(adr), pq_code)
+    assert torch.equal(idx.get_cell_by_address(adr), vq_code)
+    recon = idx.decode((pq_code, vq_code))
+    err_res = float(((recon - xb) ** 2).sum(0).mean())
+    err_vq = float(((idx.vq_codec.decode(vq_code) - xb) ** 2).sum(0).mean())
+    assert err_res < 0.7 * err_vq  # the residual codes refine the coarse reconstruction
+    idx.n_probe = 6
+    idx.use_smart_probing = False
+    v, i = idx.search(T(queries), k=k)
+    assert (N(i)[:, 0] == np.arange(nq)).mean() > 0.9
+    # oracle: same cells / base sims, tables in the kernel's arithmetic
+    topk_sims, cells, npl = idx.probe(T(queries))
+    cells_n, npl_n = N(cells), N(npl)
+    cs, sz = N(idx._cell_start)[cells_n], N(idx._cell_size)[cells_n]
+    if use_precomputed:
+        p1, p2 = idx.precomputed_adc_residual_precomputed(T(queries))
+        ev, ea = c_oracle.scan_topk_residual(N(idx._storage), N(p1), N(p2.contiguous()), cells_n,
+                                             N(topk_sims), N(idx._is_empty), cs, sz, npl_n, k)
+    else:
+        full = idx.precomputed_adc_residual(T(queries), cells)
+        ev, ea = c_oracle.scan_topk_residual(N(idx._storage), None, None, None, N(topk_sims),
+                                             N(idx._is_empty), cs, sz, npl_n, k, full=N(full))
+    assert np.array_equal(N(v), ev)
+    assert np.array_equal(N(i), orc.get_id_by_address(N(idx._address2id), ea))
+    # values are -|q - (centroid + decoded residual)|^2 of the returned ids
+    top = i[:, 0].contiguous()
+    rec = N(idx.decode((pq_code[:, top], vq_code[top])))
+    exact = -((queries - rec) ** 2).sum(0)
+    np.testing.assert_allclose(N(v)[:, 0], exact, rtol=2e-3, atol=2e-3 * np.abs(exact).max())

@@ -327,3 +327,51 @@ def test_pq_decode_and_scatter(K, fx_tiny):
     a2i = rng.integers(-1, 50, cap).astype(np.int64)
     probe = rng.integers(-5, cap + 5, (7, 9)).astype(np.int64)
     assert np.array_equal(N(K.GetIdByAddressHip()(T(a2i), T(probe))), orc.get_id_by_address(a2i, probe))
+
+
+# ---------------------------------------------------------------------------------------------
+# residual PQ scan
+# ---------------------------------------------------------------------------------------------
+def test_residual_scan_matches_golden(K, fx_residual):
+    fx = fx_residual
+    m = int(fx["m"])
+    scan = K.IVFPQTopkHip(m=m)
+    cells = fx["ref_cells"]
+    st = T(_sd(fx, "_storage"))
+    cs, sz = T(_sd(fx, "_cell_start")[cells]), T(_sd(fx, "_cell_size")[cells])
+    nq, n_probe = cells.shape
+    npl = T(np.full(nq, n_probe, np.int64))
+    a2i = T(_sd(fx, "_address2id"))
+    for k in (1, 10, 100):
+        v, a, i = scan.topk_residual_precomputed(st, T(fx["ref_part1"]), T(fx["ref_part2"]), T(cells),
+                                                 T(fx["ref_topk_sims"]), T(_sd(fx, "_is_empty")), cs, sz,
+                                                 npl, n_candidates=k, address2id=a2i)
+        assert np.array_equal(N(v), fx[f"orc_vals_k{k}"]) and np.array_equal(N(a), fx[f"orc_addr_k{k}"])
+        assert np.array_equal(N(i), orc.get_id_by_address(_sd(fx, "_address2id"), fx[f"orc_addr_k{k}"]))
+        v2, a2 = scan.topk_residual(st, T(fx["ref_full"]), T(fx["ref_topk_sims"]), None, cs, sz, npl,
+                                    n_candidates=k)
+        assert np.array_equal(N(v2), fx[f"orc_full_vals_k{k}"])
+        assert np.array_equal(N(a2), fx[f"orc_full_addr_k{k}"])
+    p1 = N(K.ResidualPart1Hip()(T(fx["queries"]), T(_sd(fx, "pq_codec.kmeans.centroids"))))
+    assert np.array_equal(p1, orc.residual_part1(fx["queries"], _sd(fx, "pq_codec.kmeans.centroids")))
+    np.testing.assert_allclose(p1, fx["ref_part1"], rtol=1e-4, atol=1e-5 * np.abs(fx["ref_part1"]).max())
+
+
+@pytest.mark.parametrize("m,k,n_probe,tomb", [(8, 10, 5, 0), (64, 100, 12, 30), (16, 300, 7, 0), (24, 1, 9, 5)])
+def test_residual_scan_random_vs_oracle(K, m, k, n_probe, tomb):
+    rng = np.random.default_rng(m * 7 + k)
+    n_cells, nq = 30, 21
+    storage, is_empty, start, sizes, a2i = _random_index(rng, m, n_cells, 140, tomb, 0.1)
+    part1 = (rng.standard_normal((nq, m, 256)) * 50).astype(np.float32)
+    part2 = (rng.standard_normal((n_cells, m, 256)) * 50).astype(np.float32)
+    cells = np.stack([rng.permutation(n_cells)[:n_probe] for _ in range(nq)])
+    cells[2, 1] = cells[2, 0]
+    base = (rng.standard_normal((nq, n_probe)) * 300).astype(np.float32)
+    npl = rng.integers(0, n_probe + 1, nq).astype(np.int64)
+    npl[:4] = n_probe
+    cs, sz = start[cells], sizes[cells]
+    ev, ea = c_oracle.scan_topk_residual(storage, part1, part2, cells, base, is_empty, cs, sz, npl, k)
+    scan = K.IVFPQTopkHip(m=m)
+    v, a = scan.topk_residual_precomputed(T(storage), T(part1), T(part2), T(cells), T(base),
+                                          T(is_empty), T(cs), T(sz), T(npl), n_candidates=k)
+    assert np.array_equal(N(v), ev) and np.array_equal(N(a), ea)

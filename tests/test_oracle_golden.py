@@ -154,3 +154,37 @@ def test_kmeans_assign_update_match_reference(fx_kmeans):
     v_np, l_np = orc.max_sim(data[:1, :, :512], init[:1], "euclidean", "direct")
     v_c, l_c = c_oracle.max_sim(data[:1, :, :512], init[:1], "euclidean", "direct")
     assert np.array_equal(l_np, l_c) and np.array_equal(v_np, v_c)
+
+
+def test_residual_tables_and_scan_against_reference(fx_residual):
+    """pq_use_residual=True: part1/part2 vs the reference's tables, the residual scan identity
+    base + sum_j (part1 + part2)[j, code_j] == -|q - (centroid + decode(code))|^2 through reference
+    functions, numpy vs C oracle, mode A (part1 + part2) vs mode B (full LUT)."""
+    fx = fx_residual
+    pq = _sd(fx, "pq_codec.kmeans.centroids")
+    vq = _sd(fx, "vq_codec.kmeans.centroids")
+    p1 = orc.residual_part1(fx["queries"], pq)
+    np.testing.assert_allclose(p1, fx["ref_part1"], rtol=1e-4, atol=1e-5 * np.abs(fx["ref_part1"]).max())
+    p2 = orc.residual_part2(vq, pq)
+    np.testing.assert_allclose(p2, fx["ref_part2"], rtol=1e-4, atol=1e-5 * np.abs(fx["ref_part2"]).max())
+    # the per-(query, probe) table equals part1 + part2[cell] up to fp32 rounding
+    cells = fx["ref_cells"]
+    comb = fx["ref_part1"][:, None] + fx["ref_part2"][cells]
+    np.testing.assert_allclose(comb, fx["ref_full"], rtol=1e-4, atol=1e-4 * np.abs(comb).max())
+    storage, is_empty = _sd(fx, "_storage"), _sd(fx, "_is_empty")
+    cs, sz = _sd(fx, "_cell_start")[cells], _sd(fx, "_cell_size")[cells]
+    nq, n_probe = cells.shape
+    npl = np.full(nq, n_probe, np.int64)
+    for k in (1, 10, 100):
+        v, a = c_oracle.scan_topk_residual(storage, fx["ref_part1"], fx["ref_part2"], cells,
+                                           fx["ref_topk_sims"], is_empty, cs, sz, npl, k)
+        assert np.array_equal(v, fx[f"orc_vals_k{k}"]) and np.array_equal(a, fx[f"orc_addr_k{k}"])
+        v2, a2 = c_oracle.scan_topk_residual(storage, None, None, None, fx["ref_topk_sims"],
+                                             is_empty, cs, sz, npl, k, full=fx["ref_full"])
+        assert np.array_equal(v2, fx[f"orc_full_vals_k{k}"]) and np.array_equal(a2, fx[f"orc_full_addr_k{k}"])
+        for q in range(nq):
+            slots = orc.probed_slots(cs[q], sz[q], npl[q])
+            slots = slots[is_empty[slots] == 0]
+            exact = np.sort(fx["ref_adc_exact"][q][slots])[::-1][:k]
+            np.testing.assert_allclose(v[q][:exact.size], exact, rtol=1e-4,
+                                       atol=2e-4 * np.abs(fx["ref_adc_exact"][q]).max())

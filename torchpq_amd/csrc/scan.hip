@@ -268,6 +268,116 @@ __global__ __launch_bounds__(kScanThreads) void scan_ref_kernel(ScanArgs a) {
                   reinterpret_cast<int*>(smem + kScanWaves * R * 64 * 4));
 }
 
+// ---- residual PQ (reference layout, exact) --------------------------------------------------
+// Replaces ivfpq_topk_residual_precomputed (ivfpq_topk.cu:1039-1208) and ivfpq_topk_residual
+// (:973-1037).  The LUT depends on the probed cell: LUT_p = part1[q] + part2[cell] (one fp32 add
+// per entry, load_precomputed_v3 :522-560) or LUT_p = full[q][p]; value(slot) starts at
+// base_sims[q][p] (:1113) and adds LUT_p[j][code_j] in ascending j.  One workgroup per query
+// walks its probes in order: barrier, rebuild the 64-KiB LUT in LDS, barrier, the 8 waves scan
+// the cell's tiles; the per-wave register top-k and shared threshold carry across cells.
+struct ResidualArgs {
+  const float* part1;       // [nq][m][256]        (mode A)
+  const float* part2;       // [n_cells][m][256]   (mode A)
+  const float* full;        // [nq][max_nprobe][m][256] (mode B) or nullptr
+  const int64_t* cells;     // [nq][max_nprobe]    (mode A)
+  const float* base_sims;   // [nq][max_nprobe]
+};
+
+template <int R>
+__global__ __launch_bounds__(kScanThreads) void scan_residual_kernel(ScanArgs a, ResidualArgs ra) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lut_bytes = a.m * 1024;
+  const int list_bytes = kScanWaves * R * 64 * 8;
+  const int region0 = lut_bytes > list_bytes ? lut_bytes : list_bytes;
+  float* lut = reinterpret_cast<float*>(smem);
+  float* qv_all = reinterpret_cast<float*>(smem + region0);
+  int* qi_all = reinterpret_cast<int*>(smem + region0 + kScanWaves * 256);
+  int* ptab = reinterpret_cast<int*>(smem + region0 + kScanWaves * 512);
+  ProbeTable tab{ptab, ptab + a.max_nprobe, ptab + 2 * a.max_nprobe};
+  unsigned* tau_key = reinterpret_cast<unsigned*>(ptab + 3 * a.max_nprobe + 1);
+
+  const int q = blockIdx.x;
+  const int wave = threadIdx.x >> 6;
+  const int lane = lane_id();
+  int n_probe = (int)a.n_probe_list[q];
+  n_probe = n_probe < 0 ? 0 : (n_probe > a.max_nprobe ? a.max_nprobe : n_probe);
+  if (wave == 0) {
+    build_probe_table(a, q, n_probe, tab);
+    if (lane == 0) *tau_key = f2key(-INFINITY);
+  }
+  __syncthreads();
+
+  WaveSelector<R> sel;
+  sel.init(qv_all + wave * 64, qi_all + wave * 64, a.k);
+  NoRefine refine;
+  const int G = a.m >> 2;
+  const uint32_t* __restrict__ codes32 = reinterpret_cast<const uint32_t*>(a.codes);
+  const int n4 = a.m * 64;  // float4 count of one LUT
+
+  for (int p = 0; p < n_probe; ++p) {
+    const int sz = tab.size[p];
+    if (sz == 0) continue;  // empty, or same start as the previous probe (ivfpq_topk.cu:1092-1107)
+    __syncthreads();        // every wave is done with the previous cell's LUT
+    float4* dst = reinterpret_cast<float4*>(lut);
+    if (ra.full) {
+      const float4* __restrict__ src =
+          reinterpret_cast<const float4*>(ra.full) + ((int64_t)q * a.max_nprobe + p) * n4;
+      for (int i = threadIdx.x; i < n4; i += kScanThreads) dst[i] = src[i];
+    } else {
+      const float4* __restrict__ s1 = reinterpret_cast<const float4*>(ra.part1) + (int64_t)q * n4;
+      const float4* __restrict__ s2 = reinterpret_cast<const float4*>(ra.part2) +
+                                      ra.cells[(int64_t)q * a.max_nprobe + p] * (int64_t)n4;
+      for (int i = threadIdx.x; i < n4; i += kScanThreads) {
+        const float4 x = s1[i], y = s2[i];
+        dst[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+      }
+    }
+    __syncthreads();
+    const float base = ra.base_sims[(int64_t)q * a.max_nprobe + p];
+    const int start = tab.start[p];
+    const int tiles = (sz + 63) >> 6;
+    for (int t = wave; t < tiles; t += kScanWaves) {
+      const int off = (t << 6) + lane;
+      const bool valid = off < sz;
+      const int s = start + off;
+      float v = base;
+      bool live = valid;
+      if (valid) {
+        if (a.is_empty) live = (a.is_empty[s] == 0);
+        for (int g = 0; g < G; ++g) {
+          const uint32_t w = codes32[(int64_t)g * a.n_slots + s];
+          const float* row = lut + g * 1024;
+          v += row[w & 255u];
+          v += row[256 + ((w >> 8) & 255u)];
+          v += row[512 + ((w >> 16) & 255u)];
+          v += row[768 + (w >> 24)];
+        }
+      }
+      const float tau_s = key2f(*reinterpret_cast<volatile unsigned*>(tau_key));
+      sel.tau = fmaxf(sel.tau, tau_s);
+      const float tau_before = sel.tau;
+      sel.push(live && (v >= sel.tau), v + 0.0f, s, refine);
+      if (sel.tau > tau_before && lane == 0) atomicMax(tau_key, f2key(sel.tau));
+    }
+  }
+  sel.flush(refine);
+  finish_query<R>(a, q, 0, sel.top, reinterpret_cast<float*>(smem),
+                  reinterpret_cast<int*>(smem + kScanWaves * R * 64 * 4));
+}
+
+// part1[q][j][c] = 2 * (q_j . r_jc), dots as ascending-dimension fma chains
+// (IVFPQIndex.precomputed_adc_residual_precomputed, index/IVFPQIndex.py:366-379)
+__global__ __launch_bounds__(256) void residual_part1_kernel(const float* __restrict__ query,
+                                                            const float* __restrict__ codebook,
+                                                            float* __restrict__ part1, int m,
+                                                            int ds, int nq) {
+  const int j = blockIdx.y, q = blockIdx.x, c = threadIdx.x;
+  float dot = 0.f;
+  for (int e = 0; e < ds; ++e)
+    dot = fmaf(query[(int64_t)(j * ds + e) * nq + q], codebook[((int64_t)j * ds + e) * 256 + c], dot);
+  part1[((int64_t)q * m + j) * 256 + c] = 2.f * dot;
+}
+
 // ---- packed-layout kernel ------------------------------------------------------------------
 // LUT in LDS in block order (scan_layout.h): entry (j, c) at dword lut_dword(M, j, c); the slot at
 // address s stores at byte position p the code of sub-quantizer subq_at(M, p, s), so lane (slot s)
@@ -817,4 +927,53 @@ extern "C" int tpq_ivfpq_scan_topk_packed(const uint8_t* packed, const uint8_t* 
   b.n_split = 1;
   b.only_flagged = a.flags;
   return dispatch_ref(b, list_regs(k), st);
+}
+
+extern "C" int tpq_ivfpq_scan_topk_residual(const uint8_t* codes, const float* part1,
+                                            const float* part2, const float* full_lut,
+                                            const int64_t* cells, const float* base_sims,
+                                            const uint8_t* is_empty, const int64_t* cell_start,
+                                            const int64_t* cell_size, const int64_t* n_probe_list,
+                                            float* out_vals, int64_t* out_addr,
+                                            const int64_t* address2id, int64_t* out_ids,
+                                            int64_t n_slots, int nq, int max_nprobe, int m, int k,
+                                            tpq_stream_t stream) {
+  ScanArgs a{codes, nullptr, part1 ? part1 : full_lut, is_empty, cell_start, cell_size, n_probe_list,
+             out_vals, out_addr, address2id, out_ids, nullptr, nullptr, nullptr, nullptr, nullptr,
+             n_slots, nq, max_nprobe, m, k, 1};
+  int rc = validate(a);
+  if (rc) return rc;
+  TPQ_REQUIRE(base_sims != nullptr, "ivfpq_scan_residual: base_sims is required");
+  TPQ_REQUIRE(full_lut != nullptr || (part1 && part2 && cells),
+              "ivfpq_scan_residual: need either full_lut or (part1, part2, cells)");
+  if (nq == 0) return TPQ_OK;
+  ResidualArgs ra{part1, part2, full_lut, cells, base_sims};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int R = list_regs(k);
+  const size_t lds = scan_lds_bytes_ref(m, R, max_nprobe);
+  auto go = [&](auto kernel) -> int {
+    int rc2 = set_lds(kernel, lds, "scan_residual_kernel");
+    if (rc2) return rc2;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)nq), dim3(kScanThreads), lds, st, a, ra);
+    TPQ_LAUNCH_CHECK("scan_residual_kernel");
+    return TPQ_OK;
+  };
+  switch (R) {
+    case 1: return go(scan_residual_kernel<1>);
+    case 2: return go(scan_residual_kernel<2>);
+    case 4: return go(scan_residual_kernel<4>);
+    case 8: return go(scan_residual_kernel<8>);
+    default: return go(scan_residual_kernel<16>);
+  }
+}
+
+extern "C" int tpq_residual_part1(const float* query, const float* codebook, float* part1, int m,
+                                  int ds, int nq, tpq_stream_t stream) {
+  TPQ_REQUIRE(query && codebook && part1, "residual_part1: null pointer");
+  TPQ_REQUIRE(m >= 1 && m <= 65535 && ds >= 1 && nq >= 0, "residual_part1: bad shape");
+  if (nq == 0) return TPQ_OK;
+  hipLaunchKernelGGL(residual_part1_kernel, dim3(nq, m), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), query, codebook, part1, m, ds, nq);
+  TPQ_LAUNCH_CHECK("residual_part1_kernel");
+  return TPQ_OK;
 }

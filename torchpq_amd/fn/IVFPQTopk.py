@@ -18,9 +18,20 @@ class IVFPQTopk:
                                n_probe_list=n_probe_list, n_candidates=k, packed=packed,
                                address2id=address2id)
 
-    def topk_residual(self, *a, **k):
-        raise NotImplementedError(
-            "residual PQ search (ivfpq_topk_residual, ivfpq_topk.cu:973-1037) is SURVEY 8(f) "
-            "rank 3: not built yet")
+    def topk_residual(self, data, precomputed, cell_start, cell_size, base_sims, is_empty,
+                      n_probe_list, k=256, address2id=None):
+        """one LUT per (query, probe): precomputed [n_query, n_probe, m, 256] (:106-161)"""
+        assert 0 < k <= 1024
+        return self._scan.topk_residual(data=data, precomputed=precomputed, base_sims=base_sims,
+                                        is_empty=is_empty, cell_start=cell_start,
+                                        cell_size=cell_size, n_probe_list=n_probe_list,
+                                        n_candidates=k, address2id=address2id)
 
-    topk_residual_precomputed = topk_residual
+    def topk_residual_precomputed(self, data, part1, part2, cell_start, cell_size, cells, base_sims,
+                                  is_empty, n_probe_list=None, k=256, address2id=None):
+        """LUT of a probe = part1[query] + part2[cell] (:163-228)"""
+        assert 0 < k <= 1024
+        return self._scan.topk_residual_precomputed(
+            data=data, part1=part1, part2=part2, cells=cells, base_sims=base_sims,
+            is_empty=is_empty, cell_start=cell_start, cell_size=cell_size,
+            n_probe_list=n_probe_list, n_candidates=k, address2id=address2id)

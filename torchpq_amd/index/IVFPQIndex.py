@@ -3,8 +3,8 @@
 Same constructor, methods, properties, asserts, tensor layouts ([d_vector, n] fp32 in, ids
 int64 out, values descending with (-inf, -1) padding) and state_dict keys.  Everything below
 the Python API runs in hand-written HIP kernels for gfx950 (libtorchpq_amd.so); the only
-library math is the coarse query x cell-centroid GEMM (rocBLAS via torch.matmul, as the
-reference uses cuBLAS).  Not built: pq_use_residual=True.
+library math is the coarse query x cell-centroid GEMM and the one-off residual tables
+(rocBLAS via torch.matmul/bmm, as the reference uses cuBLAS).
 """
 import torch
 
@@ -26,10 +26,6 @@ class IVFPQIndex(CellContainer):
         assert n_subvectors % 4 == 0, "codes are stored 4 sub-quantizers per word (contiguous_size=4)"
         assert distance in ("euclidean", "cosine"), \
             "euclidean and cosine work end to end (MultiKMeans.py:82-113)"
-        if pq_use_residual:
-            raise NotImplementedError(
-                "pq_use_residual=True (ivfpq_topk_residual*, ivfpq_topk.cu:973-1208) is not built "
-                "yet -- SURVEY 8(f) rank 3")
         super().__init__(code_size=n_subvectors, n_cells=n_cells, dtype="uint8", device=device,
                          initial_size=initial_size, expand_step_size=expand_step_size,
                          expand_mode=expand_mode, use_inverse_id_mapping=True, contiguous_size=4,
@@ -41,7 +37,9 @@ class IVFPQIndex(CellContainer):
         self.verbose = verbose
         self.pq_use_residual = pq_use_residual
         self.n_probe = 1
-        self._use_precomputed = False
+        # residual search keeps a [n_cells, m, 256] table when it fits 4 GiB (IVFPQIndex.py:52-55)
+        self._use_precomputed = bool(pq_use_residual and
+                                     (n_cells * 256 * n_subvectors * 4) <= 4 * 1024 ** 3)
         self._precomputed_part2 = None
         self._use_cublas = True
         self._use_smart_probing = True
@@ -120,7 +118,18 @@ class IVFPQIndex(CellContainer):
         assert type(value) is bool
         if value:
             assert self.pq_use_residual, " `use_precomputed=True` is only valid when `pq_use_residual` is True"
+            assert (self.pq_codec.is_trained and self.vq_codec.is_trained), "index is not trained"
+            self.precompute_part2()
+        else:
+            self._precomputed_part2 = None
         self._use_precomputed = value
+
+    def precompute_part2(self):
+        """[m, n_cells, 256]: -2 c_j . r_jc - |r_jc|^2 (reference :160-170; one-off library bmm)"""
+        pq_codebook = self.pq_codec.codebook
+        vq_codebook = self.vq_codec.codebook.reshape(self.n_subvectors, self.d_subvector, self.n_cells)
+        self._precomputed_part2 = (torch.bmm(vq_codebook.transpose(-1, -2), pq_codebook) * -2
+                                   - pq_codebook.norm(dim=1).pow(2)[:, None])
 
     def _codec_knob(codec, attr, typed):
         def getter(self):
@@ -144,6 +153,7 @@ class IVFPQIndex(CellContainer):
 
     def _after_load_state_dict(self):
         self.to(self.device)
+        self._precomputed_part2 = None
         super()._after_load_state_dict()
 
     # ---- train / encode / add (reference :234-364) ------------------------------------------------
@@ -159,9 +169,15 @@ class IVFPQIndex(CellContainer):
             x = util.normalize(x, dim=0)
         x = x.contiguous()
         self.print_message("start training VQ codec...", 1)
-        self.vq_codec.train(x)
+        code = self.vq_codec.train(x)
         self.print_message("start training PQ codec...", 1)
-        self.pq_codec.train(x)
+        if self.pq_use_residual:
+            # PQ is learnt on x - centroid(x); the caller's tensor is left untouched (the reference
+            # subtracts and re-adds in place, :246-254)
+            self.pq_codec.train((x - self.vq_codec.decode(code)).contiguous())
+            self._precomputed_part2 = None
+        else:
+            self.pq_codec.train(x)
         self.print_message("index is trained successfully!", 1)
 
     def encode(self, x):
@@ -171,10 +187,20 @@ class IVFPQIndex(CellContainer):
         x = x.to(self.device)
         if self.distance == "cosine":
             x = util.normalize(x)
-        return self.pq_codec.encode(x.contiguous())
+        x = x.contiguous()
+        if self.pq_use_residual:  # (pq_code, vq_code) of the residual x - centroid (:276-281)
+            return self._encode_raw(x)
+        return self.pq_codec.encode(x)
 
     def decode(self, x):
-        """codes [n_subvectors, n] uint8 -> [d_vector, n] f32"""
+        """codes [n_subvectors, n] uint8 -> [d_vector, n] f32; with pq_use_residual `x` is the
+        pair (pq_code, vq_code) and the result is centroid + decoded residual (:301-309)"""
+        if self.pq_use_residual:
+            assert len(x) == 2
+            pq_code, vq_code = x
+            assert pq_code.shape[0] == self.n_subvectors
+            assert pq_code.shape[1] == vq_code.shape[0]
+            return self.vq_codec.decode(vq_code.to(self.device)) + self.pq_codec.decode(pq_code.to(self.device))
         assert len(x.shape) == 2
         assert x.shape[0] == self.n_subvectors
         return self.pq_codec.decode(x.to(self.device))
@@ -188,9 +214,38 @@ class IVFPQIndex(CellContainer):
         if self.distance == "cosine":
             x = util.normalize(x)
         x = x.contiguous()
-        assigned_cells = self.vq_codec.encode(x)
-        codes = self.pq_codec.encode(x)
+        if self.pq_use_residual:
+            codes, assigned_cells = self._encode_raw(x)
+        else:
+            assigned_cells = self.vq_codec.encode(x)
+            codes = self.pq_codec.encode(x)
         return super().add(codes, cells=assigned_cells, ids=ids, return_address=return_address)
+
+    def _encode_raw(self, x):
+        """residual encode of an already normalised x"""
+        vq_code = self.vq_codec.encode(x)
+        return self.pq_codec.encode((x - self.vq_codec.decode(vq_code)).contiguous()), vq_code
+
+    # ---- residual tables (reference :366-405) -----------------------------------------------------
+    def precomputed_adc_residual_precomputed(self, x):
+        """(part1 [n_query, m, 256] = 2 q_j.r_jc,  part2 [n_cells, m, 256])"""
+        from ..kernels import ResidualPart1Hip
+        part1 = ResidualPart1Hip()(x, self.pq_codec.codebook)
+        if self._precomputed_part2 is None:
+            self.precompute_part2()
+        return part1, self._precomputed_part2.transpose(0, 1)
+
+    def precomputed_adc_residual(self, x, cells):
+        """[n_query, n_probe, m, 256]: one LUT per (query, probe); memory-hungry, used only when
+        the part2 table is disabled (use_precomputed=False)"""
+        n_query, n_probe = cells.shape
+        pq_codebook = self.pq_codec.codebook
+        xs = x.reshape(self.n_subvectors, self.d_subvector, n_query).transpose(-1, -2)
+        part1 = 2 * (xs @ pq_codebook).permute(1, 0, 2) - pq_codebook.norm(dim=1).pow(2)[None]
+        vq = self.vq_codec.codebook.reshape(self.n_subvectors, self.d_subvector, self.n_cells)
+        vq = vq[:, :, cells].permute(0, 2, 3, 1)                       # [m, nq, n_probe, ds]
+        part2 = -2 * (vq @ pq_codebook[:, None].expand(-1, n_query, -1, -1))  # [m, nq, n_probe, 256]
+        return (part1[:, None] + part2.permute(1, 2, 0, 3)).contiguous()
 
     # ---- search (reference :407-524) ---------------------------------------------------------------
     def search_cells(self, x, cells, base_sims=None, n_probe_list=None, k=1, return_address=False):
@@ -200,6 +255,24 @@ class IVFPQIndex(CellContainer):
             n_probe_list = torch.full((n_query,), cells.shape[1], device=self.device, dtype=torch.long)
         cell_start = self._cell_start[cells]
         cell_size = self._cell_size[cells]
+        if self.pq_use_residual:
+            assert base_sims is not None, "base_sims is required when pq_use_residual is True"
+            is_empty = self._is_empty if self._has_holes else None
+            if self.use_precomputed:
+                part1, part2 = self.precomputed_adc_residual_precomputed(x)
+                topk_val, topk_address, topk_ids = self._ivfpq_topk.topk_residual_precomputed(
+                    data=self._storage, part1=part1, part2=part2, cells=cells, base_sims=base_sims,
+                    cell_start=cell_start, cell_size=cell_size, is_empty=is_empty,
+                    n_probe_list=n_probe_list, k=k, address2id=self._address2id)
+            else:
+                precomputed = self.precomputed_adc_residual(x, cells)
+                topk_val, topk_address, topk_ids = self._ivfpq_topk.topk_residual(
+                    data=self._storage, base_sims=base_sims, precomputed=precomputed,
+                    cell_start=cell_start, cell_size=cell_size, is_empty=is_empty,
+                    n_probe_list=n_probe_list, k=k, address2id=self._address2id)
+            if return_address:
+                return topk_val, topk_ids, topk_address
+            return topk_val, topk_ids
         precomputed = self.pq_codec.precompute_adc(x)
         packed = None
         if self.use_packed_layout:

@@ -15,7 +15,7 @@ from .. import _lib
 from .._lib import check, load, ptr, require_gpu, stream_ptr
 
 __all__ = [
-    "IVFPQTopkHip", "IVFPQTop1Hip", "AdcLutHip", "TopkSelectHip", "Top1SelectHip",
+    "IVFPQTopkHip", "IVFPQTop1Hip", "ResidualPart1Hip", "AdcLutHip", "TopkSelectHip", "Top1SelectHip",
     "Top32SelectHip", "SmartProbingHip", "MaxSimHip", "ComputeCentroidsHip", "GetIOAHip",
     "GetWriteAddressHip", "GetCellByAddressHip", "GetIdByAddressHip", "PQDecodeHip",
     "ScatterCodesHip", "PackCodesHip", "packed_chunk_width", "PACKED_M",
@@ -126,6 +126,85 @@ class IVFPQTopkHip:
             ev[1].record(torch.cuda.current_stream(device))
             self.record_events.append(ev)
         return (values, address) if ids is None else (values, address, ids)
+
+
+    # ---- residual PQ (pq_use_residual=True) ------------------------------------------------------
+    def _residual(self, data, part1, part2, full, cells, base_sims, is_empty, cell_start, cell_size,
+                  n_probe_list, n_candidates, address2id):
+        n_data = data.shape[1]
+        n_query, n_probe = cell_start.shape
+        assert data.shape == (self.m // self.n_cs, n_data, self.n_cs)
+        assert cell_size.shape == (n_query, n_probe)
+        assert base_sims.shape == (n_query, n_probe)
+        assert data.dtype == torch.uint8
+        assert cell_start.dtype == cell_size.dtype == torch.int64
+        assert base_sims.dtype == torch.float32
+        assert n_probe_list.shape == (n_query,)
+        assert n_probe_list.dtype == torch.int64
+        if is_empty is not None:
+            assert is_empty.shape == (n_data,) and is_empty.dtype == torch.uint8
+        if n_candidates is None:
+            n_candidates = self.tpb
+        assert 0 < n_candidates <= 1024
+        # logical [q][j][c] / [cell][j][c] / [q][p][j][c] order, whatever view the caller built
+        part1 = None if part1 is None else part1.contiguous()
+        part2 = None if part2 is None else part2.contiguous()
+        full = None if full is None else full.contiguous()
+        cells = None if cells is None else cells.contiguous()
+        base_sims = base_sims.contiguous()
+        require_gpu(data, part1, part2, full, cells, base_sims, is_empty, cell_start, cell_size,
+                    n_probe_list, address2id)
+        device = data.device
+        k = n_candidates
+        values = torch.empty(n_query, k, device=device, dtype=torch.float32)
+        address = torch.empty(n_query, k, device=device, dtype=torch.int64)
+        ids = torch.empty(n_query, k, device=device, dtype=torch.int64) if address2id is not None else None
+        if n_query:
+            with torch.cuda.device(device):
+                check(load().tpq_ivfpq_scan_topk_residual(
+                    ptr(data), ptr(part1), ptr(part2), ptr(full), ptr(cells), ptr(base_sims),
+                    ptr(is_empty), ptr(cell_start), ptr(cell_size), ptr(n_probe_list), ptr(values),
+                    ptr(address), ptr(address2id), ptr(ids), n_data, n_query, n_probe, self.m, k,
+                    stream_ptr(device)), "tpq_ivfpq_scan_topk_residual")
+        return (values, address) if ids is None else (values, address, ids)
+
+    def topk_residual(self, data, precomputed, base_sims, is_empty, cell_start, cell_size,
+                      n_probe_list, n_candidates=None, address2id=None):
+        """precomputed: [n_query, max_n_probe, m, 256] f32 -- one LUT per (query, probe)
+        (kernels/IVFPQTopkCuda.py:144-210)."""
+        n_query, n_probe = cell_start.shape
+        assert precomputed.shape == (n_query, n_probe, self.m, self.k)
+        assert precomputed.dtype == torch.float32
+        return self._residual(data, None, None, precomputed, None, base_sims, is_empty, cell_start,
+                              cell_size, n_probe_list, n_candidates, address2id)
+
+    def topk_residual_precomputed(self, data, part1, part2, cells, base_sims, is_empty, cell_start,
+                                  cell_size, n_probe_list, n_candidates=None, address2id=None):
+        """part1 [n_query, m, 256], part2 [n_cells, m, 256] f32, cells [n_query, max_n_probe] int64
+        (kernels/IVFPQTopkCuda.py:212-283)."""
+        n_query = cell_start.shape[0]
+        assert part1.shape == (n_query, self.m, self.k) and part2.shape[1:] == (self.m, self.k)
+        assert part1.dtype == part2.dtype == torch.float32
+        assert cells.shape == cell_start.shape and cells.dtype == torch.int64
+        return self._residual(data, part1, part2, None, cells, base_sims, is_empty, cell_start,
+                              cell_size, n_probe_list, n_candidates, address2id)
+
+
+class ResidualPart1Hip:
+    """part1[q, j, c] = 2 * q_j . r_jc (index/IVFPQIndex.py:366-379), [n_query, m, 256] f32."""
+
+    def __call__(self, query, codebook):
+        m, ds, k = codebook.shape
+        assert k == 256 and query.shape[0] == m * ds
+        query = query.contiguous()
+        codebook = codebook.contiguous()
+        require_gpu(query, codebook)
+        nq = query.shape[1]
+        out = torch.empty(nq, m, 256, device=query.device, dtype=torch.float32)
+        with torch.cuda.device(query.device):
+            check(load().tpq_residual_part1(ptr(query), ptr(codebook), ptr(out), m, ds, nq,
+                                            stream_ptr(query.device)), "tpq_residual_part1")
+        return out
 
 
 class IVFPQTop1Hip(IVFPQTopkHip):
