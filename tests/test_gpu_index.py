@@ -283,3 +283,37 @@ def test_residual_index_end_to_end(use_precomputed):
     rec = N(idx.decode((pq_code[:, top], vq_code[top])))
     exact = -((queries - rec) ** 2).sum(0)
     np.testing.assert_allclose(N(v)[:, 0], exact, rtol=2e-3, atol=2e-3 * np.abs(exact).max())
+
+
+def test_flat_index_exact_search():
+    """FlatIndex: exact neighbours, ids, removal; doubles as recall ground truth."""
+    from torchpq_amd.index import FlatIndex, IVFPQIndex
+    rng = np.random.default_rng(9)
+    d, n, nq, k = 24, 5000, 64, 20
+    base = rng.standard_normal((d, n)).astype(np.float32)
+    queries = rng.standard_normal((d, nq)).astype(np.float32)
+    flat = FlatIndex(d_vector=d, initial_size=16, device=DEV)
+    ids = torch.arange(n, device=DEV) * 2 + 5
+    flat.add(T(base[:, :3000]), ids=ids[:3000])
+    flat.add(T(base[:, 3000:]), ids=ids[3000:])
+    assert flat.n_items == n
+    v, i = flat.search(T(queries), k=k)
+    d2 = -((queries.T[:, None, :] - base.T[None, :, :]) ** 2).sum(-1)
+    order = np.argsort(-d2, axis=1, kind="stable")[:, :k]
+    assert (N(i) == N(ids)[order]).mean() > 0.999  # GEMM-form rounding may swap exact near-ties
+    np.testing.assert_allclose(N(v), np.take_along_axis(d2, order, 1), rtol=1e-4, atol=1e-4)
+    flat.remove(ids=ids[order[:, 0]].unique())
+    v2, i2 = flat.search(T(queries), k=1)
+    assert not np.isin(N(i2)[:, 0], N(ids)[order[:, 0]]).any()
+    # recall of the IVFPQ index against it
+    np.random.seed(9)
+    ivf = IVFPQIndex(d_vector=d, n_subvectors=12, n_cells=32, initial_size=256, device=DEV)
+    ivf.train(T(base))
+    ivf.add(T(base), ids=ids)
+    ivf.n_probe = 32
+    flat2 = FlatIndex(d_vector=d, device=DEV)
+    flat2.add(T(base), ids=ids)
+    _, gt = flat2.search(T(queries), k=1)
+    _, got = ivf.search(T(queries), k=k)
+    recall = (got == gt).any(dim=1).float().mean().item()
+    assert recall > 0.8, recall

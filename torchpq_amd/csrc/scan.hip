@@ -4,25 +4,29 @@
 // ivfpq_top1.cu:385-455) and their launchers (torchpq/kernels/IVFPQTopkCuda.py:81-142).
 //
 // Structure:
-//   * one workgroup of 8 waves per (query, split); the query's 256-entry-per-sub-quantizer
-//     LUT (m KB fp32) is staged in LDS; each wave walks its share of the probed cells in
-//     64-slot tiles, one slot per lane, codes streamed straight from HBM to VGPRs;
+//   * one workgroup per (query, split); the query's 256-entry-per-sub-quantizer LUT (m KiB fp32)
+//     is staged in LDS; each wave walks its round-robin share of the probed cells in 64-slot
+//     tiles, one slot per lane, codes streamed straight from HBM to VGPRs;
 //   * value(slot) = sum_j LUT[j][code_j] in fp32, ascending j from 0.f -- bit-identical to
 //     consume_data (ivfpq_topk.cu:662-679);
 //   * per-wave register top-k (wave_topk.h) + a workgroup-shared admission threshold in LDS;
-//     no barrier inside the scan loop; one tree merge across the 8 waves at the end;
+//     no barrier inside the scan loop;
 //   * n_split > 1 splits a query's tiles over several workgroups (small batches must still
-//     fill 256 CUs; the reference's grid=(nq,) cannot) and a tiny merge kernel joins them.
+//     fill 256 CUs; the reference's grid=(nq,) cannot).
 //
-// Two code layouts:
-//   scan_ref_kernel    streams CellContainer._storage as is ([m/4][n_slots][4]); LDS lookups
-//                      hit random banks (~3.5 cycles per half-wave access).
-//   scan_packed_kernel streams the MI355X scan layout (pack.hip): per-slot XOR-permuted
-//                      sub-quantizer order so the 32 lanes of a half-wave always read 32
-//                      distinct banks (1 cycle).  The permuted order changes the fp32
-//                      summation order, so it is used only as a conservative FILTER; every
-//                      survivor (~1-2 % of slots) is re-evaluated in ascending-j order from
-//                      the reference layout before it is ranked => results stay bit-identical.
+// Kernels:
+//   scan_ref_kernel      streams CellContainer._storage as is ([m/4][n_slots][4], any m % 4 == 0):
+//                        the drop-in at the IVFPQTopkCuda.topk boundary and the exact fallback.
+//                        LDS look-ups hit random banks (~3.5 cycles per half-wave access); the 8
+//                        waves' lists are tree-merged in the workgroup.
+//   scan_residual_kernel residual PQ (per-cell LUT), reference layout, exact.
+//   scan_packed_kernel   streams the MI355X scan layout (pack.hip / scan_layout.h): per-slot
+//                        XOR-permuted sub-quantizer order so the 32 lanes of a half-wave always
+//                        read 32 distinct banks.  The permuted summation order makes its value
+//                        a SELECTION key only; each wave re-evaluates its few surviving
+//                        candidates exactly (ascending j) at the end of the query and dumps its
+//                        list; scan_merge_refine_kernel (one wave per query) merges the lists.
+//                        Results are bit-identical to scan_ref_kernel.
 #include "common.h"
 #include "scan_layout.h"
 #include "wave_topk.h"
@@ -161,22 +165,6 @@ __device__ __forceinline__ void stage_lut_linear(const ScanArgs& a, int q, float
     const int j = i >> 6, c4 = i & 63;
     dst[i] = src[((int64_t)j * a.nq + q) * 64 + c4];
   }
-}
-
-// exact value of one slot in the reference's order (ascending j), LUT linear in LDS
-__device__ __forceinline__ float exact_value_linear(const uint32_t* __restrict__ codes32,
-                                                    int64_t n_slots, int s, int G,
-                                                    const float* lut) {
-  float v = 0.f;
-  for (int g = 0; g < G; ++g) {
-    const uint32_t w = codes32[(int64_t)g * n_slots + s];
-    const float* row = lut + g * 1024;
-    v += row[w & 255u];
-    v += row[256 + ((w >> 8) & 255u)];
-    v += row[512 + ((w >> 16) & 255u)];
-    v += row[768 + (w >> 24)];
-  }
-  return v;
 }
 
 // ---- reference-layout kernel ---------------------------------------------------------------
@@ -385,12 +373,15 @@ __global__ __launch_bounds__(256) void residual_part1_kernel(const float* __rest
 //
 // The permuted order changes the fp32 summation order, so the streamed value f ("fast") is
 // used for SELECTION only: with |f - e| <= delta (e = the reference's ascending-order value),
-// every element of the exact top-k has f >= F_k - 2*delta (F_k = k-th best fast value).  The
-// lists keep the best 64R > k candidates by f; at the end of the query the survivors are
-// re-evaluated exactly (ascending j, from the packed bytes), re-ranked by (e desc, address
-// asc) and the best k written -- bit-identical to the reference-layout kernel.  If more than
-// 64R candidates crowd into the 2*delta band (pathological ties) the query is flagged and
-// redone by scan_ref_kernel.
+// every element of the exact top-k has f >= F_k - 2*delta (F_k = k-th best fast value).  Each
+// wave keeps its best 64R > k candidates by f and admits everything down to threshold - 2*delta.
+// At the end of the query a wave re-evaluates the entries that can still matter
+// (f >= shared threshold - 2*delta: ~k/8 of them) exactly -- ascending j, from the packed bytes
+// un-permuted through a private LDS row, LUT still resident -- re-ranks them by (e desc, address
+// asc) and dumps the list; scan_merge_refine_kernel merges the per-wave lists of a query and
+// writes the best k: bit-identical to the reference-layout kernel.  If a merged list ends up so
+// full of near-ties (more than 64R candidates within 2*delta of the k-th) that a member of the
+// exact top-k may have been evicted, the query is flagged and redone by scan_ref_kernel.
 
 __device__ __forceinline__ void stage_lut_blocked(const ScanArgs& a, int q, float* lut,
                                                   int n_threads) {
@@ -417,14 +408,6 @@ struct LdsLut {
     return lut[scan_layout::lut_dword(M, j, (int)c)];
   }
 };
-struct GlobalLut {
-  const float* lut;  // [m][nq][256]
-  int nq, q;
-  __device__ __forceinline__ float operator()(int j, unsigned c) const {
-    return lut[((int64_t)j * nq + q) * 256 + c];
-  }
-};
-
 // Exact (ascending-j) value of slot `idx` from its PACKED bytes: the lane un-permutes its slot
 // into sub-quantizer order through a private LDS row (stride M/4+1 dwords: conflict-free), then
 // sums LUT entries in the reference's order.

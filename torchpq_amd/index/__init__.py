@@ -1,1 +1,2 @@
+from .FlatIndex import FlatIndex
 from .IVFPQIndex import IVFPQIndex
