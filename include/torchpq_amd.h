@@ -95,6 +95,20 @@ int tpq_ivfpq_scan_topk_packed(const uint8_t* packed, const uint8_t* codes, cons
                                int k, int n_split, void* workspace, size_t workspace_bytes,
                                tpq_stream_t stream);
 
+/* Fused a-3 + a-1: the scan workgroup builds its query's LUT itself from the query and the PQ
+ * codebook (bit-identical entries to tpq_adc_lut: same fma chains), so the [m][nq][256] table is
+ * never written to or read from HBM.  This is what IVFPQIndex.search_cells
+ * (torchpq/index/IVFPQIndex.py:452-461: precompute_adc + IVFPQTopk.topk) collapses to.
+ * query f32 [m*ds][nq], codebook f32 [m][ds][256]; `packed` may be NULL (reference-layout
+ * kernel); everything else as tpq_ivfpq_scan_topk[_packed]. */
+int tpq_ivfpq_search_fused(const uint8_t* packed, const uint8_t* codes, const float* query,
+                           const float* codebook, int ds, int metric, const uint8_t* is_empty,
+                           const int64_t* cell_start, const int64_t* cell_size,
+                           const int64_t* n_probe_list, float* out_vals, int64_t* out_addr,
+                           const int64_t* address2id, int64_t* out_ids, int64_t n_slots, int nq,
+                           int max_nprobe, int m, int k, int n_split, void* workspace,
+                           size_t workspace_bytes, tpq_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * SURVEY 8(f)-3  residual-PQ list scan (pq_use_residual=True)
  * replaces IVFPQTopkCuda.topk_residual_precomputed  torchpq/kernels/IVFPQTopkCuda.py:212-283

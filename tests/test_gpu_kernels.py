@@ -375,3 +375,30 @@ def test_residual_scan_random_vs_oracle(K, m, k, n_probe, tomb):
     v, a = scan.topk_residual_precomputed(T(storage), T(part1), T(part2), T(cells), T(base),
                                           T(is_empty), T(cs), T(sz), T(npl), n_candidates=k)
     assert np.array_equal(N(v), ev) and np.array_equal(N(a), ea)
+
+
+@pytest.mark.parametrize("m,ds,k,layout,distance", [(64, 2, 100, "packed", "euclidean"), (16, 4, 10, "packed", "cosine"),
+                                                    (120, 8, 50, "packed", "euclidean"), (24, 3, 7, "ref", "euclidean"),
+                                                    (8, 16, 130, "ref", "euclidean")])
+def test_fused_lut_scan_equals_lut_then_scan(K, m, ds, k, layout, distance):
+    """tpq_ivfpq_search_fused (LUT built inside the scan workgroups) == tpq_adc_lut + scan, bit for bit."""
+    rng = np.random.default_rng(m + ds + k)
+    n_cells, nq, n_probe = 30, 33, 9
+    storage, is_empty, start, sizes, a2i = _random_index(rng, m, n_cells, 160, 0, 0.0)
+    cb = (rng.standard_normal((m, ds, 256)) * 20).astype(np.float32)
+    q = (rng.standard_normal((m * ds, nq)) * 20).astype(np.float32)
+    cells = np.stack([rng.permutation(n_cells)[:n_probe] for _ in range(nq)])
+    npl = rng.integers(1, n_probe + 1, nq).astype(np.int64)
+    cs, sz = T(start[cells]), T(sizes[cells])
+    scan = K.IVFPQTopkHip(m=m)
+    st = T(storage)
+    packed = K.PackCodesHip()(st) if layout == "packed" else None
+    lut = K.AdcLutHip()(T(q), T(cb), distance)
+    for n_split in (1, 2):
+        v0, a0 = scan.topk(st, lut, None, cs, sz, T(npl), n_candidates=k, packed=packed, n_split=n_split)
+        v1, a1, i1 = scan.topk_fused(st, T(q), T(cb), None, cs, sz, T(npl), n_candidates=k,
+                                     distance=distance, packed=packed, address2id=T(a2i), n_split=n_split)
+        assert torch.equal(v0, v1) and torch.equal(a0, a1)
+    ev, ea = c_oracle.scan_topk(storage, c_oracle.adc_lut(q, cb, distance), is_empty, start[cells],
+                                sizes[cells], npl, k)
+    assert np.array_equal(N(v1), ev) and np.array_equal(N(a1), ea)

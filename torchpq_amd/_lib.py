@@ -28,6 +28,8 @@ SIGNATURES = {
     "tpq_ivfpq_pack_codes": (_i, [_vp, _vp, _i64, _i, _i64, _i64, _vp]),
     "tpq_ivfpq_scan_topk_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
                                         _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "tpq_ivfpq_search_fused": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    _i64, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "tpq_ivfpq_scan_topk_residual": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "tpq_residual_part1": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -39,7 +39,10 @@ constexpr int kScanThreads = kScanWaves * 64;
 struct ScanArgs {
   const uint8_t* codes;    // reference layout [m/4][n_slots][4]
   const uint8_t* packed;   // scan layout (packed kernel only)
-  const float* lut;        // [m][nq][256]
+  const float* lut;        // [m][nq][256]; nullptr = build the LUT in the workgroup ("fused")
+  const float* query;      // fused: [m*ds][nq]
+  const float* codebook;   // fused: [m][ds][256]
+  int ds, euclid;          // fused: sub-vector length, 1 = 2ab-a^2-b^2 / 0 = dot
   const uint8_t* is_empty; // nullable
   const int64_t* cell_start;
   const int64_t* cell_size;
@@ -157,13 +160,54 @@ __device__ __forceinline__ void finish_query(const ScanArgs& a, int q, int part,
   }
 }
 
-__device__ __forceinline__ void stage_lut_linear(const ScanArgs& a, int q, float* lut) {
+// ---- LUT built inside the workgroup ("fused") ------------------------------------------------
+// Instead of reading a materialised [m][nq][256] table (a-3 writes 655 MB and the scan reads it
+// back at C2), the workgroup computes its query's LUT from the query and the PQ codebook, which
+// stays L2-resident (m*ds KiB).  The arithmetic is adc_lut_kernel's, operation for operation --
+// dot, |q|^2 and |c|^2 as ascending-dimension fma chains, then 2*dot, -|q|^2, -|c|^2 -- so the
+// entries are bit-identical to tpq_adc_lut's.
+__device__ __forceinline__ void stage_query(const ScanArgs& a, int q, float* xq, float* q2s,
+                                            int n_threads) {
+  const int d = a.m * a.ds;
+  for (int i = threadIdx.x; i < d; i += n_threads) xq[i] = a.query[(int64_t)i * a.nq + q];
+  __syncthreads();
+  for (int j = threadIdx.x; j < a.m; j += n_threads) {
+    float s = 0.f;
+    for (int e = 0; e < a.ds; ++e) s = fmaf(xq[j * a.ds + e], xq[j * a.ds + e], s);
+    q2s[j] = s;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float4 fused_lut4(const ScanArgs& a, int j, int c4, const float* xq,
+                                             const float* q2s) {
+  const float4* __restrict__ cb = reinterpret_cast<const float4*>(a.codebook) + (int64_t)j * a.ds * 64 + c4;
+  float4 dot = make_float4(0.f, 0.f, 0.f, 0.f), c2 = dot;
+  for (int e = 0; e < a.ds; ++e) {
+    const float4 y = cb[e * 64];
+    const float x = xq[j * a.ds + e];
+    dot.x = fmaf(x, y.x, dot.x); dot.y = fmaf(x, y.y, dot.y);
+    dot.z = fmaf(x, y.z, dot.z); dot.w = fmaf(x, y.w, dot.w);
+    c2.x = fmaf(y.x, y.x, c2.x); c2.y = fmaf(y.y, y.y, c2.y);
+    c2.z = fmaf(y.z, y.z, c2.z); c2.w = fmaf(y.w, y.w, c2.w);
+  }
+  if (!a.euclid) return dot;
+  const float q2 = q2s[j];
+  float4 v;
+  v.x = 2.f * dot.x; v.y = 2.f * dot.y; v.z = 2.f * dot.z; v.w = 2.f * dot.w;
+  v.x = v.x - q2; v.y = v.y - q2; v.z = v.z - q2; v.w = v.w - q2;
+  v.x = v.x - c2.x; v.y = v.y - c2.y; v.z = v.z - c2.z; v.w = v.w - c2.w;
+  return v;
+}
+
+__device__ __forceinline__ void stage_lut_linear(const ScanArgs& a, int q, float* lut,
+                                                 const float* xq, const float* q2s) {
   // lut[j*256 + c] <- a.lut[(j*nq + q)*256 + c]; 16-byte loads, 1 KiB rows
   const float4* __restrict__ src = reinterpret_cast<const float4*>(a.lut);
   float4* dst = reinterpret_cast<float4*>(lut);
   for (int i = threadIdx.x; i < a.m * 64; i += kScanThreads) {
     const int j = i >> 6, c4 = i & 63;
-    dst[i] = src[((int64_t)j * a.nq + q) * 64 + c4];
+    dst[i] = a.lut ? src[((int64_t)j * a.nq + q) * 64 + c4] : fused_lut4(a, j, c4, xq, q2s);
   }
 }
 
@@ -181,6 +225,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_ref_kernel(ScanArgs a) {
   int* ptab = reinterpret_cast<int*>(smem + region0 + kScanWaves * 512);
   ProbeTable tab{ptab, ptab + a.max_nprobe, ptab + 2 * a.max_nprobe};
   unsigned* tau_key = reinterpret_cast<unsigned*>(ptab + 3 * a.max_nprobe + 1);
+  float* xq = reinterpret_cast<float*>(tau_key + 1);  // fused LUT: query [m*ds], then |q_j|^2 [m]
+  float* q2s = xq + a.m * a.ds;
 
   const int q = blockIdx.x / a.n_split;
   const int part = blockIdx.x - q * a.n_split;
@@ -194,7 +240,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_ref_kernel(ScanArgs a) {
     build_probe_table(a, q, n_probe, tab);
     if (lane == 0) *tau_key = f2key(-INFINITY);
   }
-  stage_lut_linear(a, q, lut);
+  if (!a.lut) stage_query(a, q, xq, q2s, kScanThreads);
+  stage_lut_linear(a, q, lut, xq, q2s);
   __syncthreads();
 
   WaveSelector<R> sel;
@@ -384,7 +431,8 @@ __global__ __launch_bounds__(256) void residual_part1_kernel(const float* __rest
 // exact top-k may have been evicted, the query is flagged and redone by scan_ref_kernel.
 
 __device__ __forceinline__ void stage_lut_blocked(const ScanArgs& a, int q, float* lut,
-                                                  int n_threads) {
+                                                  int n_threads, const float* xq,
+                                                  const float* q2s) {
   // thread handles (j, 4 consecutive c): 16-byte global load, 4 scalar LDS stores.
   // Consecutive threads take consecutive j for the same c-group so that the LDS stores of a
   // half-wave land in distinct banks.
@@ -392,7 +440,7 @@ __device__ __forceinline__ void stage_lut_blocked(const ScanArgs& a, int q, floa
   const int m = a.m;
   for (int i = threadIdx.x; i < m * 64; i += n_threads) {
     const int c4 = i / m, j = i - c4 * m;
-    const float4 x = src[((int64_t)j * a.nq + q) * 64 + c4];
+    const float4 x = a.lut ? src[((int64_t)j * a.nq + q) * 64 + c4] : fused_lut4(a, j, c4, xq, q2s);
     const int c = c4 * 4;
     lut[scan_layout::lut_dword(m, j, c + 0)] = x.x;
     lut[scan_layout::lut_dword(m, j, c + 1)] = x.y;
@@ -465,8 +513,12 @@ __device__ __forceinline__ void finalize_and_write(const ScanArgs& a, int q, con
 // large that only one workgroup fits (m > 64, e.g. GIST m=120: 120 KiB) -- same 16 waves per CU
 constexpr int packed_waves(int M) { return M <= 64 ? 8 : 16; }
 
-// per-wave scratch of the end-of-query exact re-evaluation: 16 un-permute rows of M/4+1 dwords
-constexpr int packed_aux_bytes(int /*R*/, int M) { return packed_waves(M) * 16 * (M / 4 + 1) * 4; }
+// per-wave scratch of the end-of-query exact re-evaluation: un-permute rows of M/4+1 dwords,
+// 16 per pass (8 when the LUT leaves little LDS: m > 64)
+constexpr int refine_rows(int M) { return M <= 64 ? 16 : 8; }
+constexpr int packed_aux_bytes(int /*R*/, int M) {
+  return packed_waves(M) * refine_rows(M) * (M / 4 + 1) * 4;
+}
 
 // 2 workgroups per CU (LDS: 2 x (64 KiB LUT + ~14 KiB)) need <= 128 VGPRs: 4 waves per SIMD
 template <int R, int M>
@@ -486,6 +538,8 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
   unsigned* tau_key = reinterpret_cast<unsigned*>(ptab + 3 * a.max_nprobe + 1);
   float* red = reinterpret_cast<float*>(tau_key + 1);  // [NW] reduction scratch
   float* wave_q = red + NW;                    // [NW] each wave's r-th best
+  float* xq = wave_q + NW;                     // fused LUT: query [M*ds], then |q_j|^2 [M]
+  float* q2s = xq + M * a.ds;
 
   const int q = blockIdx.x / a.n_split;
   const int part = blockIdx.x - q * a.n_split;
@@ -499,7 +553,8 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
     if (lane == 0) *tau_key = f2key(-INFINITY);
     if (lane < NW) wave_q[lane] = -INFINITY;
   }
-  stage_lut_blocked(a, q, lut, NW * 64);
+  if (!a.lut) stage_query(a, q, xq, q2s, NW * 64);
+  stage_lut_blocked(a, q, lut, NW * 64, xq, q2s);
   __syncthreads();
 
   // delta >= |fast - exact|: both are fp32 sums of the same M terms in different orders, each
@@ -623,9 +678,21 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
   // Only entries that can still reach the top-k (f >= shared threshold - 2*delta) are touched:
   // with the quantile-shared threshold that is ~k/8 per wave, i.e. one 16-lane pass.
   {
+    // One barrier: every wave has folded its last queue in and published its r-th best, so the
+    // shared bound (b) is now computed from FRESH lists.  During the scan the lists lag (a wave
+    // admits only ~k*ln(N/k)/NW candidates in its whole life and folds them in 64 at a time), so
+    // the running threshold leaves ~100 entries per wave above it; the fresh bound leaves ~2k/NW.
+    __syncthreads();
+    {
+      float qmin = reinterpret_cast<volatile float*>(wave_q)[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) qmin = fminf(qmin, reinterpret_cast<volatile float*>(wave_q)[w]);
+      sel.tau = fmaxf(sel.tau, qmin);
+    }
     refresh_tau();
     const float cut = sel.tau - delta2;
-    uint32_t* scratch = scratch_all + wave * 16 * (M / 4 + 1);
+    constexpr int RR = refine_rows(M);
+    uint32_t* scratch = scratch_all + wave * RR * (M / 4 + 1);
     WaveTopK<R> ex;
     ex.init();
 #pragma unroll
@@ -635,10 +702,11 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
       const unsigned long long wmask = __ballot(want);
       if (wmask == 0ull) break;  // sorted by fast value: nothing further down qualifies either
       float e = -INFINITY;
-      for (int pass = 0; pass < 4; ++pass) {
-        if (((wmask >> (16 * pass)) & 0xffffull) == 0ull) continue;  // wave-uniform
-        const bool mine = want && ((lane >> 4) == pass);
-        const float ep = exact_from_packed<M>(a.packed, a.n_slots, idx, mine, scratch, lane & 15,
+#pragma unroll 1
+      for (int pass = 0; pass < 64 / RR; ++pass) {
+        if (((wmask >> (RR * pass)) & ((1ull << RR) - 1ull)) == 0ull) continue;  // wave-uniform
+        const bool mine = want && ((lane / RR) == pass);
+        const float ep = exact_from_packed<M>(a.packed, a.n_slots, idx, mine, scratch, lane % RR,
                                              LdsLut<M>{lut});
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         e = mine ? ep : e;
@@ -713,19 +781,21 @@ static int list_regs(int k) { return pow2_ceil((k + 63) / 64); }  // 1, 2, 4, 8,
 constexpr int kBandSlack = 8;  // spare list entries the packed path wants beyond k
 static int list_regs_packed(int k) { return pow2_ceil((k + kBandSlack + 63) / 64); }
 
-static size_t scan_lds_bytes_ref(int m, int R, int max_nprobe) {
+static size_t scan_lds_bytes_ref(int m, int R, int max_nprobe, int fused_floats) {
   const int lut_bytes = m * 1024;
   const int list_bytes = kScanWaves * R * 64 * 8;
   const int region0 = lut_bytes > list_bytes ? lut_bytes : list_bytes;
-  size_t b = (size_t)region0 + kScanWaves * 512 + (size_t)(3 * max_nprobe + 1) * 4 + 4;
+  size_t b = (size_t)region0 + kScanWaves * 512 + (size_t)(3 * max_nprobe + 1) * 4 + 4 +
+             (size_t)fused_floats * 4;
   return (b + 15) & ~(size_t)15;
 }
-static size_t scan_lds_bytes_packed(int m, int R, int max_nprobe) {
+static size_t scan_lds_bytes_packed(int m, int R, int max_nprobe, int fused_floats) {
   const int nw = packed_waves(m);
   size_t b = (size_t)m * 1024 + packed_aux_bytes(R, m) + nw * 512 +
-             (size_t)(3 * max_nprobe + 1) * 4 + 4 + 2 * nw * 4;
+             (size_t)(3 * max_nprobe + 1) * 4 + 4 + 2 * nw * 4 + (size_t)fused_floats * 4;
   return (b + 15) & ~(size_t)15;
 }
+static int fused_floats_of(const ScanArgs& a) { return a.lut ? 0 : a.m * a.ds + a.m; }
 
 template <class K>
 static int set_lds(K kernel, size_t bytes, const char* name) {
@@ -756,9 +826,10 @@ static void fill_ws(ScanArgs& a, void* workspace, int R, int n_lists) {
 }
 
 static int validate(const ScanArgs& a) {
-  TPQ_REQUIRE(a.codes && a.lut && a.cell_start && a.cell_size && a.n_probe_list && a.out_vals &&
-                  a.out_addr,
+  TPQ_REQUIRE(a.codes && (a.lut || (a.query && a.codebook)) && a.cell_start && a.cell_size &&
+                  a.n_probe_list && a.out_vals && a.out_addr,
               "ivfpq_scan: null pointer argument");
+  TPQ_REQUIRE(a.lut || a.ds >= 1, "ivfpq_scan: bad sub-vector length %d", a.ds);
   TPQ_REQUIRE(a.nq >= 0 && a.max_nprobe >= 1, "ivfpq_scan: bad nq/max_nprobe (%d, %d)", a.nq,
               a.max_nprobe);
   TPQ_REQUIRE(a.m >= 4 && a.m % 4 == 0, "ivfpq_scan: n_subvectors=%d must be a positive multiple of 4", a.m);
@@ -781,7 +852,7 @@ static int need_ws(const void* ws, size_t have, size_t need, const char* who) {
 
 template <int R>
 static int launch_ref(ScanArgs a, hipStream_t st) {
-  const size_t lds = scan_lds_bytes_ref(a.m, R, a.max_nprobe);
+  const size_t lds = scan_lds_bytes_ref(a.m, R, a.max_nprobe, fused_floats_of(a));
   int rc = set_lds(scan_ref_kernel<R>, lds, "scan_ref_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(scan_ref_kernel<R>, dim3((unsigned)a.nq * a.n_split), dim3(kScanThreads), lds,
@@ -806,7 +877,7 @@ static int dispatch_ref(const ScanArgs& a, int R, hipStream_t st) {
 
 template <int R, int M>
 static int launch_packed(ScanArgs a, hipStream_t st) {
-  const size_t lds = scan_lds_bytes_packed(M, R, a.max_nprobe);
+  const size_t lds = scan_lds_bytes_packed(M, R, a.max_nprobe, fused_floats_of(a));
   int rc = set_lds(scan_packed_kernel<R, M>, lds, "scan_packed_kernel");
   if (rc) return rc;
   // delta = 1.05 * 2 (M-1) u * sum_j max|LUT_j|,  u = 2^-24
@@ -842,18 +913,46 @@ extern "C" size_t tpq_ivfpq_scan_workspace_bytes(int nq, int k, int n_split, int
   return ws_bytes_for(nq, R, n_split * packed_waves(m));  // covers both kernels
 }
 
+static int run_ref(ScanArgs a, void* workspace, size_t workspace_bytes, tpq_stream_t stream);
+static int run_packed(ScanArgs a, void* workspace, size_t workspace_bytes, tpq_stream_t stream);
+
+extern "C" int tpq_ivfpq_search_fused(const uint8_t* packed, const uint8_t* codes,
+                                      const float* query, const float* codebook, int ds,
+                                      int metric, const uint8_t* is_empty,
+                                      const int64_t* cell_start, const int64_t* cell_size,
+                                      const int64_t* n_probe_list, float* out_vals,
+                                      int64_t* out_addr, const int64_t* address2id,
+                                      int64_t* out_ids, int64_t n_slots, int nq, int max_nprobe,
+                                      int m, int k, int n_split, void* workspace,
+                                      size_t workspace_bytes, tpq_stream_t stream) {
+  TPQ_REQUIRE(metric == TPQ_METRIC_NEG_SQ_L2 || metric == TPQ_METRIC_INNER,
+              "ivfpq_search_fused: bad metric %d", metric);
+  TPQ_REQUIRE(ds >= 1 && ds <= 1024, "ivfpq_search_fused: bad sub-vector length %d", ds);
+  ScanArgs a{codes, packed, nullptr, query, codebook, ds, metric == TPQ_METRIC_NEG_SQ_L2 ? 1 : 0,
+             is_empty, cell_start, cell_size, n_probe_list, out_vals, out_addr, address2id, out_ids,
+             nullptr, nullptr, nullptr, nullptr, nullptr, n_slots, nq, max_nprobe, m, k, n_split};
+  bool has_packed_kernel = (m == 8 || m == 16 || m == 32 || m == 64 || m == 120);
+  if (packed && has_packed_kernel) return run_packed(a, workspace, workspace_bytes, stream);
+  return run_ref(a, workspace, workspace_bytes, stream);
+}
+
 extern "C" int tpq_ivfpq_scan_topk(const uint8_t* codes, const float* lut, const uint8_t* is_empty,
                                    const int64_t* cell_start, const int64_t* cell_size,
                                    const int64_t* n_probe_list, float* out_vals, int64_t* out_addr,
                                    const int64_t* address2id, int64_t* out_ids, int64_t n_slots,
                                    int nq, int max_nprobe, int m, int k, int n_split,
                                    void* workspace, size_t workspace_bytes, tpq_stream_t stream) {
-  ScanArgs a{codes, nullptr, lut, is_empty, cell_start, cell_size, n_probe_list, out_vals, out_addr,
-             address2id, out_ids, nullptr, nullptr, nullptr, nullptr, nullptr, n_slots, nq,
-             max_nprobe, m, k, n_split};
+  ScanArgs a{codes, nullptr, lut, nullptr, nullptr, 0, 0, is_empty, cell_start, cell_size,
+             n_probe_list, out_vals, out_addr, address2id, out_ids, nullptr, nullptr, nullptr,
+             nullptr, nullptr, n_slots, nq, max_nprobe, m, k, n_split};
+  return run_ref(a, workspace, workspace_bytes, stream);
+}
+
+static int run_ref(ScanArgs a, void* workspace, size_t workspace_bytes, tpq_stream_t stream) {
   int rc = validate(a);
   if (rc) return rc;
-  if (nq == 0) return TPQ_OK;
+  if (a.nq == 0) return TPQ_OK;
+  const int nq = a.nq, k = a.k, n_split = a.n_split;
   const int R = list_regs(k);
   if (n_split > 1) {
     rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, R, n_split), "ivfpq_scan");
@@ -871,13 +970,18 @@ extern "C" int tpq_ivfpq_scan_topk_packed(const uint8_t* packed, const uint8_t* 
                                           int64_t* out_ids, int64_t n_slots, int nq, int max_nprobe,
                                           int m, int k, int n_split, void* workspace,
                                           size_t workspace_bytes, tpq_stream_t stream) {
-  ScanArgs a{codes, packed, lut, is_empty, cell_start, cell_size, n_probe_list, out_vals, out_addr,
-             address2id, out_ids, nullptr, nullptr, nullptr, nullptr, nullptr, n_slots, nq,
-             max_nprobe, m, k, n_split};
+  ScanArgs a{codes, packed, lut, nullptr, nullptr, 0, 0, is_empty, cell_start, cell_size,
+             n_probe_list, out_vals, out_addr, address2id, out_ids, nullptr, nullptr, nullptr,
+             nullptr, nullptr, n_slots, nq, max_nprobe, m, k, n_split};
+  return run_packed(a, workspace, workspace_bytes, stream);
+}
+
+static int run_packed(ScanArgs a, void* workspace, size_t workspace_bytes, tpq_stream_t stream) {
   int rc = validate(a);
   if (rc) return rc;
-  TPQ_REQUIRE(packed != nullptr, "ivfpq_scan_packed: null packed pointer");
-  if (nq == 0) return TPQ_OK;
+  TPQ_REQUIRE(a.packed != nullptr, "ivfpq_scan_packed: null packed pointer");
+  if (a.nq == 0) return TPQ_OK;
+  const int nq = a.nq, k = a.k, n_split = a.n_split, m = a.m;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int R = list_regs_packed(k);
   if (R > 16) {  // k within kBandSlack of 1024: no room for the candidate band, scan exactly
@@ -921,9 +1025,9 @@ extern "C" int tpq_ivfpq_scan_topk_residual(const uint8_t* codes, const float* p
                                             const int64_t* address2id, int64_t* out_ids,
                                             int64_t n_slots, int nq, int max_nprobe, int m, int k,
                                             tpq_stream_t stream) {
-  ScanArgs a{codes, nullptr, part1 ? part1 : full_lut, is_empty, cell_start, cell_size, n_probe_list,
-             out_vals, out_addr, address2id, out_ids, nullptr, nullptr, nullptr, nullptr, nullptr,
-             n_slots, nq, max_nprobe, m, k, 1};
+  ScanArgs a{codes, nullptr, part1 ? part1 : full_lut, nullptr, nullptr, 0, 0, is_empty, cell_start,
+             cell_size, n_probe_list, out_vals, out_addr, address2id, out_ids, nullptr, nullptr,
+             nullptr, nullptr, nullptr, n_slots, nq, max_nprobe, m, k, 1};
   int rc = validate(a);
   if (rc) return rc;
   TPQ_REQUIRE(base_sims != nullptr, "ivfpq_scan_residual: base_sims is required");
@@ -933,7 +1037,7 @@ extern "C" int tpq_ivfpq_scan_topk_residual(const uint8_t* codes, const float* p
   ResidualArgs ra{part1, part2, full_lut, cells, base_sims};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int R = list_regs(k);
-  const size_t lds = scan_lds_bytes_ref(m, R, max_nprobe);
+  const size_t lds = scan_lds_bytes_ref(m, R, max_nprobe, 0);
   auto go = [&](auto kernel) -> int {
     int rc2 = set_lds(kernel, lds, "scan_residual_kernel");
     if (rc2) return rc2;

@@ -47,6 +47,7 @@ class IVFPQIndex(CellContainer):
         self._use_tensor_core = False
         self._fp16_scale_mode = "a"
         self.use_packed_layout = True   # MI355X scan layout (bank-conflict-free LDS look-ups)
+        self.use_fused_lut = True       # build the ADC LUT inside the scan workgroups (no HBM table)
         self.max_query_batch = 32768    # bounds the [m, nq, 256] LUT (m=64: 2 GiB per batch)
 
         self.vq_codec = VQCodec(n_clusters=n_cells, n_redo=1, max_iter=15, tol=1e-4,
@@ -273,12 +274,23 @@ class IVFPQIndex(CellContainer):
             if return_address:
                 return topk_val, topk_ids, topk_address
             return topk_val, topk_ids
-        precomputed = self.pq_codec.precompute_adc(x)
         packed = None
         if self.use_packed_layout:
             from ..kernels import PACKED_M
             if self.n_subvectors in PACKED_M:
                 packed = self.packed_storage()
+        # the fused path re-reads the codebook (m*ds KiB, L2-resident) per workgroup instead of a
+        # 1-KiB-per-sub-quantizer LUT row from HBM: a win while the sub-vectors are short
+        if self.use_fused_lut and self.d_subvector <= 4:
+            topk_val, topk_address, topk_ids = self._ivfpq_topk.topk_fused(
+                data=self._storage, query=x, codebook=self.pq_codec.codebook, cell_start=cell_start,
+                cell_size=cell_size, is_empty=self._is_empty if self._has_holes else None,
+                n_probe_list=n_probe_list, k=k, distance=self.distance, packed=packed,
+                address2id=self._address2id)
+            if return_address:
+                return topk_val, topk_ids, topk_address
+            return topk_val, topk_ids
+        precomputed = self.pq_codec.precompute_adc(x)
         topk_val, topk_address, topk_ids = self._ivfpq_topk.topk(
             data=self._storage, precomputed=precomputed, cell_start=cell_start,
             cell_size=cell_size, is_empty=self._is_empty if self._has_holes else None,

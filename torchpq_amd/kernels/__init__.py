@@ -128,6 +128,54 @@ class IVFPQTopkHip:
         return (values, address) if ids is None else (values, address, ids)
 
 
+    def topk_fused(self, data, query, codebook, is_empty, cell_start, cell_size, n_probe_list,
+                   n_candidates, distance="euclidean", packed=None, address2id=None, n_split=None):
+        """precompute_adc + topk in one pass: the LUT is built inside the scan workgroups
+        (query [d, n_query] f32, codebook [m, ds, 256] f32); results identical to
+        topk(precomputed=AdcLutHip()(query, codebook))."""
+        n_data = data.shape[1]
+        n_query, n_probe = cell_start.shape
+        m, ds, kk = codebook.shape
+        assert m == self.m and kk == self.k
+        assert query.shape == (m * ds, n_query)
+        assert query.dtype == codebook.dtype == torch.float32
+        assert data.shape == (self.m // self.n_cs, n_data, self.n_cs) and data.dtype == torch.uint8
+        assert cell_size.shape == (n_query, n_probe)
+        assert cell_start.dtype == cell_size.dtype == torch.int64
+        assert n_probe_list.shape == (n_query,) and n_probe_list.dtype == torch.int64
+        assert 0 < n_candidates <= 1024
+        query = query.contiguous()
+        codebook = codebook.contiguous()
+        require_gpu(data, query, codebook, is_empty, cell_start, cell_size, n_probe_list, packed,
+                    address2id)
+        device = data.device
+        k = n_candidates
+        values = torch.empty(n_query, k, device=device, dtype=torch.float32)
+        address = torch.empty(n_query, k, device=device, dtype=torch.int64)
+        ids = torch.empty(n_query, k, device=device, dtype=torch.int64) if address2id is not None else None
+        if n_query == 0:
+            return (values, address) if ids is None else (values, address, ids)
+        lib = load()
+        if n_split is None:
+            n_split = self._n_split(n_query, device)
+        ws_bytes = lib.tpq_ivfpq_scan_workspace_bytes(n_query, k, n_split, self.m)
+        ws = torch.empty(max(ws_bytes, 1), device=device, dtype=torch.uint8)
+        metric = _lib.METRIC_NEG_SQ_L2 if distance == "euclidean" else _lib.METRIC_INNER
+        ev = None
+        if self.record_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(torch.cuda.current_stream(device))
+        with torch.cuda.device(device):
+            check(lib.tpq_ivfpq_search_fused(
+                ptr(packed), ptr(data), ptr(query), ptr(codebook), ds, metric, ptr(is_empty),
+                ptr(cell_start), ptr(cell_size), ptr(n_probe_list), ptr(values), ptr(address),
+                ptr(address2id), ptr(ids), n_data, n_query, n_probe, self.m, k, n_split, ptr(ws),
+                ws_bytes, stream_ptr(device)), "tpq_ivfpq_search_fused")
+        if ev is not None:
+            ev[1].record(torch.cuda.current_stream(device))
+            self.record_events.append(ev)
+        return (values, address) if ids is None else (values, address, ids)
+
     # ---- residual PQ (pq_use_residual=True) ------------------------------------------------------
     def _residual(self, data, part1, part2, full, cells, base_sims, is_empty, cell_start, cell_size,
                   n_probe_list, n_candidates, address2id):
