@@ -154,6 +154,13 @@ int tpq_adc_lut(const float* query, const float* codebook, float* lut, int m, in
 int tpq_topk_select(const float* x, float* vals, int64_t* idx, int rows, int cols, int k,
                     tpq_stream_t stream);
 
+/* a-4 fused: the epilogue of metric.negative_squared_l2_distance (torchpq/metric.py:89-96) applied
+ * inside the select: v = (2*dots[r][c] - a2[r]) - b2[c] (the reference's rounding order), then
+ * row top-k as above.  dots f32 [rows][cols] = x^T C (library GEMM), a2 [rows] = |x|^2,
+ * b2 [cols] = |C|^2. */
+int tpq_coarse_select(const float* dots, const float* a2, const float* b2, float* vals, int64_t* idx,
+                      int rows, int cols, int k, tpq_stream_t stream);
+
 /* a-5  smart probing          torchpq/index/IVFPQIndex.py:499-512
  * topk_sims f32 [rows][n_probe] -> n_probe_list i64 [rows] in [0, n_probe]
  * p = softmax(-sqrt(|s|)/T); H = -sum(p*log2(p)/log2(n_probe)); out = ceil(H*n_probe) */

@@ -317,3 +317,37 @@ def test_flat_index_exact_search():
     _, got = ivf.search(T(queries), k=k)
     recall = (got == gt).any(dim=1).float().mean().item()
     assert recall > 0.8, recall
+
+
+def test_search_edge_cases_many_probes_batches_empty():
+    """n_probe = 1 and > 64 (probe table built in 64-probe chunks), query batches split by
+    max_query_batch, search on an empty / untouched cell set."""
+    from torchpq_amd.index import IVFPQIndex
+    rng = np.random.default_rng(12)
+    d, n, nq = 32, 30000, 150
+    base = (rng.standard_normal((d, n)) * 3).astype(np.float32)
+    queries = (rng.standard_normal((d, nq)) * 3).astype(np.float32)
+    np.random.seed(12)
+    idx = IVFPQIndex(d_vector=d, n_subvectors=8, n_cells=160, initial_size=32, device=DEV)
+    idx.train(T(base[:, :8000]))
+    idx.use_smart_probing = False
+    idx.n_probe = 5
+    v, i = idx.search(T(queries), k=7)  # nothing added yet
+    assert torch.isneginf(v).all() and (i == -1).all()
+    idx.add(T(base))
+    for n_probe, k in [(1, 1), (1, 20), (100, 10), (160, 64)]:
+        idx.n_probe = n_probe
+        v, i = idx.search(T(queries), k=k)
+        ev, ei, _, _ = _expected_search(idx, queries, k)
+        assert np.array_equal(N(v), ev) and np.array_equal(N(i), ei), (n_probe, k)
+    idx.n_probe = 12
+    v_all, i_all = idx.search(T(queries), k=10)
+    idx.max_query_batch = 64  # 150 queries -> 3 batches
+    v_b, i_b = idx.search(T(queries), k=10)
+    assert torch.equal(v_all, v_b) and torch.equal(i_all, i_b)
+    idx.use_smart_probing = True
+    idx.max_query_batch = 32768
+    v_s, i_s = idx.search(T(queries), k=10)
+    ev, ei, _, npl = _expected_search(idx, queries, 10)
+    assert np.array_equal(N(v_s), ev) and np.array_equal(N(i_s), ei)
+    assert npl.min() >= 1 and npl.max() <= 12

@@ -402,3 +402,20 @@ def test_fused_lut_scan_equals_lut_then_scan(K, m, ds, k, layout, distance):
     ev, ea = c_oracle.scan_topk(storage, c_oracle.adc_lut(q, cb, distance), is_empty, start[cells],
                                 sizes[cells], npl, k)
     assert np.array_equal(N(v1), ev) and np.array_equal(N(a1), ea)
+
+
+def test_coarse_select_equals_metric_then_select(K):
+    """tpq_coarse_select == metric.negative_squared_l2_distance + tpq_topk_select, bit for bit."""
+    from torchpq_amd import metric
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    x = torch.randn(128, 777, generator=g, device=DEV) * 30
+    c = torch.randn(128, 1024, generator=g, device=DEV) * 30
+    sims = metric.negative_squared_l2_distance(x, c).contiguous()
+    for k in (1, 32, 64):
+        v0, i0 = K.TopkSelectHip()(sims, k=k)
+        dots = x.transpose(0, 1).contiguous() @ c
+        v1, i1 = K.CoarseSelectHip()(dots, (x * x).sum(0), (c * c).sum(0), k)
+        assert torch.equal(v0, v1) and torch.equal(i0, i1)
+        ev, ei = orc.topk_desc(N(sims), k)
+        assert np.array_equal(N(v1), ev) and np.array_equal(N(i1), ei)

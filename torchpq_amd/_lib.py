@@ -35,6 +35,7 @@ SIGNATURES = {
     "tpq_residual_part1": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tpq_adc_lut": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tpq_topk_select": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tpq_coarse_select": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tpq_smart_probing": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "tpq_get_id_by_address": (_i, [_vp, _i64, _vp, _vp, _i64, _vp]),
     "tpq_max_sim": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -10,8 +10,13 @@ namespace tpq {
 
 constexpr int kSelWaves = 4;
 
+// a2 / b2 non-null: the coarse-probe epilogue of metric.negative_squared_l2_distance
+// (torchpq/metric.py:89-96) is applied on the fly -- v = (2*x - a2[row]) - b2[col], the reference's
+// order of roundings -- so the three element-wise passes over the [nq, n_cells] GEMM output vanish.
 template <int R>
 __global__ __launch_bounds__(kSelWaves * 64) void topk_select_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ a2,
+                                                                    const float* __restrict__ b2,
                                                                     float* __restrict__ vals,
                                                                     int64_t* __restrict__ idx,
                                                                     int rows, int cols, int k) {
@@ -24,10 +29,20 @@ __global__ __launch_bounds__(kSelWaves * 64) void topk_select_kernel(const float
   sel.init(qv + wave * 64, qi + wave * 64, k);
   NoRefine refine;
   const float* __restrict__ xr = x + (int64_t)row * cols;
+  const float ra2 = a2 ? a2[row] : 0.f;
   for (int base = 0; base < cols; base += 64) {
     const int c = base + lane;
     const bool valid = c < cols;
-    const float v = valid ? xr[c] + 0.0f : -INFINITY;  // +0.f: -0.0 -> +0.0 (key order)
+    float v = -INFINITY;
+    if (valid) {
+      v = xr[c];
+      if (a2) {
+        v = 2.f * v;
+        v = v - ra2;
+        v = v - b2[c];
+      }
+      v = v + 0.0f;  // -0.0 -> +0.0 (key order)
+    }
     sel.push(valid && (v >= sel.tau), v, c, refine);
   }
   sel.flush(refine);
@@ -85,10 +100,10 @@ __global__ __launch_bounds__(256) void id_by_address_kernel(const int64_t* __res
 }
 
 template <int R>
-static int launch_select(const float* x, float* v, int64_t* i, int rows, int cols, int k,
-                         hipStream_t st) {
+static int launch_select(const float* x, const float* a2, const float* b2, float* v, int64_t* i,
+                         int rows, int cols, int k, hipStream_t st) {
   hipLaunchKernelGGL(topk_select_kernel<R>, dim3((rows + kSelWaves - 1) / kSelWaves),
-                     dim3(kSelWaves * 64), 0, st, x, v, i, rows, cols, k);
+                     dim3(kSelWaves * 64), 0, st, x, a2, b2, v, i, rows, cols, k);
   TPQ_LAUNCH_CHECK("topk_select_kernel");
   return TPQ_OK;
 }
@@ -97,19 +112,33 @@ static int launch_select(const float* x, float* v, int64_t* i, int rows, int col
 
 using namespace tpq;
 
+static int select_impl(const float* x, const float* a2, const float* b2, float* vals, int64_t* idx,
+                       int rows, int cols, int k, tpq_stream_t stream);
+
 extern "C" int tpq_topk_select(const float* x, float* vals, int64_t* idx, int rows, int cols, int k,
                                tpq_stream_t stream) {
+  return select_impl(x, nullptr, nullptr, vals, idx, rows, cols, k, stream);
+}
+
+extern "C" int tpq_coarse_select(const float* dots, const float* a2, const float* b2, float* vals,
+                                 int64_t* idx, int rows, int cols, int k, tpq_stream_t stream) {
+  TPQ_REQUIRE(a2 && b2, "coarse_select: null norm pointer");
+  return select_impl(dots, a2, b2, vals, idx, rows, cols, k, stream);
+}
+
+static int select_impl(const float* x, const float* a2, const float* b2, float* vals, int64_t* idx,
+                       int rows, int cols, int k, tpq_stream_t stream) {
   TPQ_REQUIRE(x && vals && idx, "topk_select: null pointer");
   TPQ_REQUIRE(rows >= 0 && cols >= 1, "topk_select: bad shape [%d, %d]", rows, cols);
   TPQ_REQUIRE(k >= 1 && k <= 1024 && k <= cols, "topk_select: k=%d out of range (cols=%d, max 1024)", k, cols);
   if (rows == 0) return TPQ_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int r = (k + 63) / 64;
-  if (r <= 1) return launch_select<1>(x, vals, idx, rows, cols, k, st);
-  if (r <= 2) return launch_select<2>(x, vals, idx, rows, cols, k, st);
-  if (r <= 4) return launch_select<4>(x, vals, idx, rows, cols, k, st);
-  if (r <= 8) return launch_select<8>(x, vals, idx, rows, cols, k, st);
-  return launch_select<16>(x, vals, idx, rows, cols, k, st);
+  if (r <= 1) return launch_select<1>(x, a2, b2, vals, idx, rows, cols, k, st);
+  if (r <= 2) return launch_select<2>(x, a2, b2, vals, idx, rows, cols, k, st);
+  if (r <= 4) return launch_select<4>(x, a2, b2, vals, idx, rows, cols, k, st);
+  if (r <= 8) return launch_select<8>(x, a2, b2, vals, idx, rows, cols, k, st);
+  return launch_select<16>(x, a2, b2, vals, idx, rows, cols, k, st);
 }
 
 extern "C" int tpq_smart_probing(const float* topk_sims, int64_t* n_probe_list, int rows,

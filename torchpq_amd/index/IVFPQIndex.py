@@ -12,7 +12,7 @@ from .. import metric, util
 from ..codec import PQCodec, VQCodec
 from ..container import CellContainer
 from ..fn import IVFPQTopk, Topk
-from ..kernels import SmartProbingHip
+from ..kernels import CoarseSelectHip, SmartProbingHip
 
 
 class IVFPQIndex(CellContainer):
@@ -57,6 +57,7 @@ class IVFPQIndex(CellContainer):
         self._ivfpq_topk = IVFPQTopk(n_subvectors=n_subvectors, contiguous_size=self.contiguous_size)
         self._topk = Topk()
         self._smart_probing = SmartProbingHip()
+        self._coarse_select = CoarseSelectHip()
         self.to(device)
 
     # ---- knobs (reference :89-232) ---------------------------------------------------------------
@@ -302,7 +303,13 @@ class IVFPQIndex(CellContainer):
     def probe(self, x):
         """Coarse step: (topk_sims, cells [n_query, n_probe], n_probe_list [n_query])."""
         vq_codebook = self.vq_codec.codebook
-        if self.use_cublas:
+        if self.use_cublas and self.n_probe <= 1024:
+            # library GEMM, then the 2ab - a^2 - b^2 epilogue (reference rounding order) fused into
+            # the row select: one pass over the [n_query, n_cells] matrix instead of four
+            dots = x.transpose(0, 1).contiguous() @ vq_codebook
+            topk_sims, cells = self._coarse_select(dots, (x * x).sum(dim=0),
+                                                   (vq_codebook * vq_codebook).sum(dim=0), self.n_probe)
+        elif self.use_cublas:
             sims = metric.negative_squared_l2_distance(x, vq_codebook).contiguous()
             topk_sims, cells = self._topk(sims, k=self.n_probe, dim=1)
         else:

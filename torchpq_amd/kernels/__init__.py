@@ -15,7 +15,7 @@ from .. import _lib
 from .._lib import check, load, ptr, require_gpu, stream_ptr
 
 __all__ = [
-    "IVFPQTopkHip", "IVFPQTop1Hip", "ResidualPart1Hip", "AdcLutHip", "TopkSelectHip", "Top1SelectHip",
+    "IVFPQTopkHip", "IVFPQTop1Hip", "ResidualPart1Hip", "AdcLutHip", "TopkSelectHip", "CoarseSelectHip", "Top1SelectHip",
     "Top32SelectHip", "SmartProbingHip", "MaxSimHip", "ComputeCentroidsHip", "GetIOAHip",
     "GetWriteAddressHip", "GetCellByAddressHip", "GetIdByAddressHip", "PQDecodeHip",
     "ScatterCodesHip", "PackCodesHip", "packed_chunk_width", "PACKED_M",
@@ -303,6 +303,25 @@ class TopkSelectHip:
         with torch.cuda.device(x.device):
             check(load().tpq_topk_select(ptr(x), ptr(vals), ptr(inds), rows, cols, k,
                                          stream_ptr(x.device)), "tpq_topk_select")
+        return vals, inds
+
+
+class CoarseSelectHip:
+    """negative_squared_l2_distance epilogue + row top-k in one pass (metric.py:89-96 + fn/Topk.py):
+    dots [n_query, n_cells] = x^T C, a2 [n_query], b2 [n_cells] -> (sims, cells) [n_query, k]."""
+
+    def __call__(self, dots, a2, b2, k):
+        assert dots.dtype == a2.dtype == b2.dtype == torch.float32 and len(dots.shape) == 2
+        rows, cols = dots.shape
+        assert a2.shape == (rows,) and b2.shape == (cols,)
+        assert 1 <= k <= 1024 and k <= cols
+        dots, a2, b2 = dots.contiguous(), a2.contiguous(), b2.contiguous()
+        require_gpu(dots, a2, b2)
+        vals = torch.empty(rows, k, device=dots.device, dtype=torch.float32)
+        inds = torch.empty(rows, k, device=dots.device, dtype=torch.int64)
+        with torch.cuda.device(dots.device):
+            check(load().tpq_coarse_select(ptr(dots), ptr(a2), ptr(b2), ptr(vals), ptr(inds), rows,
+                                           cols, k, stream_ptr(dots.device)), "tpq_coarse_select")
         return vals, inds
 
 
