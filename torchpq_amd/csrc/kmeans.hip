@@ -159,24 +159,50 @@ __global__ __launch_bounds__(256, (DH <= 32 ? 2 : 1)) void max_sim_codebook_kern
   }
   __syncthreads();
 
-#pragma unroll 1
-  for (int t = 0; t < kMsTiles; ++t) {
+  // software pipeline over the block's tiles: the data fragment of tile t+1 is in flight while
+  // tile t runs its 256 MFMAs
+  auto load_frag = [&](int t, float (&xf)[DH], bool& iv, int& i) {
     const int tile = blockIdx.x * kMsTiles + t;
-    if (tile * 128 >= m) break;
-    const int i = tile * 128 + wave * 32 + l31;
-    const bool iv = i < m;
-    float xf[DH];
+    i = tile * 128 + wave * 32 + l31;
+    iv = (t < kMsTiles) && (i < m);
 #pragma unroll
     for (int kk = 0; kk < DH; ++kk) {
       const int k = 2 * kk + half;
       xf[kk] = (iv && k < d) ? Ab[(int64_t)k * m + i] : 0.f;
     }
+  };
+  constexpr bool kPrefetch = DH <= 16;  // deeper fragments would spill under the 256-VGPR cap
+  float xn[kPrefetch ? DH : 1];
+  bool ivn = false;
+  int in_ = 0;
+  if constexpr (kPrefetch) load_frag(0, xn, ivn, in_);
+#pragma unroll 1
+  for (int t = 0; t < kMsTiles; ++t) {
+    if ((blockIdx.x * kMsTiles + t) * 128 >= m) break;
+    float xf[DH];
+    bool iv;
+    int i;
+    if constexpr (kPrefetch) {
+#pragma unroll
+      for (int kk = 0; kk < DH; ++kk) xf[kk] = xn[kk];
+      iv = ivn;
+      i = in_;
+      load_frag(t + 1, xn, ivn, in_);
+    } else {
+      load_frag(t, xf, iv, i);
+    }
+    // |a|^2 as the ascending-k fma chain: this lane holds k = 2kk+half, its partner (lane ^ 32)
+    // the other parity
     float a2 = 0.f;
-    if (euclidean && iv)
-      for (int k = 0; k < d; ++k) {
-        const float x = Ab[(int64_t)k * m + i];
-        a2 = fmaf(x, x, a2);
+    if (euclidean) {
+#pragma unroll
+      for (int kk = 0; kk < DH; ++kk) {
+        const float xo = __shfl_xor(xf[kk], 32, 64);
+        const float x0 = half ? xo : xf[kk], x1 = half ? xf[kk] : xo;
+        a2 = fmaf(x0, x0, a2);
+        if (2 * kk + 1 < d) a2 = fmaf(x1, x1, a2);
       }
+    }
     // two passes of 4 centroid tiles: 64 accumulator registers instead of 128; the data fragment
     // is re-used from registers, the LDS traffic is unchanged.  Within a lane the centroid index
     // grows with (pass, tt, r), so "first maximum" == smallest index.
