@@ -161,17 +161,21 @@ __global__ __launch_bounds__(256, (DH <= 32 ? 2 : 1)) void max_sim_codebook_kern
 
   // software pipeline over the block's tiles: the data fragment of tile t+1 is in flight while
   // tile t runs its 256 MFMAs
+  // SRSRC buffer loads: 32-bit per-lane offset + uniform row offset in an SGPR, so the 2*DH loads
+  // of a fragment need no per-load 64-bit address registers (what made a prefetched fragment spill)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(Ab), 0, (int)(((int64_t)d * m * 4 > 0x7fffffffLL) ? 0x7fffffff : (int64_t)d * m * 4),
+      0x00020000);
   auto load_frag = [&](int t, float (&xf)[DH], bool& iv, int& i) {
     const int tile = blockIdx.x * kMsTiles + t;
     i = tile * 128 + wave * 32 + l31;
     iv = (t < kMsTiles) && (i < m);
+    const int voff = iv ? (half * m + i) * 4 : 0x7ffffff0;  // out of range -> the load returns 0
 #pragma unroll
-    for (int kk = 0; kk < DH; ++kk) {
-      const int k = 2 * kk + half;
-      xf[kk] = (iv && k < d) ? Ab[(int64_t)k * m + i] : 0.f;
-    }
+    for (int kk = 0; kk < DH; ++kk)
+      xf[kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, kk * 2 * m * 4, 0));
   };
-  constexpr bool kPrefetch = DH <= 16;  // deeper fragments would spill under the 256-VGPR cap
+  constexpr bool kPrefetch = DH <= 32;  // DH = 64 runs one wave per SIMD already
   float xn[kPrefetch ? DH : 1];
   bool ivn = false;
   int in_ = 0;
