@@ -246,7 +246,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_ref_kernel(ScanArgs a) {
 
   WaveSelector<R> sel;
   sel.init(qv_all + wave * 64, qi_all + wave * 64, a.k);
-  NoRefine refine;
 
   const int total_tiles = tab.tile_begin[n_probe];
   const int t_begin = (int)(((int64_t)total_tiles * part) / a.n_split);
@@ -291,12 +290,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_ref_kernel(ScanArgs a) {
     const float tau_s = key2f(*reinterpret_cast<volatile unsigned*>(tau_key));
     sel.tau = fmaxf(sel.tau, tau_s);
     const float tau_before = sel.tau;
-    sel.push(live && (v >= sel.tau), v, s, refine);
+    sel.push(live && (v >= sel.tau), v, s);
     if (sel.tau > tau_before && lane == 0) atomicMax(tau_key, f2key(sel.tau));
   }
   {
     const float tau_before = sel.tau;
-    sel.flush(refine);
+    sel.flush();
     if (sel.tau > tau_before && lane == 0) atomicMax(tau_key, f2key(sel.tau));
   }
   finish_query<R>(a, q, part, sel.top, reinterpret_cast<float*>(smem),
@@ -344,7 +343,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_residual_kernel(ScanArgs a,
 
   WaveSelector<R> sel;
   sel.init(qv_all + wave * 64, qi_all + wave * 64, a.k);
-  NoRefine refine;
   const int G = a.m >> 2;
   const uint32_t* __restrict__ codes32 = reinterpret_cast<const uint32_t*>(a.codes);
   const int n4 = a.m * 64;  // float4 count of one LUT
@@ -391,11 +389,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_residual_kernel(ScanArgs a,
       const float tau_s = key2f(*reinterpret_cast<volatile unsigned*>(tau_key));
       sel.tau = fmaxf(sel.tau, tau_s);
       const float tau_before = sel.tau;
-      sel.push(live && (v >= sel.tau), v + 0.0f, s, refine);
+      sel.push(live && (v >= sel.tau), v + 0.0f, s);
       if (sel.tau > tau_before && lane == 0) atomicMax(tau_key, f2key(sel.tau));
     }
   }
-  sel.flush(refine);
+  sel.flush();
   finish_query<R>(a, q, 0, sel.top, reinterpret_cast<float*>(smem),
                   reinterpret_cast<int*>(smem + kScanWaves * R * 64 * 4));
 }
@@ -578,7 +576,6 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
   WaveSelector<R> sel;
   sel.init(qv_all + wave * 64, qi_all + wave * 64, a.k);
   sel.margin = delta2;
-  NoRefine refine;
 
   const int total_tiles = tab.tile_begin[n_probe];
   const int t_begin = (int)(((int64_t)total_tiles * part) / a.n_split);
@@ -627,7 +624,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
     refresh_tau();
     const float tau_before = sel.tau;
     const int flushes_before = sel.n_flush;
-    sel.push(live && (v >= sel.tau - delta2), v, t.s, refine);
+    sel.push(live && (v >= sel.tau - delta2), v, t.s);
     if (sel.n_flush != flushes_before) publish(tau_before);
   };
 
@@ -668,7 +665,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
   }
   {
     const float tau_before = sel.tau;
-    sel.flush(refine);
+    sel.flush();
     publish(tau_before);
   }
 

@@ -27,7 +27,6 @@ __global__ __launch_bounds__(kSelWaves * 64) void topk_select_kernel(const float
   if (row >= rows) return;
   WaveSelector<R> sel;
   sel.init(qv + wave * 64, qi + wave * 64, k);
-  NoRefine refine;
   const float* __restrict__ xr = x + (int64_t)row * cols;
   const float ra2 = a2 ? a2[row] : 0.f;
   for (int base = 0; base < cols; base += 64) {
@@ -43,9 +42,9 @@ __global__ __launch_bounds__(kSelWaves * 64) void topk_select_kernel(const float
       }
       v = v + 0.0f;  // -0.0 -> +0.0 (key order)
     }
-    sel.push(valid && (v >= sel.tau), v, c, refine);
+    sel.push(valid && (v >= sel.tau), v, c);
   }
-  sel.flush(refine);
+  sel.flush();
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int e = r * 64 + lane;

@@ -186,12 +186,6 @@ struct WaveTopK {
 };
 
 // Threshold filter + per-wave LDS queue in front of a WaveTopK.
-// `Refine` lets the caller replace a queued candidate's value before it is ranked
-// (used by the packed scan to re-evaluate survivors in the reference's summation order).
-struct NoRefine {
-  __device__ __forceinline__ float operator()(float v, int /*idx*/, bool /*active*/) const { return v; }
-};
-
 template <int R>
 struct WaveSelector {
   WaveTopK<R> top;
@@ -214,8 +208,7 @@ struct WaveSelector {
     margin = 0.f;
   }
 
-  template <class Refine>
-  __device__ __forceinline__ void flush(const Refine& refine) {
+  __device__ __forceinline__ void flush() {
     if (qn == 0) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     const int lane = lane_id();
@@ -225,7 +218,6 @@ struct WaveSelector {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     qn = 0;
     ++n_flush;
-    bv = refine(bv, bi, act);
     if (!(bv >= tau - margin)) {  // fell under the (possibly raised) threshold, or NaN: drop
       bv = -INFINITY;
       bi = kPadIdx;
@@ -235,13 +227,12 @@ struct WaveSelector {
   }
 
   // every lane calls; lanes with pass==true enqueue (v, idx)
-  template <class Refine>
-  __device__ __forceinline__ void push(bool pass, float v, int idx, const Refine& refine) {
+  __device__ __forceinline__ void push(bool pass, float v, int idx) {
     unsigned long long mask = __ballot(pass);
     if (mask == 0ull) return;
     int n = __popcll(mask);
     if (qn + n > 64) {
-      flush(refine);
+      flush();
     }
     const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));

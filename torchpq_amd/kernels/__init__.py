@@ -7,8 +7,6 @@ There is no CPU path: tensors must live on the GPU.
 """
 from __future__ import annotations
 
-import math
-
 import torch
 
 from .. import _lib
@@ -26,10 +24,6 @@ PACKED_M = (8, 16, 32, 64, 120)  # n_subvectors with an instantiated packed-layo
 
 def packed_chunk_width(m):
     return 16 if m % 16 == 0 else (8 if m % 8 == 0 else 4)
-
-
-def _next_power_of_2(x):
-    return 1 if x == 0 else 2 ** math.ceil(math.log2(x))
 
 
 class IVFPQTopkHip:
