@@ -268,7 +268,8 @@ def test_max_sim_and_centroids_match_reference_golden(K, fx_kmeans):
     np.testing.assert_allclose(cen, fx["ref_centroids"], rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("l,d,n,k", [(1, 5, 1000, 7), (3, 40, 9000, 256), (2, 17, 100, 1024)])
+@pytest.mark.parametrize("l,d,n,k", [(1, 5, 1000, 7), (3, 40, 9000, 256), (2, 17, 100, 1024),
+                                     (1, 24, 30000, 16384)])
 def test_compute_centroids(K, l, d, n, k):
     rng = np.random.default_rng(n + k)
     data = rng.standard_normal((l, d, n)).astype(np.float32)

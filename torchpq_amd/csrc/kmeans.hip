@@ -130,7 +130,10 @@ constexpr int kMsTiles = 8;  // 128-point tiles per block
 template <int DH, bool euclidean>
 __global__ __launch_bounds__(256, (DH <= 32 ? 2 : 1)) void max_sim_codebook_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ vals,
-    int64_t* __restrict__ inds, int d, int m, int n) {
+    int64_t* __restrict__ inds, int d, int m, int n_total, int c0, int first) {
+  // this launch covers centroids [c0, c0 + n) of the n_total; later chunks fold their best into
+  // the running (vals, inds) -- ascending chunks, so on a tie the earlier (smaller) index stays
+  const int n = (n_total - c0) < 256 ? (n_total - c0) : 256;
   extern __shared__ __attribute__((aligned(16))) float msh[];
   float* cs = msh;                   // [2*DH][256], zero beyond (d, n)
   float* b2s = msh + 2 * DH * 256;   // [256]: |b|^2 (euclidean) or 0 (inner); padding columns
@@ -139,11 +142,11 @@ __global__ __launch_bounds__(256, (DH <= 32 ? 2 : 1)) void max_sim_codebook_kern
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l31 = lane & 31, half = lane >> 5;
   const float* __restrict__ Ab = A + (int64_t)b * d * m;
-  const float* __restrict__ Bb = B + (int64_t)b * d * n;
+  const float* __restrict__ Bb = B + (int64_t)b * d * n_total + c0;
 
   for (int e = threadIdx.x; e < 2 * DH * 256; e += 256) {
     const int k = e >> 8, c = e & 255;
-    cs[e] = (k < d && c < n) ? Bb[(int64_t)k * n + c] : 0.f;
+    cs[e] = (k < d && c < n) ? Bb[(int64_t)k * n_total + c] : 0.f;
   }
   __syncthreads();
   {
@@ -255,6 +258,14 @@ __global__ __launch_bounds__(256, (DH <= 32 ? 2 : 1)) void max_sim_codebook_kern
       besti = oi;
     }
     if (half == 0 && iv) {
+      besti += c0;
+      if (!first) {
+        const float pv = vals[(int64_t)b * m + i];
+        if (!(best > pv)) {
+          best = pv;
+          besti = (int)inds[(int64_t)b * m + i];
+        }
+      }
       vals[(int64_t)b * m + i] = best;
       inds[(int64_t)b * m + i] = besti;
     }
@@ -271,8 +282,11 @@ static int launch_codebook(const float* A, const float* B, float* vals, int64_t*
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                        "max_sim_codebook_kernel attr");
     if (rc) return rc;
-    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, A, B, vals, inds, d, m, n);
-    TPQ_LAUNCH_CHECK("max_sim_codebook_kernel");
+    for (int c0 = 0; c0 < n; c0 += 256) {
+      hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, A, B, vals, inds, d, m, n, c0,
+                         c0 == 0 ? 1 : 0);
+      TPQ_LAUNCH_CHECK("max_sim_codebook_kernel");
+    }
     return TPQ_OK;
   };
   return euclid ? go(max_sim_codebook_kernel<DH, true>) : go(max_sim_codebook_kernel<DH, false>);
@@ -340,6 +354,24 @@ __global__ __launch_bounds__(256) void centroid_accum_kernel(const float* __rest
       const float c = scnt[t];
       if (c != 0.f) unsafeAtomicAdd(&counts[(int64_t)b * k + t], c);
     }
+}
+
+// ---- update, many clusters (coarse quantiser: k in the thousands) ------------------------------
+// With thousands of bins per dimension an LDS privatisation no longer fits and contention on any
+// one bin is low, so each (point, dimension) goes straight to an L2 float atomic.
+__global__ __launch_bounds__(256) void centroid_accum_global_kernel(
+    const float* __restrict__ data, const int64_t* __restrict__ labels, float* __restrict__ sums,
+    float* __restrict__ counts, int d, int64_t n, int k) {
+  const int b = blockIdx.z;
+  const int e0 = blockIdx.y * kCcDT;
+  const int ne = (d - e0) < kCcDT ? (d - e0) : kCcDT;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t lab = labels[(int64_t)b * n + i];
+  if (lab < 0 || lab >= k) return;
+  if (blockIdx.y == 0) unsafeAtomicAdd(&counts[(int64_t)b * k + lab], 1.0f);
+  for (int e = 0; e < ne; ++e)
+    unsafeAtomicAdd(&sums[((int64_t)b * d + e0 + e) * k + lab], data[((int64_t)b * d + e0 + e) * n + i]);
 }
 
 // ---- update, codebook-sized problems (k <= 256) ---------------------------------------------
@@ -463,7 +495,8 @@ extern "C" int tpq_max_sim(const float* A, const float* B, float* vals, int64_t*
   if (m == 0) return TPQ_OK;
   const int euclid = metric == TPQ_METRIC_NEG_SQ_L2 ? 1 : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (n <= 256 && d <= 128) {  // PQ codebook shape: centroids resident in LDS
+  // centroids resident in LDS, 256 at a time (one launch per chunk; PQ codebooks need one)
+  if (d <= 128 && n <= 65536) {
     const int dh = (d + 1) / 2;
     if (dh <= 1) return launch_codebook<1>(A, B, vals, inds, l, d, m, n, euclid, st);
     if (dh <= 2) return launch_codebook<2>(A, B, vals, inds, l, d, m, n, euclid, st);
@@ -495,17 +528,15 @@ extern "C" int tpq_compute_centroids(const float* data, const int64_t* labels, f
     return TPQ_ERR_WORKSPACE;
   }
   const size_t lds = (size_t)(kCcDT + 1) * k * sizeof(float);
-  if (lds > 160 * 1024) {
-    set_error("compute_centroids: k=%d needs %zu bytes of LDS (> 160 KiB)", k, lds);
-    return TPQ_ERR_UNSUPPORTED;
-  }
+  const bool lds_fits = lds <= 160 * 1024;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int rc = check_hip(hipMemsetAsync(workspace, 0, need, st), "compute_centroids memset");
   if (rc) return rc;
   float* sums = reinterpret_cast<float*>(workspace);
   float* counts = sums + (size_t)l * d * k;
   if (n > 0) {
-    rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(centroid_accum_kernel),
+    if (lds_fits)
+      rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(centroid_accum_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                    "centroid_accum_kernel attr");
     if (rc) return rc;
@@ -521,6 +552,17 @@ extern "C" int tpq_compute_centroids(const float* data, const int64_t* labels, f
                          dim3((unsigned)((n + points - 1) / points), dt64, l), dim3(256), 0, st, data,
                          labels, sums, counts, d, n, k, points);
       TPQ_LAUNCH_CHECK("centroid_accum_codebook_kernel");
+      const int64_t total = (int64_t)l * d * k;
+      hipLaunchKernelGGL(centroid_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
+                         0, st, sums, counts, centroids, d, k, total);
+      TPQ_LAUNCH_CHECK("centroid_finalize_kernel");
+      return TPQ_OK;
+    }
+    if (!lds_fits) {
+      hipLaunchKernelGGL(centroid_accum_global_kernel,
+                         dim3((unsigned)((n + 255) / 256), (d + kCcDT - 1) / kCcDT, l), dim3(256), 0,
+                         st, data, labels, sums, counts, d, n, k);
+      TPQ_LAUNCH_CHECK("centroid_accum_global_kernel");
       const int64_t total = (int64_t)l * d * k;
       hipLaunchKernelGGL(centroid_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
                          0, st, sums, counts, centroids, d, k, total);
