@@ -116,11 +116,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # TPQ_BENCH_ONE_DEVICE=1 is a validation hook for 1-GPU boxes: every rank uses cuda:0 and the
+    # rendezvous runs over gloo (RCCL refuses two ranks on one device); never set by the driver
+    one_device = os.environ.get("TPQ_BENCH_ONE_DEVICE", "0") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from torchpq_amd import distributed as tpd
     from torchpq_amd.index import IVFPQIndex
@@ -216,7 +224,7 @@ def main():
         d2 = (-2.0 * queries[:, :ns].T @ base) + (base * base).sum(0)[None, :]
         nn = d2.argmin(dim=1)
         out["recall_gt@%d" % args.k] = round(float((ids[:ns] == nn[:, None]).any(dim=1).float().mean().item()), 4)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # CPU baseline: rank 0 at N=1 only
             cb, cpu_ids = cpu_baseline(idx, queries, args.k, min(args.cpu_sample, args.nq))
             out["cpu_baseline"] = cb
             gpu_ids = ids[:cpu_ids.shape[0]].cpu().numpy()
