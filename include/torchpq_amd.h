@@ -131,6 +131,29 @@ int tpq_ivfpq_scan_topk_residual(const uint8_t* codes, const float* part1, const
 int tpq_residual_part1(const float* query, const float* codebook, float* part1, int m, int ds,
                        int nq, tpq_stream_t stream);
 
+/* Residual scan at the speed of the plain scan (same reference kernel, ivfpq_topk.cu:1039-1208,
+ * same results bit for bit).  Only part1[q] lives in LDS (staged once per query, or built in the
+ * workgroup from query [m*ds][nq] + codebook [m][ds][256] when part1 == NULL); the cell-dependent
+ * half of the selection value is a per-slot constant:
+ *   tpq_ivfpq_residual_slot_terms: slot_term f32 [n_slots] = sum_j part2[cell(s)][j][code_j(s)]
+ *                                  cell_bound f32 [n_cells] = sum_j max_c |part2[cell][j][c]|
+ * (derived from CellContainer._storage + part2; recompute after add/remove/expand).
+ * Survivors are re-evaluated exactly (base_sims + fl(part1 + part2) ascending j); queries whose
+ * candidate band overflows, or that list a cell twice, are redone by the exact kernel.
+ * workspace: tpq_ivfpq_scan_workspace_bytes(nq, k, n_split, m).  m in {8,16,32,64,120}. */
+int tpq_ivfpq_residual_slot_terms(const uint8_t* codes, const float* part2,
+                                  const int64_t* cell_start, const int64_t* cell_size,
+                                  float* slot_term, float* cell_bound, int64_t n_slots,
+                                  int n_cells, int m, tpq_stream_t stream);
+int tpq_ivfpq_scan_topk_residual_packed(
+    const uint8_t* packed, const uint8_t* codes, const float* part1, const float* query,
+    const float* codebook, int ds, const float* part2, const float* slot_term,
+    const float* cell_bound, const int64_t* cells, const float* base_sims, const uint8_t* is_empty,
+    const int64_t* cell_start, const int64_t* cell_size, const int64_t* n_probe_list,
+    float* out_vals, int64_t* out_addr, const int64_t* address2id, int64_t* out_ids,
+    int64_t n_slots, int nq, int max_nprobe, int m, int k, int n_split, void* workspace,
+    size_t workspace_bytes, tpq_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * a-3  ADC look-up table
  * replaces PQCodec.precompute_adc  torchpq/codec/PQCodec.py:62-75

@@ -283,6 +283,23 @@ def test_residual_index_end_to_end(use_precomputed):
     rec = N(idx.decode((pq_code[:, top], vq_code[top])))
     exact = -((queries - rec) ** 2).sum(0)
     np.testing.assert_allclose(N(v)[:, 0], exact, rtol=2e-3, atol=2e-3 * np.abs(exact).max())
+    if use_precomputed:
+        # scan layout (default) == reference layout == table-fed scan layout, bit for bit; the
+        # per-slot constants of the scan layout follow the codes through add / remove
+        def three_ways():
+            out = []
+            for packed, fused in ((True, True), (False, True), (True, False)):
+                idx.use_packed_layout, idx.use_fused_lut = packed, fused
+                out.append(idx.search(T(queries), k=k))
+            idx.use_packed_layout = idx.use_fused_lut = True
+            return out
+        for vv, ii in three_ways():
+            assert torch.equal(vv, v) and torch.equal(ii, i)
+        idx.add(T((base[:, :500] + 0.5).astype(np.float32)), ids=torch.arange(n, n + 500, device=DEV))
+        idx.remove(ids=torch.arange(0, 200, device=DEV))
+        (va, ia), (vb, ib), (vc, ic) = three_ways()
+        assert not torch.equal(ia, i)
+        assert torch.equal(va, vb) and torch.equal(ia, ib) and torch.equal(va, vc) and torch.equal(ia, ic)
 
 
 def test_flat_index_exact_search():

@@ -378,6 +378,61 @@ def test_residual_scan_random_vs_oracle(K, m, k, n_probe, tomb):
     assert np.array_equal(N(v), ev) and np.array_equal(N(a), ea)
 
 
+@pytest.mark.parametrize("m,k,n_probe,tomb,mode", [
+    (8, 10, 5, 0, "part1"), (64, 100, 12, 30, "part1"), (16, 300, 7, 0, "fused"), (32, 1, 9, 5, "fused"),
+    (120, 60, 6, 0, "part1"), (64, 100, 12, 0, "ties"), (16, 20, 8, 3, "dup"), (64, 1020, 9, 0, "part1")])
+def test_residual_packed_scan_vs_oracle(K, m, k, n_probe, tomb, mode):
+    """tpq_ivfpq_scan_topk_residual_packed == the residual oracle, bit for bit (values, addresses),
+    incl. splits, tombstones, mass ties (band overflow -> exact redo) and a cell listed twice."""
+    rng = np.random.default_rng(m * 11 + k)
+    n_cells, nq = 30, 21
+    storage, is_empty, start, sizes, a2i = _random_index(rng, m, n_cells, 140, tomb, 0.1)
+    part2 = (rng.standard_normal((n_cells, m, 256)) * 50).astype(np.float32)
+    ds, query, cb = 2, None, None
+    if mode == "fused":
+        cb = (rng.standard_normal((m, ds, 256)) * 8).astype(np.float32)
+        query = (rng.standard_normal((m * ds, nq)) * 8).astype(np.float32)
+        part1 = orc.residual_part1(query, cb)
+    elif mode == "ties":  # small integers: thousands of exactly equal values
+        part1 = rng.integers(-1, 2, (nq, m, 256)).astype(np.float32)
+        part2 = rng.integers(-1, 2, (n_cells, m, 256)).astype(np.float32)
+    else:
+        part1 = (rng.standard_normal((nq, m, 256)) * 50).astype(np.float32)
+    cells = np.stack([rng.permutation(n_cells)[:n_probe] for _ in range(nq)])
+    cells[2, 1] = cells[2, 0]          # adjacent repeat: skipped (ivfpq_topk.cu:1092-1107)
+    if mode == "dup":
+        cells[3, 4] = cells[3, 1]      # non-adjacent repeat: the cell is scanned twice
+        cells[5, 7] = cells[5, 0]
+    base = (rng.standard_normal((nq, n_probe)) * 300).astype(np.float32)
+    if mode == "ties":
+        base = np.round(base / 100).astype(np.float32)
+    npl = rng.integers(0, n_probe + 1, nq).astype(np.int64)
+    npl[:8] = n_probe
+    cs, sz = start[cells], sizes[cells]
+    ev, ea = c_oracle.scan_topk_residual(storage, part1, part2, cells, base, is_empty, cs, sz, npl, k)
+    scan = K.IVFPQTopkHip(m=m)
+    st, p2 = T(storage), T(part2)
+    packed = K.PackCodesHip()(st)
+    slot_term, cell_bound = K.ResidualSlotTermsHip()(st, p2, T(start), T(sizes))
+    # the per-slot constant is the ascending-j fp32 sum of the slot's part2 entries
+    stn, codes = N(slot_term), orc.storage_to_codes(storage, np.arange(storage.shape[1]))
+    for s in rng.integers(0, storage.shape[1], 50):
+        c = np.searchsorted(start, s, side="right") - 1
+        if s < start[c] + sizes[c]:
+            acc = np.float32(0)
+            for j in range(m):
+                acc = np.float32(acc + part2[c, j, codes[j, s]])
+            assert stn[s] == acc
+    np.testing.assert_allclose(N(cell_bound), np.abs(part2).max(-1).sum(-1), rtol=1e-5)
+    for n_split in (1, 3):
+        v, a = scan.topk_residual_packed(
+            st, packed, p2, slot_term, cell_bound, T(cells), T(base), T(is_empty), T(cs), T(sz), T(npl),
+            n_candidates=k, part1=None if mode == "fused" else T(part1),
+            query=T(query) if mode == "fused" else None, codebook=T(cb) if mode == "fused" else None,
+            n_split=n_split)
+        assert np.array_equal(N(v), ev) and np.array_equal(N(a), ea), (mode, n_split)
+
+
 @pytest.mark.parametrize("m,ds,k,layout,distance", [(64, 2, 100, "packed", "euclidean"), (16, 4, 10, "packed", "cosine"),
                                                     (120, 8, 50, "packed", "euclidean"), (24, 3, 7, "ref", "euclidean"),
                                                     (8, 16, 130, "ref", "euclidean")])

@@ -33,6 +33,10 @@ SIGNATURES = {
     "tpq_ivfpq_scan_topk_residual": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "tpq_residual_part1": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tpq_ivfpq_residual_slot_terms": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "tpq_ivfpq_scan_topk_residual_packed": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp,
+                                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i,
+                                                 _i, _i, _i, _vp, _sz, _vp]),
     "tpq_adc_lut": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tpq_topk_select": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tpq_coarse_select": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

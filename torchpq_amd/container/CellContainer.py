@@ -47,6 +47,7 @@ class CellContainer(BaseContainer):
         self.register_buffer("_is_empty", torch.ones(cap, device=device, dtype=torch.uint8))
         self._packed = None          # scan-layout copy of _storage (derived, never saved)
         self._packed_valid = False
+        self._codes_version = 0      # bumped whenever codes or their placement change
         self._has_holes = False      # a tombstone inside some [start, start+size)
         self._get_cell_by_address_hip = GetCellByAddressHip()
         self._get_ioa_hip = GetIOAHip()
@@ -73,6 +74,7 @@ class CellContainer(BaseContainer):
         super()._after_load_state_dict()
         self._packed = None
         self._packed_valid = False
+        self._codes_version += 1
         self._drop_inverse_id_mapping()
         # a foreign state_dict may carry tombstones inside a cell's occupied range
         pos = torch.arange(self.capacity, device=self._is_empty.device)
@@ -120,6 +122,7 @@ class CellContainer(BaseContainer):
         assert data.shape[1] == address.shape[0]
         packed = self._packed if self._packed_valid else None
         self._scatter_codes_hip(data.to(self.device), address.to(self.device), self._storage, packed)
+        self._codes_version += 1
 
     def empty(self):
         super().empty()
@@ -127,6 +130,7 @@ class CellContainer(BaseContainer):
         self._cell_size.fill_(0)
         self._is_empty.fill_(1)
         self._packed_valid = False
+        self._codes_version += 1
         self._has_holes = False
         self.print_message("index has been emptied", 2)
 
@@ -159,6 +163,7 @@ class CellContainer(BaseContainer):
         self._cell_capacity.copy_(new_capacity)
         self._packed = None
         self._packed_valid = False
+        self._codes_version += 1
         self._drop_inverse_id_mapping()
         return added
 
@@ -256,5 +261,6 @@ class CellContainer(BaseContainer):
         self._address2id[tail] = -1
         self._cell_size[ucells] -= counts
         self._packed_valid = False
+        self._codes_version += 1
         self._drop_inverse_id_mapping()
         self.print_message(f"{n_removed} items has been removed", 2)

@@ -1,0 +1,966 @@
+// Device code of the IVF list scan (shared by scan.hip and the per-M scan_packed.hip units).
+#pragma once
+#include "common.h"
+#include "scan_layout.h"
+#include "wave_topk.h"
+
+namespace tpq {
+
+constexpr int kScanWaves = 8;
+constexpr int kScanThreads = kScanWaves * 64;
+
+struct ScanArgs {
+  const uint8_t* codes;    // reference layout [m/4][n_slots][4]
+  const uint8_t* packed;   // scan layout (packed kernel only)
+  const float* lut;        // [m][nq][256]; nullptr = build the LUT in the workgroup ("fused")
+  const float* query;      // fused: [m*ds][nq]
+  const float* codebook;   // fused: [m][ds][256]
+  int ds, euclid;          // fused: sub-vector length, 1 = 2ab-a^2-b^2 / 0 = dot / 2 = 2ab
+  const uint8_t* is_empty; // nullable
+  const int64_t* cell_start;
+  const int64_t* cell_size;
+  const int64_t* n_probe_list;
+  float* out_vals;
+  int64_t* out_addr;
+  const int64_t* address2id;
+  int64_t* out_ids;
+  float* ws_vals;  // [nq][n_split][64R]
+  int* ws_idx;
+  int* flags;             // [nq] packed path: 1 = candidate band overflowed, redo exactly
+  float* ws_delta;        // [nq] packed path: fast-vs-exact error bound of the query
+  const int* only_flagged;  // reference kernel: when set, only queries with a non-zero flag run
+  int64_t n_slots;
+  int nq, max_nprobe, m, k, n_split;
+};
+
+// ---- shared pieces -----------------------------------------------------------------------
+
+struct ProbeTable {  // lives in LDS
+  int* start;        // [max_nprobe]
+  int* size;         // [max_nprobe]
+  int* tile_begin;   // [max_nprobe + 1] exclusive prefix of ceil(size/64)
+};
+
+// wave 0 fills the probe table; cells whose start equals the previous probe's start are
+// skipped (ivfpq_topk.cu:864-866)
+__device__ __forceinline__ void build_probe_table(const ScanArgs& a, int q, int n_probe,
+                                                  ProbeTable t) {
+  const int lane = lane_id();
+  int running = 0;
+  for (int base = 0; base < n_probe; base += 64) {
+    const int p = base + lane;
+    int st = 0, sz = 0;
+    if (p < n_probe) {
+      st = (int)a.cell_start[(int64_t)q * a.max_nprobe + p];
+      sz = (int)a.cell_size[(int64_t)q * a.max_nprobe + p];
+      if (p > 0 && a.cell_start[(int64_t)q * a.max_nprobe + p - 1] == (int64_t)st) sz = 0;
+      if (sz < 0) sz = 0;
+    }
+    int tiles = (sz + 63) >> 6;
+    int incl = tiles;  // inclusive wave scan
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (p < n_probe) {
+      t.start[p] = st;
+      t.size[p] = sz;
+      t.tile_begin[p] = running + incl - tiles;
+    }
+    running += readlane_i(incl, 63);
+  }
+  if (lane == 0) t.tile_begin[n_probe] = running;
+}
+
+// lists travel as keys: `lv` holds the high words (value images), `li` the low words (~index)
+template <int R>
+__device__ __forceinline__ void store_list(const WaveTopK<R>& top, float* lv, int* li) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    reinterpret_cast<unsigned*>(lv)[r * 64 + lane] = top.k[r].hi;
+    reinterpret_cast<unsigned*>(li)[r * 64 + lane] = top.k[r].lo;
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void merge_list(WaveTopK<R>& top, const float* lv, const int* li) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    top.insert_sorted(Key{reinterpret_cast<const unsigned*>(lv)[r * 64 + lane],
+                          reinterpret_cast<const unsigned*>(li)[r * 64 + lane]});
+}
+
+template <int R>
+__device__ __forceinline__ void write_final(const ScanArgs& a, int q, const WaveTopK<R>& top) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int e = r * 64 + lane;
+    if (e < a.k) {
+      const int idx = key_index(top.k[r]);
+      const bool pad = (idx == kPadIdx);
+      const int64_t adr = pad ? -1 : (int64_t)idx;
+      a.out_vals[(int64_t)q * a.k + e] = pad ? -INFINITY : key_value(top.k[r]);
+      a.out_addr[(int64_t)q * a.k + e] = adr;
+      if (a.out_ids) a.out_ids[(int64_t)q * a.k + e] = pad ? -1 : a.address2id[adr];
+    }
+  }
+}
+
+// Cross-wave tree merge through LDS (`lv`/`li` may alias the dead LUT), then output.
+template <int R>
+__device__ __forceinline__ void finish_query(const ScanArgs& a, int q, int part,
+                                             WaveTopK<R>& top, float* lv, int* li) {
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();  // every wave is done with the LUT
+  for (int stride = 1; stride < kScanWaves; stride <<= 1) {
+    if ((wave & (2 * stride - 1)) == stride) store_list<R>(top, lv + wave * R * 64, li + wave * R * 64);
+    __syncthreads();
+    if ((wave & (2 * stride - 1)) == 0)
+      merge_list<R>(top, lv + (wave + stride) * R * 64, li + (wave + stride) * R * 64);
+    __syncthreads();
+  }
+  if (wave == 0) {
+    if (a.n_split == 1) {
+      write_final<R>(a, q, top);
+    } else {
+      const int64_t o = ((int64_t)q * a.n_split + part) * (R * 64);
+      store_list<R>(top, a.ws_vals + o, a.ws_idx + o);
+    }
+  }
+}
+
+// ---- LUT built inside the workgroup ("fused") ------------------------------------------------
+// Instead of reading a materialised [m][nq][256] table (a-3 writes 655 MB and the scan reads it
+// back at C2), the workgroup computes its query's LUT from the query and the PQ codebook, which
+// stays L2-resident (m*ds KiB).  The arithmetic is adc_lut_kernel's, operation for operation --
+// dot, |q|^2 and |c|^2 as ascending-dimension fma chains, then 2*dot, -|q|^2, -|c|^2 -- so the
+// entries are bit-identical to tpq_adc_lut's.
+__device__ __forceinline__ void stage_query(const ScanArgs& a, int q, float* xq, float* q2s,
+                                            int n_threads) {
+  const int d = a.m * a.ds;
+  for (int i = threadIdx.x; i < d; i += n_threads) xq[i] = a.query[(int64_t)i * a.nq + q];
+  __syncthreads();
+  for (int j = threadIdx.x; j < a.m; j += n_threads) {
+    float s = 0.f;
+    for (int e = 0; e < a.ds; ++e) s = fmaf(xq[j * a.ds + e], xq[j * a.ds + e], s);
+    q2s[j] = s;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float4 fused_lut4(const ScanArgs& a, int j, int c4, const float* xq,
+                                             const float* q2s) {
+  const float4* __restrict__ cb = reinterpret_cast<const float4*>(a.codebook) + (int64_t)j * a.ds * 64 + c4;
+  float4 dot = make_float4(0.f, 0.f, 0.f, 0.f), c2 = dot;
+  for (int e = 0; e < a.ds; ++e) {
+    const float4 y = cb[e * 64];
+    const float x = xq[j * a.ds + e];
+    dot.x = fmaf(x, y.x, dot.x); dot.y = fmaf(x, y.y, dot.y);
+    dot.z = fmaf(x, y.z, dot.z); dot.w = fmaf(x, y.w, dot.w);
+    c2.x = fmaf(y.x, y.x, c2.x); c2.y = fmaf(y.y, y.y, c2.y);
+    c2.z = fmaf(y.z, y.z, c2.z); c2.w = fmaf(y.w, y.w, c2.w);
+  }
+  if (!a.euclid) return dot;
+  const float q2 = q2s[j];
+  float4 v;
+  v.x = 2.f * dot.x; v.y = 2.f * dot.y; v.z = 2.f * dot.z; v.w = 2.f * dot.w;
+  if (a.euclid == 2) return v;  // residual part1 = 2 q_j.r_jc (residual_part1_kernel)
+  v.x = v.x - q2; v.y = v.y - q2; v.z = v.z - q2; v.w = v.w - q2;
+  v.x = v.x - c2.x; v.y = v.y - c2.y; v.z = v.z - c2.z; v.w = v.w - c2.w;
+  return v;
+}
+
+__device__ __forceinline__ void stage_lut_linear(const ScanArgs& a, int q, float* lut,
+                                                 const float* xq, const float* q2s) {
+  // lut[j*256 + c] <- a.lut[(j*nq + q)*256 + c]; 16-byte loads, 1 KiB rows
+  const float4* __restrict__ src = reinterpret_cast<const float4*>(a.lut);
+  float4* dst = reinterpret_cast<float4*>(lut);
+  for (int i = threadIdx.x; i < a.m * 64; i += kScanThreads) {
+    const int j = i >> 6, c4 = i & 63;
+    dst[i] = a.lut ? src[((int64_t)j * a.nq + q) * 64 + c4] : fused_lut4(a, j, c4, xq, q2s);
+  }
+}
+
+// ---- reference-layout kernel ---------------------------------------------------------------
+
+template <int R>
+__global__ __launch_bounds__(kScanThreads) void scan_ref_kernel(ScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lut_bytes = a.m * 1024;
+  const int list_bytes = kScanWaves * R * 64 * 8;
+  const int region0 = lut_bytes > list_bytes ? lut_bytes : list_bytes;
+  float* lut = reinterpret_cast<float*>(smem);
+  float* qv_all = reinterpret_cast<float*>(smem + region0);
+  int* qi_all = reinterpret_cast<int*>(smem + region0 + kScanWaves * 256);
+  int* ptab = reinterpret_cast<int*>(smem + region0 + kScanWaves * 512);
+  ProbeTable tab{ptab, ptab + a.max_nprobe, ptab + 2 * a.max_nprobe};
+  unsigned* tau_key = reinterpret_cast<unsigned*>(ptab + 3 * a.max_nprobe + 1);
+  float* xq = reinterpret_cast<float*>(tau_key + 1);  // fused LUT: query [m*ds], then |q_j|^2 [m]
+  float* q2s = xq + a.m * a.ds;
+
+  const int q = blockIdx.x / a.n_split;
+  const int part = blockIdx.x - q * a.n_split;
+  if (a.only_flagged && a.only_flagged[q] == 0) return;  // exact redo of flagged queries only
+  const int wave = threadIdx.x >> 6;
+  const int lane = lane_id();
+  int n_probe = (int)a.n_probe_list[q];
+  n_probe = n_probe < 0 ? 0 : (n_probe > a.max_nprobe ? a.max_nprobe : n_probe);
+
+  if (wave == 0) {
+    build_probe_table(a, q, n_probe, tab);
+    if (lane == 0) *tau_key = f2key(-INFINITY);
+  }
+  if (!a.lut) stage_query(a, q, xq, q2s, kScanThreads);
+  stage_lut_linear(a, q, lut, xq, q2s);
+  __syncthreads();
+
+  WaveSelector<R> sel;
+  sel.init(qv_all + wave * 64, qi_all + wave * 64, a.k);
+
+  const int total_tiles = tab.tile_begin[n_probe];
+  const int t_begin = (int)(((int64_t)total_tiles * part) / a.n_split);
+  const int t_end = (int)(((int64_t)total_tiles * (part + 1)) / a.n_split);
+  const int G = a.m >> 2;
+  const uint32_t* __restrict__ codes32 = reinterpret_cast<const uint32_t*>(a.codes);
+
+  int p = 0;
+  for (int T = t_begin + wave; T < t_end; T += kScanWaves) {
+    while (T >= tab.tile_begin[p + 1]) ++p;
+    const int off = ((T - tab.tile_begin[p]) << 6) + lane;
+    const bool valid = off < tab.size[p];
+    const int s = tab.start[p] + off;
+    float v = 0.f;
+    bool live = valid;
+    if (valid) {
+      if (a.is_empty) live = (a.is_empty[s] == 0);  // ivfpq_topk.cu:878,883-884
+      int g = 0;
+      for (; g + 4 <= G; g += 4) {
+        uint32_t w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = codes32[(int64_t)(g + u) * a.n_slots + s];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* row = lut + (g + u) * 1024;
+          v += row[w[u] & 255u];
+          v += row[256 + ((w[u] >> 8) & 255u)];
+          v += row[512 + ((w[u] >> 16) & 255u)];
+          v += row[768 + (w[u] >> 24)];
+        }
+      }
+      for (; g < G; ++g) {
+        const uint32_t w = codes32[(int64_t)g * a.n_slots + s];
+        const float* row = lut + g * 1024;
+        v += row[w & 255u];
+        v += row[256 + ((w >> 8) & 255u)];
+        v += row[512 + ((w >> 16) & 255u)];
+        v += row[768 + (w >> 24)];
+      }
+    }
+    // workgroup-shared admission threshold: any wave's k-th best bounds the final k-th best
+    const float tau_s = key2f(*reinterpret_cast<volatile unsigned*>(tau_key));
+    sel.tau = fmaxf(sel.tau, tau_s);
+    const float tau_before = sel.tau;
+    sel.push(live && (v >= sel.tau), v, s);
+    if (sel.tau > tau_before && lane == 0) atomicMax(tau_key, f2key(sel.tau));
+  }
+  {
+    const float tau_before = sel.tau;
+    sel.flush();
+    if (sel.tau > tau_before && lane == 0) atomicMax(tau_key, f2key(sel.tau));
+  }
+  finish_query<R>(a, q, part, sel.top, reinterpret_cast<float*>(smem),
+                  reinterpret_cast<int*>(smem + kScanWaves * R * 64 * 4));
+}
+
+// ---- residual PQ (reference layout, exact) --------------------------------------------------
+// Replaces ivfpq_topk_residual_precomputed (ivfpq_topk.cu:1039-1208) and ivfpq_topk_residual
+// (:973-1037).  The LUT depends on the probed cell: LUT_p = part1[q] + part2[cell] (one fp32 add
+// per entry, load_precomputed_v3 :522-560) or LUT_p = full[q][p]; value(slot) starts at
+// base_sims[q][p] (:1113) and adds LUT_p[j][code_j] in ascending j.  One workgroup per query
+// walks its probes in order: barrier, rebuild the 64-KiB LUT in LDS, barrier, the 8 waves scan
+// the cell's tiles; the per-wave register top-k and shared threshold carry across cells.
+struct ResidualArgs {
+  const float* part1;       // [nq][m][256]        (mode A; nullptr = 2 q_j.r_jc built from query/codebook)
+  const float* part2;       // [n_cells][m][256]   (mode A)
+  const float* full;        // [nq][max_nprobe][m][256] (mode B) or nullptr
+  const int64_t* cells;     // [nq][max_nprobe]    (mode A)
+  const float* base_sims;   // [nq][max_nprobe]
+  const float* slot_term;   // packed kernel: [n_slots] sum_j part2[cell(s)][j][code_j(s)]
+  const float* cell_bound;  // packed kernel: [n_cells] sum_j max_c |part2[cell][j][c]|
+};
+
+template <int R>
+__global__ __launch_bounds__(kScanThreads) void scan_residual_kernel(ScanArgs a, ResidualArgs ra) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lut_bytes = a.m * 1024;
+  const int list_bytes = kScanWaves * R * 64 * 8;
+  const int region0 = lut_bytes > list_bytes ? lut_bytes : list_bytes;
+  float* lut = reinterpret_cast<float*>(smem);
+  float* qv_all = reinterpret_cast<float*>(smem + region0);
+  int* qi_all = reinterpret_cast<int*>(smem + region0 + kScanWaves * 256);
+  int* ptab = reinterpret_cast<int*>(smem + region0 + kScanWaves * 512);
+  ProbeTable tab{ptab, ptab + a.max_nprobe, ptab + 2 * a.max_nprobe};
+  unsigned* tau_key = reinterpret_cast<unsigned*>(ptab + 3 * a.max_nprobe + 1);
+
+  float* xq = reinterpret_cast<float*>(tau_key + 1);  // part1 built here: query [m*ds], |q_j|^2 [m]
+  float* q2s = xq + a.m * a.ds;
+
+  const int q = blockIdx.x;
+  if (a.only_flagged && a.only_flagged[q] == 0) return;  // exact redo of flagged queries only
+  const int wave = threadIdx.x >> 6;
+  const int lane = lane_id();
+  int n_probe = (int)a.n_probe_list[q];
+  n_probe = n_probe < 0 ? 0 : (n_probe > a.max_nprobe ? a.max_nprobe : n_probe);
+  if (wave == 0) {
+    build_probe_table(a, q, n_probe, tab);
+    if (lane == 0) *tau_key = f2key(-INFINITY);
+  }
+  const bool build_part1 = !ra.full && !ra.part1;
+  if (build_part1) stage_query(a, q, xq, q2s, kScanThreads);
+  __syncthreads();
+
+  WaveSelector<R> sel;
+  sel.init(qv_all + wave * 64, qi_all + wave * 64, a.k);
+  const int G = a.m >> 2;
+  const uint32_t* __restrict__ codes32 = reinterpret_cast<const uint32_t*>(a.codes);
+  const int n4 = a.m * 64;  // float4 count of one LUT
+
+  for (int p = 0; p < n_probe; ++p) {
+    const int sz = tab.size[p];
+    if (sz == 0) continue;  // empty, or same start as the previous probe (ivfpq_topk.cu:1092-1107)
+    __syncthreads();        // every wave is done with the previous cell's LUT
+    float4* dst = reinterpret_cast<float4*>(lut);
+    if (ra.full) {
+      const float4* __restrict__ src =
+          reinterpret_cast<const float4*>(ra.full) + ((int64_t)q * a.max_nprobe + p) * n4;
+      for (int i = threadIdx.x; i < n4; i += kScanThreads) dst[i] = src[i];
+    } else {
+      const float4* __restrict__ s1 = reinterpret_cast<const float4*>(ra.part1) + (int64_t)q * n4;
+      const float4* __restrict__ s2 = reinterpret_cast<const float4*>(ra.part2) +
+                                      ra.cells[(int64_t)q * a.max_nprobe + p] * (int64_t)n4;
+      for (int i = threadIdx.x; i < n4; i += kScanThreads) {
+        const float4 x = build_part1 ? fused_lut4(a, i >> 6, i & 63, xq, q2s) : s1[i];
+        const float4 y = s2[i];
+        dst[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+      }
+    }
+    __syncthreads();
+    const float base = ra.base_sims[(int64_t)q * a.max_nprobe + p];
+    const int start = tab.start[p];
+    const int tiles = (sz + 63) >> 6;
+    for (int t = wave; t < tiles; t += kScanWaves) {
+      const int off = (t << 6) + lane;
+      const bool valid = off < sz;
+      const int s = start + off;
+      float v = base;
+      bool live = valid;
+      if (valid) {
+        if (a.is_empty) live = (a.is_empty[s] == 0);
+        for (int g = 0; g < G; ++g) {
+          const uint32_t w = codes32[(int64_t)g * a.n_slots + s];
+          const float* row = lut + g * 1024;
+          v += row[w & 255u];
+          v += row[256 + ((w >> 8) & 255u)];
+          v += row[512 + ((w >> 16) & 255u)];
+          v += row[768 + (w >> 24)];
+        }
+      }
+      const float tau_s = key2f(*reinterpret_cast<volatile unsigned*>(tau_key));
+      sel.tau = fmaxf(sel.tau, tau_s);
+      const float tau_before = sel.tau;
+      sel.push(live && (v >= sel.tau), v + 0.0f, s);
+      if (sel.tau > tau_before && lane == 0) atomicMax(tau_key, f2key(sel.tau));
+    }
+  }
+  sel.flush();
+  finish_query<R>(a, q, 0, sel.top, reinterpret_cast<float*>(smem),
+                  reinterpret_cast<int*>(smem + kScanWaves * R * 64 * 4));
+}
+
+// ---- packed-layout kernel ------------------------------------------------------------------
+// LUT in LDS in block order (scan_layout.h): entry (j, c) at dword lut_dword(M, j, c); the slot at
+// address s stores at byte position p the code of sub-quantizer subq_at(M, p, s), so lane (slot s)
+// step p reads a bank that differs from every other lane of its half-wave.
+//
+// The permuted order changes the fp32 summation order, so the streamed value f ("fast") is
+// used for SELECTION only: with |f - e| <= delta (e = the reference's ascending-order value),
+// every element of the exact top-k has f >= F_k - 2*delta (F_k = k-th best fast value).  Each
+// wave keeps its best 64R > k candidates by f and admits everything down to threshold - 2*delta.
+// At the end of the query a wave re-evaluates the entries that can still matter
+// (f >= shared threshold - 2*delta: ~k/8 of them) exactly -- ascending j, from the packed bytes
+// un-permuted through a private LDS row, LUT still resident -- re-ranks them by (e desc, address
+// asc) and dumps the list; scan_merge_refine_kernel merges the per-wave lists of a query and
+// writes the best k: bit-identical to the reference-layout kernel.  If a merged list ends up so
+// full of near-ties (more than 64R candidates within 2*delta of the k-th) that a member of the
+// exact top-k may have been evicted, the query is flagged and redone by scan_ref_kernel.
+
+__device__ __forceinline__ void stage_lut_blocked(const ScanArgs& a, int q, float* lut,
+                                                  int n_threads, const float* xq,
+                                                  const float* q2s, const float* part1 = nullptr) {
+  // thread handles (j, 4 consecutive c): 16-byte global load, 4 scalar LDS stores.
+  // Consecutive threads take consecutive j for the same c-group so that the LDS stores of a
+  // half-wave land in distinct banks.
+  const float4* __restrict__ src = reinterpret_cast<const float4*>(a.lut);
+  const int m = a.m;
+  for (int i = threadIdx.x; i < m * 64; i += n_threads) {
+    const int c4 = i / m, j = i - c4 * m;
+    const float4 x = part1 ? reinterpret_cast<const float4*>(part1)[((int64_t)q * m + j) * 64 + c4]
+                     : a.lut ? src[((int64_t)j * a.nq + q) * 64 + c4]
+                             : fused_lut4(a, j, c4, xq, q2s);
+    const int c = c4 * 4;
+    lut[scan_layout::lut_dword(m, j, c + 0)] = x.x;
+    lut[scan_layout::lut_dword(m, j, c + 1)] = x.y;
+    lut[scan_layout::lut_dword(m, j, c + 2)] = x.z;
+    lut[scan_layout::lut_dword(m, j, c + 3)] = x.w;
+  }
+}
+
+template <int M>
+struct LdsLut {
+  const float* lut;
+  __device__ __forceinline__ float operator()(int j, unsigned c) const {
+    return lut[scan_layout::lut_dword(M, j, (int)c)];
+  }
+};
+// residual PQ: entry = part1 (LDS) + part2[cell] (global, L2-resident), rounded like the LUT the
+// reference builds per probe (load_precomputed_v3, ivfpq_topk.cu:522-560)
+template <int M>
+struct ResidualLut {
+  const float* lut;
+  const float* part2_cell;  // this lane's cell: [M][256]
+  __device__ __forceinline__ float operator()(int j, unsigned c) const {
+    return lut[scan_layout::lut_dword(M, j, (int)c)] + part2_cell[j * 256 + (int)c];
+  }
+};
+// Exact (ascending-j) value of slot `idx` from its PACKED bytes: the lane un-permutes its slot
+// into sub-quantizer order through a private LDS row (stride M/4+1 dwords: conflict-free), then
+// sums LUT entries in the reference's order.
+template <int M, class LutFn>
+__device__ __forceinline__ float exact_from_packed(const uint8_t* __restrict__ packed,
+                                                   int64_t n_slots, int idx, bool active,
+                                                   uint32_t* scratch, int row_id,
+                                                   const LutFn& lutfn, float init = 0.f) {
+  using L = scan_layout::Layout<M>;
+  constexpr int G = M / 4;
+  uint32_t* row = scratch + row_id * (G + 1);
+  if (active) {
+    typename L::chunk_t w[L::kChunks];
+    L::load(packed, n_slots, idx, w);
+#pragma unroll
+    for (int d = 0; d < G; ++d) {
+      const scan_layout::BlockAt<M> kb(4 * d);
+      const int sb = idx & (kb.size - 1);
+      const uint32_t x = (uint32_t)(sb & 3);
+      const uint32_t sel = 0x03020100u ^ (x * 0x01010101u);  // out.byte[k] = in.byte[k ^ x]
+      const uint32_t wd = L::word(w, d);
+      const int dst = (kb.base >> 2) + ((d - (kb.base >> 2)) ^ (sb >> 2));
+      row[dst] = __builtin_amdgcn_perm(wd, wd, sel);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  float v = init;
+  if (active) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const uint32_t wd = row[g];
+      v += lutfn(4 * g + 0, wd & 255u);
+      v += lutfn(4 * g + 1, (wd >> 8) & 255u);
+      v += lutfn(4 * g + 2, (wd >> 16) & 255u);
+      v += lutfn(4 * g + 3, wd >> 24);
+    }
+  }
+  return active ? v : -INFINITY;
+}
+
+// phase 2, wave-level: the merged list already carries EXACT values; write the best k and raise
+// the overflow flag when the list is so full of near-ties that a member of the exact top-k may
+// have been evicted from a wave's list (see the header comment of this section)
+template <int R, bool RES = false>
+__device__ __forceinline__ void finalize_and_write(const ScanArgs& a, int q, const WaveTopK<R>& top,
+                                                   float delta2) {
+  const float ek = top.kth_value(a.k);
+  const Key klast = readlane_key(top.k[R - 1], 63);
+  const bool overflow = (key_index(klast) != kPadIdx) && !(key_value(klast) < ek - delta2);
+  write_final<R>(a, q, top);
+  if constexpr (RES) {  // flags were zeroed by the host; the scan may already have raised this one
+    if (lane_id() == 0 && overflow) a.flags[q] = 1;
+  } else {
+    if (lane_id() == 0) a.flags[q] = overflow ? 1 : 0;
+  }
+}
+
+// waves per workgroup: 8 while two workgroups share a CU (LUT <= 64 KiB); 16 when the LUT is so
+// large that only one workgroup fits (m > 64, e.g. GIST m=120: 120 KiB) -- same 16 waves per CU
+constexpr int packed_waves(int M) { return M <= 64 ? 8 : 16; }
+
+// per-wave scratch of the end-of-query exact re-evaluation: un-permute rows of M/4+1 dwords,
+// 16 per pass (8 when the LUT leaves little LDS: m > 64)
+constexpr int refine_rows(int M) { return M <= 64 ? 16 : 8; }
+constexpr int packed_aux_bytes(int /*R*/, int M) {
+  return packed_waves(M) * refine_rows(M) * (M / 4 + 1) * 4;
+}
+
+// 2 workgroups per CU (LDS: 2 x (64 KiB LUT + ~14 KiB)) need <= 128 VGPRs: 4 waves per SIMD
+//
+// RES = residual PQ (replaces ivfpq_topk_residual_precomputed, ivfpq_topk.cu:1039-1208, at full
+// scan speed): the reference rebuilds LUT_p = part1[q] + part2[cell_p] in shared memory for every
+// probe (128 KiB read per 62 KiB of codes at C2).  Here only part1[q] is staged, once per query;
+// the cell-dependent half of the fast value, sum_j part2[cell(s)][j][code_j(s)], is a per-SLOT
+// constant precomputed at index-build time (ResidualArgs::slot_term, 4 B per slot) and
+//   f(s) = sum_j part1[j][code_j] (permuted order) + (base_p + slot_term[s]).
+// f is again a selection key only (|f - e| <= delta with the bound below); survivors are
+// re-evaluated with the reference's arithmetic: v = base_p; v += fl(part1 + part2) ascending j.
+template <int R, int M, bool RES>
+__global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_packed_kernel(ScanArgs a,
+                                                                                    ResidualArgs ra,
+                                                                                    float delta_rel) {
+  using L = scan_layout::Layout<M>;
+  constexpr int NW = packed_waves(M);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int lut_bytes = M * 1024;
+  constexpr int aux_bytes = packed_aux_bytes(R, M);
+  float* lut = reinterpret_cast<float*>(smem);
+  uint32_t* scratch_all = reinterpret_cast<uint32_t*>(smem + lut_bytes);
+  float* qv_all = reinterpret_cast<float*>(smem + lut_bytes + aux_bytes);
+  int* qi_all = reinterpret_cast<int*>(smem + lut_bytes + aux_bytes + NW * 256);
+  int* ptab = reinterpret_cast<int*>(smem + lut_bytes + aux_bytes + NW * 512);
+  ProbeTable tab{ptab, ptab + a.max_nprobe, ptab + 2 * a.max_nprobe};
+  unsigned* tau_key = reinterpret_cast<unsigned*>(ptab + 3 * a.max_nprobe + 1);
+  float* red = reinterpret_cast<float*>(tau_key + 1);  // [2 NW] reduction scratch
+  float* wave_q = red + 2 * NW;                // [NW] each wave's r-th best
+  float* pbase = wave_q + NW;                  // RES: [max_nprobe] base_sims of the probe
+  int* pcell = reinterpret_cast<int*>(pbase + (RES ? a.max_nprobe : 0));  // RES: [max_nprobe] cell
+  float* xq = reinterpret_cast<float*>(pcell + (RES ? a.max_nprobe : 0));
+  float* q2s = xq + M * a.ds;                  // fused LUT: query [M*ds], then |q_j|^2 [M]
+
+  const int q = blockIdx.x / a.n_split;
+  const int part = blockIdx.x - q * a.n_split;
+  const int wave = threadIdx.x >> 6;
+  const int lane = lane_id();
+  int n_probe = (int)a.n_probe_list[q];
+  n_probe = n_probe < 0 ? 0 : (n_probe > a.max_nprobe ? a.max_nprobe : n_probe);
+
+  if (wave == 0) {
+    build_probe_table(a, q, n_probe, tab);
+    if (lane == 0) *tau_key = f2key(-INFINITY);
+    if (lane < NW) wave_q[lane] = -INFINITY;
+  }
+  const float* part1 = RES ? ra.part1 : nullptr;
+  if (!a.lut && !part1) stage_query(a, q, xq, q2s, NW * 64);
+  stage_lut_blocked(a, q, lut, NW * 64, xq, q2s, part1);
+  float probe_mx = 0.f;
+  if constexpr (RES) {
+    for (int pp = threadIdx.x; pp < n_probe; pp += NW * 64) {
+      const float b = ra.base_sims[(int64_t)q * a.max_nprobe + pp];
+      const int c = (int)ra.cells[(int64_t)q * a.max_nprobe + pp];
+      pbase[pp] = b;
+      pcell[pp] = c;
+      probe_mx = fmaxf(probe_mx, fabsf(b) + ra.cell_bound[c]);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) probe_mx = fmaxf(probe_mx, __shfl_xor(probe_mx, d, 64));
+    if (lane == 0) red[NW + wave] = probe_mx;
+  }
+  __syncthreads();
+
+  // delta >= |fast - exact|: both are fp32 sums of the same M terms in different orders, each
+  // within (M-1) u * sum|x_i| of the real sum (u = 2^-24), and sum|x_i| <= sum_j max_c|LUT[j][c]|.
+  // RES: the terms are base_p, part1_j, part2_j: exact = M sequential adds of fl(part1_j+part2_j)
+  // onto base_p, fast = (M-1)-add sums of the part1's and of the part2's plus two more adds: each
+  // within (M+1) u A of the real sum, A = |base_p| + sum_j max|part1_j| + cell_bound[cell_p]
+  // (the host passes delta_rel with M+1 in place of M-1).
+  float part_sum = 0.f;
+  for (int j = wave; j < M; j += NW) {
+    float mx = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fabsf(lut[scan_layout::lut_dword(M, j, lane * 4 + u)]));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    part_sum += mx;
+  }
+  if (lane == 0) red[wave] = part_sum;
+  __syncthreads();
+  float bound = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) bound += red[w];
+  if constexpr (RES) {
+    float mx = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mx = fmaxf(mx, red[NW + w]);
+    bound += mx;
+  }
+  const float delta2 = 2.f * delta_rel * bound;  // 2*delta: width of the candidate band
+
+  WaveSelector<R> sel;
+  sel.init(qv_all + wave * 64, qi_all + wave * 64, a.k);
+  sel.margin = delta2;
+
+  const int total_tiles = tab.tile_begin[n_probe];
+  const int t_begin = (int)(((int64_t)total_tiles * part) / a.n_split);
+  const int t_end = (int)(((int64_t)total_tiles * (part + 1)) / a.n_split);
+
+  // Workgroup-shared admission threshold.  Two valid lower bounds of the final k-th best:
+  //  (a) any wave's own k-th best (tau_key, atomic max);
+  //  (b) min over the 8 waves of each wave's r-th best, r = ceil(k/8): the 8 lists then hold
+  //      >= 8r >= k candidates at or above it.  Tiles are dealt round-robin to the waves, so
+  //      (b) tracks the true k-th best closely and keeps the pass rate near k*ln(N/k)/N.
+  const int r_share = (a.k + NW - 1) / NW;
+  // readers poll ONE word per tile; the (rare) publisher folds bound (b) into it
+  auto refresh_tau = [&]() {
+    sel.tau = fmaxf(sel.tau, key2f(*reinterpret_cast<volatile unsigned*>(tau_key)));
+  };
+  auto publish = [&](float /*tau_before*/) {
+    // readlane must run with every lane active: inside `if (lane == 0)` the source lane is
+    // inactive and its register contents are undefined to the compiler
+    const float mine = sel.top.kth_value(r_share);
+    if (lane == 0) {
+      reinterpret_cast<volatile float*>(wave_q)[wave] = mine;
+      float qmin = reinterpret_cast<volatile float*>(wave_q)[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) qmin = fminf(qmin, reinterpret_cast<volatile float*>(wave_q)[w]);
+      atomicMax(tau_key, f2key(fmaxf(sel.tau, qmin)));
+    }
+  };
+
+  struct Tile {
+    int s;
+    bool valid;
+    float add;  // RES: base_p + slot_term[s]
+  };
+  int p = 0;
+  auto locate = [&](int T) -> Tile {
+    while (T >= tab.tile_begin[p + 1]) ++p;
+    const int off = ((T - tab.tile_begin[p]) << 6) + lane;
+    Tile t{tab.start[p] + off, off < tab.size[p], 0.f};
+    if constexpr (RES) {
+      if (t.valid) t.add = pbase[p] + ra.slot_term[t.s];
+    }
+    return t;
+  };
+  auto consume = [&](const typename L::chunk_t(&w)[L::kChunks], const Tile& t) {
+    float v = 0.f;
+    bool live = t.valid;
+    if (t.valid) {
+      if (a.is_empty) live = (a.is_empty[t.s] == 0);
+      v = L::accumulate(w, t.s, lut);
+      if constexpr (RES) v += t.add;
+    }
+    refresh_tau();
+    const float tau_before = sel.tau;
+    const int flushes_before = sel.n_flush;
+    sel.push(live && (v >= sel.tau - delta2), v, t.s);
+    if (sel.n_flush != flushes_before) publish(tau_before);
+  };
+
+  // software pipeline: the codes of tile T+NW are in flight while tile T is being consumed
+  // (m <= 64; larger m runs 16 waves per workgroup under a 128-VGPR cap and relies on them)
+  if constexpr (M <= 64) {
+    typename L::chunk_t w0[L::kChunks], w1[L::kChunks];
+    Tile m0{0, false}, m1{0, false};
+    int T = t_begin + wave;
+    if (T < t_end) {
+      m0 = locate(T);
+      if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
+    }
+    while (T < t_end) {
+      int Tn = T + NW;
+      if (Tn < t_end) {
+        m1 = locate(Tn);
+        if (m1.valid) L::load(a.packed, a.n_slots, m1.s, w1);
+      }
+      consume(w0, m0);
+      T = Tn;
+      if (T >= t_end) break;
+      Tn = T + NW;
+      if (Tn < t_end) {
+        m0 = locate(Tn);
+        if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
+      }
+      consume(w1, m1);
+      T = Tn;
+    }
+  } else {
+    typename L::chunk_t w0[L::kChunks];
+    for (int T = t_begin + wave; T < t_end; T += NW) {
+      const Tile m0 = locate(T);
+      if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
+      consume(w0, m0);
+    }
+  }
+  {
+    const float tau_before = sel.tau;
+    sel.flush();
+    publish(tau_before);
+  }
+
+  // End of query, per wave and without any barrier: re-evaluate the surviving candidates of
+  // this wave's list exactly (ascending j, LUT still in LDS), re-rank them by exact value and
+  // dump the list; scan_merge_refine_kernel (one wave per query) merges the 8 x n_split lists.
+  // Only entries that can still reach the top-k (f >= shared threshold - 2*delta) are touched:
+  // with the quantile-shared threshold that is ~k/8 per wave, i.e. one 16-lane pass.
+  {
+    // One barrier: every wave has folded its last queue in and published its r-th best, so the
+    // shared bound (b) is now computed from FRESH lists.  During the scan the lists lag (a wave
+    // admits only ~k*ln(N/k)/NW candidates in its whole life and folds them in 64 at a time), so
+    // the running threshold leaves ~100 entries per wave above it; the fresh bound leaves ~2k/NW.
+    __syncthreads();
+    float shared_tau;  // identical in every wave (the loop below must be workgroup-uniform)
+    {
+      float qmin = reinterpret_cast<volatile float*>(wave_q)[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) qmin = fminf(qmin, reinterpret_cast<volatile float*>(wave_q)[w]);
+      shared_tau = fmaxf(qmin, key2f(*reinterpret_cast<volatile unsigned*>(tau_key)));
+      sel.tau = fmaxf(sel.tau, shared_tau);
+    }
+    // Two counting rounds pull the bound up to (nearly) the exact k-th best fast value of the
+    // workgroup: invariant "at least k list entries are >= lo".  Round 0 tests the NW published
+    // quantiles themselves, round 1 NW keys evenly spaced inside the bracket round 0 leaves; every
+    // wave counts its own sorted registers (ballots), the NW x NW counts meet in the dead queue
+    // area, and each wave reduces them redundantly -- two barriers, no list ever leaves registers.
+    // Every candidate kept beyond the k-th costs an exact re-evaluation (M gathers; M cache lines
+    // of the part2 table in the residual kernel), so the tight cut pays for itself.
+    {
+      unsigned* cnt = reinterpret_cast<unsigned*>(qv_all);  // [2][NW][NW]
+      auto count_ge = [&](unsigned t) -> unsigned {
+        unsigned c = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) c += (unsigned)__popcll(__ballot(sel.top.k[r].hi >= t));
+        return c;
+      };
+      auto wave_max = [&](unsigned x) -> unsigned {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+          const unsigned o = (unsigned)__shfl_xor((int)x, d, 64);
+          x = o > x ? o : x;
+        }
+        return x;
+      };
+      unsigned lo = f2key(shared_tau), hi = 0xFFFFFFFFu;
+#pragma unroll 1
+      for (int round = 0; round < 2; ++round) {
+        unsigned my_t = 0;  // lane j < NW: threshold j of this round
+        if (round == 0) {
+          if (lane < NW) my_t = f2key(reinterpret_cast<volatile float*>(wave_q)[lane]);
+        } else {
+          const unsigned long long span = (unsigned long long)(hi - lo);
+          my_t = lo + (unsigned)((span * (unsigned)(lane + 1)) / (unsigned)(NW + 1));
+        }
+        unsigned mine = 0;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          const unsigned c = count_ge((unsigned)__builtin_amdgcn_readlane((int)my_t, j));
+          mine = (lane == j) ? c : mine;
+        }
+        unsigned* cr = cnt + round * NW * NW;
+        if (lane < NW) cr[wave * NW + lane] = mine;
+        __syncthreads();
+        unsigned total = 0;
+        if (lane < NW) {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) total += cr[w * NW + lane];
+        }
+        const bool in = lane < NW;
+        const bool ok = in && total >= (unsigned)a.k;
+        const unsigned best_ok = wave_max(ok ? my_t : 0u);           // largest threshold still >= k
+        const unsigned best_no = ~wave_max((in && !ok) ? ~my_t : 0u);  // smallest one below k
+        lo = best_ok > lo ? best_ok : lo;
+        hi = best_no < hi ? best_no : hi;
+        if (hi == 0xFFFFFFFFu || hi <= lo) break;  // wave-uniform: nothing left to bracket
+      }
+      sel.tau = fmaxf(sel.tau, key2f(lo));
+    }
+    const float cut = sel.tau - delta2;
+    constexpr int RR = refine_rows(M);
+    uint32_t* scratch = scratch_all + wave * RR * (M / 4 + 1);
+    WaveTopK<R> ex;
+    ex.init();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int idx = key_index(sel.top.k[r]);
+      const bool want = (idx != kPadIdx) && (key_value(sel.top.k[r]) >= cut);
+      const unsigned long long wmask = __ballot(want);
+      if (wmask == 0ull) break;  // sorted by fast value: nothing further down qualifies either
+      float e = -INFINITY;
+      float init = 0.f;
+      const float* p2 = ra.part2;
+      if constexpr (RES) {
+        // which probe does the candidate's slot belong to?  (first match in probe order; a slot
+        // covered by two probes -- a cell listed twice, non-adjacent -- is scanned twice by the
+        // reference with two different bases: leave such queries to the exact kernel)
+        int myp = -1, n_match = 0;
+        for (int pp = 0; pp < n_probe; ++pp) {
+          const bool hit = want && ((unsigned)(idx - tab.start[pp]) < (unsigned)tab.size[pp]);
+          myp = (hit && myp < 0) ? pp : myp;
+          n_match += hit ? 1 : 0;
+        }
+        if (n_match > 1) a.flags[q] = 1;
+        myp = myp < 0 ? 0 : myp;
+        init = pbase[myp];
+        p2 = ra.part2 + (int64_t)pcell[myp] * (M * 256);
+      }
+#pragma unroll 1
+      for (int pass = 0; pass < 64 / RR; ++pass) {
+        if (((wmask >> (RR * pass)) & ((1ull << RR) - 1ull)) == 0ull) continue;  // wave-uniform
+        const bool mine = want && ((lane / RR) == pass);
+        float ep;
+        if constexpr (RES)
+          ep = exact_from_packed<M>(a.packed, a.n_slots, idx, mine, scratch, lane % RR,
+                                    ResidualLut<M>{lut, p2}, init);
+        else
+          ep = exact_from_packed<M>(a.packed, a.n_slots, idx, mine, scratch, lane % RR,
+                                    LdsLut<M>{lut});
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        e = mine ? ep : e;
+      }
+      ex.insert_unsorted(want ? make_key(e, idx) : pad_key());
+    }
+    const int64_t o = (((int64_t)q * a.n_split + part) * NW + wave) * (R * 64);
+    store_list<R>(ex, a.ws_vals + o, a.ws_idx + o);
+    if (part == 0 && wave == 0 && lane == 0) a.ws_delta[q] = delta2;
+  }
+}
+
+// ---- split merge ---------------------------------------------------------------------------
+
+template <int R>
+__global__ __launch_bounds__(64) void scan_merge_kernel(ScanArgs a) {
+  const int q = blockIdx.x;
+  if (a.only_flagged && a.only_flagged[q] == 0) return;
+  WaveTopK<R> top;
+  top.init();
+  for (int part = 0; part < a.n_split; ++part) {
+    const int64_t o = ((int64_t)q * a.n_split + part) * (R * 64);
+    merge_list<R>(top, a.ws_vals + o, a.ws_idx + o);
+  }
+  write_final<R>(a, q, top);
+}
+
+// packed path, phase 2: merge the per-wave lists of a query (exact values) and write the result
+template <int R, int M, bool RES>
+__global__ __launch_bounds__(64) void scan_merge_refine_kernel(ScanArgs a) {
+  const int q = blockIdx.x;
+  const int lane = lane_id();
+  const int n_lists = a.n_split * packed_waves(M);  // a multiple of 8
+  WaveTopK<R> top;
+  top.init();
+  // Rank-major order (every list's best 64 first): once those are in, most later chunks fail the
+  // wave-uniform early-exit test.  Loads are issued 8 chunks at a time, a group ahead of the
+  // merges, so the wave is not serialised on one global-load latency per chunk.
+  const float* __restrict__ bv = a.ws_vals + (int64_t)q * n_lists * (R * 64);
+  const int* __restrict__ bi = a.ws_idx + (int64_t)q * n_lists * (R * 64);
+  const int n_groups = (n_lists / 8) * R;  // group g: rank chunk g / (n_lists/8), lists 8*(g % ..)
+  auto load_group = [&](int g, Key (&kk)[8]) {
+    const int r = g / (n_lists / 8), l0 = (g % (n_lists / 8)) * 8;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t o = (int64_t)(l0 + u) * (R * 64) + r * 64 + lane;
+      kk[u] = Key{reinterpret_cast<const unsigned*>(bv)[o], reinterpret_cast<const unsigned*>(bi)[o]};
+    }
+  };
+  Key k0[8], k1[8];
+  load_group(0, k0);
+  for (int g = 0; g < n_groups; g += 2) {
+    if (g + 1 < n_groups) load_group(g + 1, k1);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) top.insert_sorted(k0[u]);
+    if (g + 1 >= n_groups) break;
+    if (g + 2 < n_groups) load_group(g + 2, k0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) top.insert_sorted(k1[u]);
+  }
+  finalize_and_write<R, RES>(a, q, top, a.ws_delta[q]);
+}
+
+// ---- host side -----------------------------------------------------------------------------
+
+static int pow2_ceil(int r) {
+  int p = 1;
+  while (p < r) p <<= 1;
+  return p;
+}
+static int list_regs(int k) { return pow2_ceil((k + 63) / 64); }  // 1, 2, 4, 8, 16
+constexpr int kBandSlack = 8;  // spare list entries the packed path wants beyond k
+static int list_regs_packed(int k) { return pow2_ceil((k + kBandSlack + 63) / 64); }
+
+static size_t scan_lds_bytes_ref(int m, int R, int max_nprobe, int fused_floats) {
+  const int lut_bytes = m * 1024;
+  const int list_bytes = kScanWaves * R * 64 * 8;
+  const int region0 = lut_bytes > list_bytes ? lut_bytes : list_bytes;
+  size_t b = (size_t)region0 + kScanWaves * 512 + (size_t)(3 * max_nprobe + 1) * 4 + 4 +
+             (size_t)fused_floats * 4;
+  return (b + 15) & ~(size_t)15;
+}
+static size_t scan_lds_bytes_packed(int m, int R, int max_nprobe, int fused_floats, bool res) {
+  const int nw = packed_waves(m);
+  size_t b = (size_t)m * 1024 + packed_aux_bytes(R, m) + nw * 512 +
+             (size_t)(3 * max_nprobe + 1) * 4 + 4 + 3 * nw * 4 + (res ? 8 * (size_t)max_nprobe : 0) +
+             (size_t)fused_floats * 4;
+  return (b + 15) & ~(size_t)15;
+}
+static int fused_floats_of(const ScanArgs& a) { return a.lut ? 0 : a.m * a.ds + a.m; }
+
+// per-M translation units (scan_packed.hip compiled with -DTPQ_PACKED_M=<M>)
+int dispatch_packed_8(const ScanArgs& a, const ResidualArgs* ra, int R, hipStream_t st);
+int dispatch_packed_16(const ScanArgs& a, const ResidualArgs* ra, int R, hipStream_t st);
+int dispatch_packed_32(const ScanArgs& a, const ResidualArgs* ra, int R, hipStream_t st);
+int dispatch_packed_64(const ScanArgs& a, const ResidualArgs* ra, int R, hipStream_t st);
+int dispatch_packed_120(const ScanArgs& a, const ResidualArgs* ra, int R, hipStream_t st);
+
+template <class K>
+static int set_lds(K kernel, size_t bytes, const char* name) {
+  if (bytes > 160 * 1024) {
+    set_error("%s: needs %zu bytes of LDS (> 160 KiB per CU on gfx950)", name, bytes);
+    return TPQ_ERR_UNSUPPORTED;
+  }
+  return check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes),
+                   name);
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// workspace: [flags nq*4][delta nq*4][lists nq*n_lists*64R*8]; n_lists = n_split (reference
+// kernel, only when n_split > 1) or n_split * waves-per-workgroup (packed kernel, always)
+static size_t ws_bytes_for(int nq, int R, int n_lists) {
+  return 2 * align256((size_t)nq * 4) + (size_t)nq * n_lists * R * 64 * 8;
+}
+
+static void fill_ws(ScanArgs& a, void* workspace, int R, int n_lists) {
+  char* p = reinterpret_cast<char*>(workspace);
+  a.flags = reinterpret_cast<int*>(p);
+  a.ws_delta = reinterpret_cast<float*>(p + align256((size_t)a.nq * 4));
+  char* lists = p + 2 * align256((size_t)a.nq * 4);
+  a.ws_vals = reinterpret_cast<float*>(lists);
+  a.ws_idx = reinterpret_cast<int*>(lists + (size_t)a.nq * n_lists * R * 64 * 4);
+}
+
+static int validate(const ScanArgs& a) {
+  TPQ_REQUIRE(a.codes && (a.lut || (a.query && a.codebook)) && a.cell_start && a.cell_size &&
+                  a.n_probe_list && a.out_vals && a.out_addr,
+              "ivfpq_scan: null pointer argument");
+  TPQ_REQUIRE(a.lut || a.ds >= 1, "ivfpq_scan: bad sub-vector length %d", a.ds);
+  TPQ_REQUIRE(a.nq >= 0 && a.max_nprobe >= 1, "ivfpq_scan: bad nq/max_nprobe (%d, %d)", a.nq,
+              a.max_nprobe);
+  TPQ_REQUIRE(a.m >= 4 && a.m % 4 == 0, "ivfpq_scan: n_subvectors=%d must be a positive multiple of 4", a.m);
+  TPQ_REQUIRE(a.k >= 1 && a.k <= 1024, "ivfpq_scan: k=%d out of range (0, 1024]", a.k);
+  TPQ_REQUIRE(a.n_slots >= 0 && a.n_slots < 0x7fffffffLL, "ivfpq_scan: n_slots=%lld out of range",
+              (long long)a.n_slots);
+  TPQ_REQUIRE(a.n_split >= 1 && a.n_split <= 1024, "ivfpq_scan: n_split=%d out of range", a.n_split);
+  TPQ_REQUIRE((a.out_ids == nullptr) || (a.address2id != nullptr),
+              "ivfpq_scan: out_ids given without address2id");
+  return TPQ_OK;
+}
+
+static int need_ws(const void* ws, size_t have, size_t need, const char* who) {
+  if (need && (!ws || have < need)) {
+    set_error("%s: workspace too small (%zu < %zu)", who, have, need);
+    return TPQ_ERR_WORKSPACE;
+  }
+  return TPQ_OK;
+}
+
+}  // namespace tpq

@@ -1,0 +1,47 @@
+// Scan-layout list scan: one translation unit per sub-quantizer count, compiled with
+// -DTPQ_PACKED_M=<M> (build.sh) so the 5 x 2 x 5 kernel instantiations build in parallel.
+// Device code: scan_device.h; C ABI: scan.hip.
+#include "scan_device.h"
+
+#ifndef TPQ_PACKED_M
+#error "compile with -DTPQ_PACKED_M=<n_subvectors>"
+#endif
+
+namespace tpq {
+
+template <int R, int M, bool RES>
+static int launch_packed(ScanArgs a, ResidualArgs ra, hipStream_t st) {
+  const size_t lds = scan_lds_bytes_packed(M, R, a.max_nprobe, fused_floats_of(a), RES);
+  int rc = set_lds(scan_packed_kernel<R, M, RES>, lds, "scan_packed_kernel");
+  if (rc) return rc;
+  // delta = 1.05 * 2 (M-1) u * sum_j max|LUT_j|,  u = 2^-24   (residual: M+1 roundings, see kernel)
+  const float delta_rel = 1.05f * 2.0f * 5.9604645e-8f * (float)(RES ? M + 1 : M - 1);
+  hipLaunchKernelGGL((scan_packed_kernel<R, M, RES>), dim3((unsigned)a.nq * a.n_split),
+                     dim3(packed_waves(M) * 64), lds, st, a, ra, delta_rel);
+  TPQ_LAUNCH_CHECK("scan_packed_kernel");
+  hipLaunchKernelGGL((scan_merge_refine_kernel<R, M, RES>), dim3(a.nq), dim3(64), 0, st, a);
+  TPQ_LAUNCH_CHECK("scan_merge_refine_kernel");
+  return TPQ_OK;
+}
+
+template <int M, bool RES>
+static int dispatch_r(const ScanArgs& a, const ResidualArgs& ra, int R, hipStream_t st) {
+  switch (R) {
+    case 1: return launch_packed<1, M, RES>(a, ra, st);
+    case 2: return launch_packed<2, M, RES>(a, ra, st);
+    case 4: return launch_packed<4, M, RES>(a, ra, st);
+    case 8: return launch_packed<8, M, RES>(a, ra, st);
+    default: return launch_packed<16, M, RES>(a, ra, st);
+  }
+}
+
+#define TPQ_CAT2(a, b) a##b
+#define TPQ_CAT(a, b) TPQ_CAT2(a, b)
+
+int TPQ_CAT(dispatch_packed_, TPQ_PACKED_M)(const ScanArgs& a, const ResidualArgs* ra, int R,
+                                            hipStream_t st) {
+  if (ra) return dispatch_r<TPQ_PACKED_M, true>(a, *ra, R, st);
+  return dispatch_r<TPQ_PACKED_M, false>(a, ResidualArgs{}, R, st);
+}
+
+}  // namespace tpq

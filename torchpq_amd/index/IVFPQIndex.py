@@ -41,6 +41,8 @@ class IVFPQIndex(CellContainer):
         self._use_precomputed = bool(pq_use_residual and
                                      (n_cells * 256 * n_subvectors * 4) <= 4 * 1024 ** 3)
         self._precomputed_part2 = None
+        self._part2_by_cell = None       # [n_cells, m, 256] contiguous copy for the scan kernels
+        self._slot_terms = None          # (codes version, slot_term [capacity], cell_bound [n_cells])
         self._use_cublas = True
         self._use_smart_probing = True
         self._smart_probing_temperature = 30.0
@@ -123,8 +125,13 @@ class IVFPQIndex(CellContainer):
             assert (self.pq_codec.is_trained and self.vq_codec.is_trained), "index is not trained"
             self.precompute_part2()
         else:
-            self._precomputed_part2 = None
+            self._drop_part2()
         self._use_precomputed = value
+
+    def _drop_part2(self):
+        self._precomputed_part2 = None
+        self._part2_by_cell = None
+        self._slot_terms = None
 
     def precompute_part2(self):
         """[m, n_cells, 256]: -2 c_j . r_jc - |r_jc|^2 (reference :160-170; one-off library bmm)"""
@@ -132,6 +139,17 @@ class IVFPQIndex(CellContainer):
         vq_codebook = self.vq_codec.codebook.reshape(self.n_subvectors, self.d_subvector, self.n_cells)
         self._precomputed_part2 = (torch.bmm(vq_codebook.transpose(-1, -2), pq_codebook) * -2
                                    - pq_codebook.norm(dim=1).pow(2)[:, None])
+        self._part2_by_cell = self._precomputed_part2.transpose(0, 1).contiguous()
+        self._slot_terms = None
+
+    def _residual_slot_terms(self):
+        """(slot_term, cell_bound) of the packed residual scan, rebuilt when the codes changed"""
+        if self._slot_terms is None or self._slot_terms[0] != self._codes_version:
+            from ..kernels import ResidualSlotTermsHip
+            st, cb = ResidualSlotTermsHip()(self._storage, self._part2_by_cell, self._cell_start,
+                                            self._cell_size)
+            self._slot_terms = (self._codes_version, st, cb)
+        return self._slot_terms[1], self._slot_terms[2]
 
     def _codec_knob(codec, attr, typed):
         def getter(self):
@@ -155,7 +173,7 @@ class IVFPQIndex(CellContainer):
 
     def _after_load_state_dict(self):
         self.to(self.device)
-        self._precomputed_part2 = None
+        self._drop_part2()
         super()._after_load_state_dict()
 
     # ---- train / encode / add (reference :234-364) ------------------------------------------------
@@ -177,7 +195,7 @@ class IVFPQIndex(CellContainer):
             # PQ is learnt on x - centroid(x); the caller's tensor is left untouched (the reference
             # subtracts and re-adds in place, :246-254)
             self.pq_codec.train((x - self.vq_codec.decode(code)).contiguous())
-            self._precomputed_part2 = None
+            self._drop_part2()
         else:
             self.pq_codec.train(x)
         self.print_message("index is trained successfully!", 1)
@@ -235,7 +253,7 @@ class IVFPQIndex(CellContainer):
         part1 = ResidualPart1Hip()(x, self.pq_codec.codebook)
         if self._precomputed_part2 is None:
             self.precompute_part2()
-        return part1, self._precomputed_part2.transpose(0, 1)
+        return part1, self._part2_by_cell
 
     def precomputed_adc_residual(self, x, cells):
         """[n_query, n_probe, m, 256]: one LUT per (query, probe); memory-hungry, used only when
@@ -260,7 +278,24 @@ class IVFPQIndex(CellContainer):
         if self.pq_use_residual:
             assert base_sims is not None, "base_sims is required when pq_use_residual is True"
             is_empty = self._is_empty if self._has_holes else None
-            if self.use_precomputed:
+            from ..kernels import PACKED_M
+            if self.use_precomputed and self.use_packed_layout and self.n_subvectors in PACKED_M:
+                # scan layout: part1[q] staged once per query (built in the workgroup while the
+                # sub-vectors are short), the cell-dependent half folded into a per-slot constant
+                if self._precomputed_part2 is None:
+                    self.precompute_part2()
+                slot_term, cell_bound = self._residual_slot_terms()
+                fused = self.use_fused_lut and self.d_subvector <= 4
+                part1 = None if fused else self.precomputed_adc_residual_precomputed(x)[0]
+                topk_val, topk_address, topk_ids = self._ivfpq_topk._scan.topk_residual_packed(
+                    data=self._storage, packed=self.packed_storage(), part2=self._part2_by_cell,
+                    slot_term=slot_term, cell_bound=cell_bound, cells=cells, base_sims=base_sims,
+                    is_empty=is_empty, cell_start=cell_start, cell_size=cell_size,
+                    n_probe_list=n_probe_list, n_candidates=k, part1=part1,
+                    query=x if fused else None,
+                    codebook=self.pq_codec.codebook if fused else None,
+                    address2id=self._address2id)
+            elif self.use_precomputed:
                 part1, part2 = self.precomputed_adc_residual_precomputed(x)
                 topk_val, topk_address, topk_ids = self._ivfpq_topk.topk_residual_precomputed(
                     data=self._storage, part1=part1, part2=part2, cells=cells, base_sims=base_sims,

@@ -13,7 +13,7 @@ from .. import _lib
 from .._lib import check, load, ptr, require_gpu, stream_ptr
 
 __all__ = [
-    "IVFPQTopkHip", "IVFPQTop1Hip", "ResidualPart1Hip", "AdcLutHip", "TopkSelectHip", "CoarseSelectHip", "Top1SelectHip",
+    "IVFPQTopkHip", "IVFPQTop1Hip", "ResidualPart1Hip", "ResidualSlotTermsHip", "AdcLutHip", "TopkSelectHip", "CoarseSelectHip", "Top1SelectHip",
     "Top32SelectHip", "SmartProbingHip", "MaxSimHip", "ComputeCentroidsHip", "GetIOAHip",
     "GetWriteAddressHip", "GetCellByAddressHip", "GetIdByAddressHip", "PQDecodeHip",
     "ScatterCodesHip", "PackCodesHip", "packed_chunk_width", "PACKED_M",
@@ -210,6 +210,69 @@ class IVFPQTopkHip:
                     stream_ptr(device)), "tpq_ivfpq_scan_topk_residual")
         return (values, address) if ids is None else (values, address, ids)
 
+    def topk_residual_packed(self, data, packed, part2, slot_term, cell_bound, cells, base_sims,
+                             is_empty, cell_start, cell_size, n_probe_list, n_candidates,
+                             part1=None, query=None, codebook=None, address2id=None, n_split=None):
+        """Residual scan on the scan layout (tpq_ivfpq_scan_topk_residual_packed): results equal
+        topk_residual_precomputed bit for bit.  part1 [n_query, m, 256] or (query [d, n_query],
+        codebook [m, ds, 256]) from which the workgroup builds it; part2 [n_cells, m, 256]
+        contiguous; slot_term / cell_bound from ResidualSlotTermsHip."""
+        n_data = data.shape[1]
+        n_query, n_probe = cell_start.shape
+        assert self.m in PACKED_M and packed is not None
+        assert data.shape == (self.m // self.n_cs, n_data, self.n_cs) and data.dtype == torch.uint8
+        assert part2.shape[1:] == (self.m, self.k) and part2.dtype == torch.float32
+        assert part2.is_contiguous()
+        assert slot_term.shape == (n_data,) and slot_term.dtype == torch.float32
+        assert cell_bound.shape == (part2.shape[0],) and cell_bound.dtype == torch.float32
+        assert cells.shape == cell_start.shape == cell_size.shape == base_sims.shape
+        assert cells.dtype == cell_start.dtype == cell_size.dtype == torch.int64
+        assert base_sims.dtype == torch.float32
+        assert n_probe_list.shape == (n_query,) and n_probe_list.dtype == torch.int64
+        assert 0 < n_candidates <= 1024
+        ds = 0
+        if part1 is not None:
+            assert part1.shape == (n_query, self.m, self.k) and part1.dtype == torch.float32
+            part1 = part1.contiguous()
+        else:
+            assert query is not None and codebook is not None
+            ds = codebook.shape[1]
+            assert codebook.shape == (self.m, ds, self.k) and query.shape == (self.m * ds, n_query)
+            assert query.dtype == codebook.dtype == torch.float32
+            query = query.contiguous()
+            codebook = codebook.contiguous()
+        cells = cells.contiguous()
+        base_sims = base_sims.contiguous()
+        require_gpu(data, packed, part1, query, codebook, part2, slot_term, cell_bound, cells,
+                    base_sims, is_empty, cell_start, cell_size, n_probe_list, address2id)
+        device = data.device
+        k = n_candidates
+        values = torch.empty(n_query, k, device=device, dtype=torch.float32)
+        address = torch.empty(n_query, k, device=device, dtype=torch.int64)
+        ids = torch.empty(n_query, k, device=device, dtype=torch.int64) if address2id is not None else None
+        if n_query == 0:
+            return (values, address) if ids is None else (values, address, ids)
+        lib = load()
+        if n_split is None:
+            n_split = self._n_split(n_query, device)
+        ws_bytes = lib.tpq_ivfpq_scan_workspace_bytes(n_query, k, n_split, self.m)
+        ws = torch.empty(max(ws_bytes, 1), device=device, dtype=torch.uint8)
+        ev = None
+        if self.record_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(torch.cuda.current_stream(device))
+        with torch.cuda.device(device):
+            check(lib.tpq_ivfpq_scan_topk_residual_packed(
+                ptr(packed), ptr(data), ptr(part1), ptr(query), ptr(codebook), ds, ptr(part2),
+                ptr(slot_term), ptr(cell_bound), ptr(cells), ptr(base_sims), ptr(is_empty),
+                ptr(cell_start), ptr(cell_size), ptr(n_probe_list), ptr(values), ptr(address),
+                ptr(address2id), ptr(ids), n_data, n_query, n_probe, self.m, k, n_split, ptr(ws),
+                ws_bytes, stream_ptr(device)), "tpq_ivfpq_scan_topk_residual_packed")
+        if ev is not None:
+            ev[1].record(torch.cuda.current_stream(device))
+            self.record_events.append(ev)
+        return (values, address) if ids is None else (values, address, ids)
+
     def topk_residual(self, data, precomputed, base_sims, is_empty, cell_start, cell_size,
                       n_probe_list, n_candidates=None, address2id=None):
         """precomputed: [n_query, max_n_probe, m, 256] f32 -- one LUT per (query, probe)
@@ -230,6 +293,28 @@ class IVFPQTopkHip:
         assert cells.shape == cell_start.shape and cells.dtype == torch.int64
         return self._residual(data, part1, part2, None, cells, base_sims, is_empty, cell_start,
                               cell_size, n_probe_list, n_candidates, address2id)
+
+
+class ResidualSlotTermsHip:
+    """Per-slot / per-cell constants of the packed residual scan (tpq_ivfpq_residual_slot_terms):
+    slot_term [n_data] f32 = sum_j part2[cell(s), j, code_j(s)], cell_bound [n_cells] f32."""
+
+    def __call__(self, data, part2, cell_start, cell_size):
+        n_cells, m, kk = part2.shape
+        n_data = data.shape[1]
+        assert kk == 256 and data.shape == (m // 4, n_data, 4) and data.dtype == torch.uint8
+        assert part2.dtype == torch.float32 and part2.is_contiguous()
+        assert cell_start.shape == cell_size.shape == (n_cells,)
+        assert cell_start.dtype == cell_size.dtype == torch.int64
+        require_gpu(data, part2, cell_start, cell_size)
+        slot_term = torch.empty(n_data, device=data.device, dtype=torch.float32)
+        cell_bound = torch.empty(n_cells, device=data.device, dtype=torch.float32)
+        with torch.cuda.device(data.device):
+            check(load().tpq_ivfpq_residual_slot_terms(
+                ptr(data), ptr(part2), ptr(cell_start), ptr(cell_size), ptr(slot_term),
+                ptr(cell_bound), n_data, n_cells, m, stream_ptr(data.device)),
+                "tpq_ivfpq_residual_slot_terms")
+        return slot_term, cell_bound
 
 
 class ResidualPart1Hip:
