@@ -140,7 +140,7 @@ int tpq_residual_part1(const float* query, const float* codebook, float* part1, 
  * (derived from CellContainer._storage + part2; recompute after add/remove/expand).
  * Survivors are re-evaluated exactly (base_sims + fl(part1 + part2) ascending j); queries whose
  * candidate band overflows, or that list a cell twice, are redone by the exact kernel.
- * workspace: tpq_ivfpq_scan_workspace_bytes(nq, k, n_split, m).  m in {8,16,32,64,120}. */
+ * workspace: tpq_ivfpq_scan_workspace_bytes(nq, k, n_split, m).  m: any value of TPQ_PACKED_M_LIST. */
 int tpq_ivfpq_residual_slot_terms(const uint8_t* codes, const float* part2,
                                   const int64_t* cell_start, const int64_t* cell_size,
                                   float* slot_term, float* cell_bound, int64_t n_slots,

@@ -12,6 +12,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _scan_layout_at_every_m(monkeypatch):
+    """the index tests use small m: keep the scan layout (and its incremental scatter) exercised"""
+    from torchpq_amd.index import IVFPQIndex
+    monkeypatch.setattr(IVFPQIndex, "packed_min_subvectors", 0)
+
+
 def T(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 

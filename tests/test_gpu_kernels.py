@@ -96,8 +96,19 @@ def _random_index(rng, m, n_cells, mean_size, n_tomb=0, dup_frac=0.0):
     (64, 1024, 24, 1, "packed", 0, 0.0),
     (120, 100, 10, 1, "packed", 0, 0.0),
     (120, 33, 10, 3, "ref", 9, 0.0),
-    (24, 7, 5, 1, "ref", 0, 0.0),      # m without a packed kernel: reference-layout path
+    (36, 7, 5, 1, "packed", 0, 0.0),   # m without a scan-layout kernel: reference-layout path
     (12, 300, 9, 2, "ref", 0, 0.1),
+    (4, 10, 6, 1, "packed", 5, 0.0),
+    (12, 300, 9, 2, "packed", 0, 0.1),
+    (20, 50, 7, 1, "packed", 0, 0.0),
+    (24, 7, 5, 3, "packed", 0, 0.2),
+    (28, 100, 8, 1, "packed", 11, 0.0),
+    (40, 64, 8, 2, "packed", 0, 0.0),
+    (48, 130, 11, 1, "packed", 0, 0.05),
+    (56, 10, 6, 1, "packed", 0, 0.0),
+    (96, 100, 10, 2, "packed", 7, 0.0),
+    (128, 100, 10, 1, "packed", 0, 0.0),
+    (128, 500, 10, 3, "packed", 0, 0.3),
 ])
 def test_scan_random_vs_oracle(K, m, k, n_probe, n_split, layout, tomb, dup):
     rng = np.random.default_rng(hash((m, k, n_probe, n_split)) % 2**32)
@@ -123,6 +134,23 @@ def test_scan_random_vs_oracle(K, m, k, n_probe, n_split, layout, tomb, dup):
         v2, a2 = scan.topk(st, T(lut), None, T(cs), T(sz), T(npl), n_candidates=k, packed=packed,
                            n_split=n_split)
         assert np.array_equal(N(v2), ev) and np.array_equal(N(a2), ea)
+
+
+def test_scan_packed_falls_back_when_lds_is_short(K):
+    """m=128 with a 700-entry probe table does not fit 160 KiB next to the 128-KiB LUT: the packed
+    entry point must still answer (reference-layout kernel), bit-exactly."""
+    rng = np.random.default_rng(77)
+    m, n_cells, nq, n_probe, k = 128, 800, 5, 700, 40
+    storage, is_empty, start, sizes, a2i = _random_index(rng, m, n_cells, 6)
+    lut = (rng.standard_normal((m, nq, 256)) * 100).astype(np.float32)
+    cells = np.stack([rng.permutation(n_cells)[:n_probe] for _ in range(nq)])
+    npl = np.full(nq, n_probe, np.int64)
+    cs, sz = start[cells], sizes[cells]
+    ev, ea = c_oracle.scan_topk(storage, lut, is_empty, cs, sz, npl, k)
+    st = T(storage)
+    v, a = K.IVFPQTopkHip(m=m).topk(st, T(lut), T(is_empty), T(cs), T(sz), T(npl), n_candidates=k,
+                                    packed=K.PackCodesHip()(st), n_split=2)
+    assert np.array_equal(N(v), ev) and np.array_equal(N(a), ea)
 
 
 def test_scan_empty_and_degenerate(K):

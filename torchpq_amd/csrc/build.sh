@@ -16,7 +16,7 @@ stale() {  # object older than its source or any shared header?
      || "$obj" -ot "${HERE}/../../include/torchpq_amd.h" || "${FORCE:-0}" == "1" ]]
 }
 # the scan-layout kernels: one translation unit per sub-quantizer count
-for m in 8 16 32 64 120; do
+for m in 4 8 12 16 20 24 28 32 40 48 56 64 96 120 128; do  # = TPQ_PACKED_M_LIST (scan_device.h)
   obj="${HERE}/build/scan_packed_${m}.o"
   if stale "$obj" "${HERE}/scan_packed.hip"; then
     ( "$HIPCC" "${FLAGS[@]}" -DTPQ_PACKED_M=${m} -x hip -c "${HERE}/scan_packed.hip" -o "$obj" ${EXTRA_FLAGS:-} ) &

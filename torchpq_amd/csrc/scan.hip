@@ -85,6 +85,12 @@ extern "C" size_t tpq_ivfpq_scan_workspace_bytes(int nq, int k, int n_split, int
 static int run_ref(ScanArgs a, void* workspace, size_t workspace_bytes, tpq_stream_t stream);
 static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_t workspace_bytes,
                       tpq_stream_t stream);
+static bool has_packed_kernel(int m) {
+#define TPQ_IS_M(M) if (m == M) return true;
+  TPQ_PACKED_M_LIST(TPQ_IS_M)
+#undef TPQ_IS_M
+  return false;
+}
 static int run_residual_ref(ScanArgs a, ResidualArgs ra, hipStream_t st);
 
 extern "C" int tpq_ivfpq_search_fused(const uint8_t* packed, const uint8_t* codes,
@@ -102,8 +108,7 @@ extern "C" int tpq_ivfpq_search_fused(const uint8_t* packed, const uint8_t* code
   ScanArgs a{codes, packed, nullptr, query, codebook, ds, metric == TPQ_METRIC_NEG_SQ_L2 ? 1 : 0,
              is_empty, cell_start, cell_size, n_probe_list, out_vals, out_addr, address2id, out_ids,
              nullptr, nullptr, nullptr, nullptr, nullptr, n_slots, nq, max_nprobe, m, k, n_split};
-  bool has_packed_kernel = (m == 8 || m == 16 || m == 32 || m == 64 || m == 120);
-  if (packed && has_packed_kernel) return run_packed(a, nullptr, workspace, workspace_bytes, stream);
+  if (packed && has_packed_kernel(m)) return run_packed(a, nullptr, workspace, workspace_bytes, stream);
   return run_ref(a, workspace, workspace_bytes, stream);
 }
 
@@ -156,7 +161,17 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
   const int nq = a.nq, k = a.k, n_split = a.n_split, m = a.m;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int R = list_regs_packed(k);
-  if (R > 16) {  // k within kBandSlack of 1024: no room for the candidate band, scan exactly
+  if (!has_packed_kernel(m)) {
+    set_error("ivfpq_scan_packed: no scan-layout kernel instantiated for n_subvectors=%d; use "
+              "tpq_ivfpq_scan_topk", m);
+    return TPQ_ERR_UNSUPPORTED;
+  }
+  // k within kBandSlack of 1024 (no room for the candidate band), or a probe table that no longer
+  // fits next to the LUT: scan exactly with the reference-layout kernel
+  const bool lds_fits =
+      scan_lds_bytes_packed(m, R > 16 ? 16 : R, a.max_nprobe, fused_floats_of(a), ra != nullptr) <=
+      160 * 1024;
+  if (R > 16 || !lds_fits) {
     if (ra) {
       a.n_split = 1;
       return run_residual_ref(a, *ra, st);
@@ -178,15 +193,10 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
     if (rc) return rc;
   }
   switch (m) {
-    case 8: rc = dispatch_packed_8(a, ra, R, st); break;
-    case 16: rc = dispatch_packed_16(a, ra, R, st); break;
-    case 32: rc = dispatch_packed_32(a, ra, R, st); break;
-    case 64: rc = dispatch_packed_64(a, ra, R, st); break;
-    case 120: rc = dispatch_packed_120(a, ra, R, st); break;
-    default:
-      set_error("ivfpq_scan_packed: no packed kernel instantiated for n_subvectors=%d "
-                "(available: 8, 16, 32, 64, 120); use tpq_ivfpq_scan_topk", m);
-      return TPQ_ERR_UNSUPPORTED;
+#define TPQ_CASE_M(M) case M: rc = dispatch_packed_##M(a, ra, R, st); break;
+    TPQ_PACKED_M_LIST(TPQ_CASE_M)
+#undef TPQ_CASE_M
+    default: rc = TPQ_ERR_UNSUPPORTED; break;
   }
   if (rc) return rc;
   // exact redo of the (normally zero) queries whose candidate band overflowed

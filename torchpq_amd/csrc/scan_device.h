@@ -904,11 +904,13 @@ static size_t scan_lds_bytes_packed(int m, int R, int max_nprobe, int fused_floa
 static int fused_floats_of(const ScanArgs& a) { return a.lut ? 0 : a.m * a.ds + a.m; }
 
 // per-M translation units (scan_packed.hip compiled with -DTPQ_PACKED_M=<M>)
-int dispatch_packed_8(const ScanArgs& a, const ResidualArgs* ra, int R, hipStream_t st);
-int dispatch_packed_16(const ScanArgs& a, const ResidualArgs* ra, int R, hipStream_t st);
-int dispatch_packed_32(const ScanArgs& a, const ResidualArgs* ra, int R, hipStream_t st);
-int dispatch_packed_64(const ScanArgs& a, const ResidualArgs* ra, int R, hipStream_t st);
-int dispatch_packed_120(const ScanArgs& a, const ResidualArgs* ra, int R, hipStream_t st);
+// (keep the list in sync with build.sh and torchpq_amd/kernels PACKED_M)
+#define TPQ_PACKED_M_LIST(X) \
+  X(4) X(8) X(12) X(16) X(20) X(24) X(28) X(32) X(40) X(48) X(56) X(64) X(96) X(120) X(128)
+#define TPQ_DECLARE_PACKED(M) \
+  int dispatch_packed_##M(const ScanArgs& a, const ResidualArgs* ra, int R, hipStream_t st);
+TPQ_PACKED_M_LIST(TPQ_DECLARE_PACKED)
+#undef TPQ_DECLARE_PACKED
 
 template <class K>
 static int set_lds(K kernel, size_t bytes, const char* name) {

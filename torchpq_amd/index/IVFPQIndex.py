@@ -16,6 +16,11 @@ from ..kernels import CoarseSelectHip, SmartProbingHip
 
 
 class IVFPQIndex(CellContainer):
+    # plain (non-residual) search: below this many sub-quantizers the two code layouts scan within
+    # +-7 % of each other (the per-tile selection work dominates, not the LDS look-ups), so the
+    # second copy of the codes is not kept; the residual scan uses the scan layout at every m
+    packed_min_subvectors = 56
+
     def __init__(self, d_vector, n_subvectors=8, n_cells=128, initial_size=None,
                  expand_step_size=128, expand_mode="double", distance="euclidean",
                  device="cuda:0", pq_use_residual=False, verbose=0):
@@ -313,7 +318,7 @@ class IVFPQIndex(CellContainer):
         packed = None
         if self.use_packed_layout:
             from ..kernels import PACKED_M
-            if self.n_subvectors in PACKED_M:
+            if self.n_subvectors in PACKED_M and self.n_subvectors >= self.packed_min_subvectors:
                 packed = self.packed_storage()
         # the fused path re-reads the codebook (m*ds KiB, L2-resident) per workgroup instead of a
         # 1-KiB-per-sub-quantizer LUT row from HBM: a win while the sub-vectors are short

@@ -19,7 +19,8 @@ __all__ = [
     "ScatterCodesHip", "PackCodesHip", "packed_chunk_width", "PACKED_M",
 ]
 
-PACKED_M = (8, 16, 32, 64, 120)  # n_subvectors with an instantiated packed-layout scan kernel
+# n_subvectors with an instantiated scan-layout kernel (= TPQ_PACKED_M_LIST in csrc/scan_device.h)
+PACKED_M = (4, 8, 12, 16, 20, 24, 28, 32, 40, 48, 56, 64, 96, 120, 128)
 
 
 def packed_chunk_width(m):
