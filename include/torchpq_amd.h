@@ -184,6 +184,23 @@ int tpq_topk_select(const float* x, float* vals, int64_t* idx, int rows, int col
 int tpq_coarse_select(const float* dots, const float* a2, const float* b2, float* vals, int64_t* idx,
                       int rows, int cols, int k, tpq_stream_t stream);
 
+/* a-4 + a-5 + the list-extent gathers in one call: the whole coarse step of IVFPQIndex.search
+ * (torchpq/index/IVFPQIndex.py:486-512 and :425-426) as two launches -- an fp32-MFMA kernel that
+ * writes sims = 2 x^T C - |x|^2 - |C|^2 (replaces the cuBLAS GEMM + 3 element-wise passes of
+ * metric.negative_squared_l2_distance, torchpq/metric.py:31-98) into `workspace`, and the row
+ * select whose epilogue also gathers cell_start/cell_size of the chosen cells and derives
+ * n_probe_list (smart probing when smart_temperature > 0, else n_probe for every query).
+ * query f32 [d][nq], centroids f32 [d][n_cells], cell_*_tbl i64 [n_cells]
+ * -> topk_sims f32 [nq][n_probe] (descending), cells / cell_start / cell_size i64 [nq][n_probe],
+ *    n_probe_list i64 [nq].   1 <= n_probe <= min(n_cells, 1024). */
+size_t tpq_ivfpq_coarse_probe_workspace_bytes(int nq, int n_cells);
+int tpq_ivfpq_coarse_probe(const float* query, const float* centroids,
+                           const int64_t* cell_start_tbl, const int64_t* cell_size_tbl,
+                           float* topk_sims, int64_t* cells, int64_t* cell_start,
+                           int64_t* cell_size, int64_t* n_probe_list, int d, int nq, int n_cells,
+                           int n_probe, float smart_temperature, void* workspace,
+                           size_t workspace_bytes, tpq_stream_t stream);
+
 /* a-5  smart probing          torchpq/index/IVFPQIndex.py:499-512
  * topk_sims f32 [rows][n_probe] -> n_probe_list i64 [rows] in [0, n_probe]
  * p = softmax(-sqrt(|s|)/T); H = -sum(p*log2(p)/log2(n_probe)); out = ceil(H*n_probe) */

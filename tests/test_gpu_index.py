@@ -309,6 +309,30 @@ def test_residual_index_end_to_end(use_precomputed):
         assert torch.equal(va, vb) and torch.equal(ia, ib) and torch.equal(va, vc) and torch.equal(ia, ic)
 
 
+@pytest.mark.parametrize("residual", [False, True])
+def test_graphed_search_replays_search(residual):
+    """search() is sync-free and captures into one HIP graph; replays equal eager calls."""
+    from torchpq_amd.index import IVFPQIndex
+    rng = np.random.default_rng(12)
+    d, n, nq, k = 32, 4000, 9, 10
+    base = rng.standard_normal((d, n)).astype(np.float32)
+    np.random.seed(12)
+    idx = IVFPQIndex(d_vector=d, n_subvectors=8, n_cells=16, initial_size=512, device=DEV,
+                     pq_use_residual=residual)
+    idx.train(T(base))
+    idx.add(T(base))
+    idx.n_probe = 5
+    g = idx.graphed_search(nq, k=k)
+    for seed in (1, 2, 3):
+        q = T(np.random.default_rng(seed).standard_normal((d, nq)).astype(np.float32))
+        v, i = g(q)
+        ev, ei = idx.search(q, k=k)
+        assert torch.equal(v, ev) and torch.equal(i, ei)
+    idx.add(T(base[:, :10] + 1), ids=torch.arange(n, n + 10, device=DEV))
+    with pytest.raises(AssertionError):
+        g(q)
+
+
 def test_flat_index_exact_search():
     """FlatIndex: exact neighbours, ids, removal; doubles as recall ground truth."""
     from torchpq_amd.index import FlatIndex, IVFPQIndex

@@ -503,3 +503,34 @@ def test_coarse_select_equals_metric_then_select(K):
         assert torch.equal(v0, v1) and torch.equal(i0, i1)
         ev, ei = orc.topk_desc(N(sims), k)
         assert np.array_equal(N(v1), ev) and np.array_equal(N(i1), ei)
+
+
+@pytest.mark.parametrize("d,nq,n_cells,n_probe,smart", [(128, 777, 1024, 32, True), (32, 5, 16, 16, False),
+                                                       (960, 70, 300, 64, True), (7, 1, 40, 1, True),
+                                                       (128, 130, 2000, 200, True)])
+def test_coarse_probe_fused(K, d, nq, n_cells, n_probe, smart):
+    """tpq_ivfpq_coarse_probe: sims within fp32 tolerance of the oracle's (float64-accumulated)
+    metric, the selection EXACT on the kernel's own sims, extents gathered, probe counts equal to
+    tpq_smart_probing on the same sims."""
+    rng = np.random.default_rng(d + nq)
+    x = (rng.standard_normal((d, nq)) * 20).astype(np.float32)
+    c = (rng.standard_normal((d, n_cells)) * 20).astype(np.float32)
+    sizes = rng.integers(0, 500, n_cells).astype(np.int64)
+    start = (np.cumsum(sizes + 3) - sizes - 3).astype(np.int64)
+    sims, cells, cs, sz, npl = K.CoarseProbeHip()(T(x), T(c), T(start), T(sizes), n_probe,
+                                                  30.0 if smart else None)
+    sims, cells = N(sims), N(cells)
+    exact = -((x.astype(np.float64).T[:, None, :] - c.astype(np.float64).T[None]) ** 2).sum(-1)
+    scale = np.abs(exact).max()
+    got_at = np.take_along_axis(exact, cells, axis=1)
+    np.testing.assert_allclose(sims, got_at, rtol=1e-4, atol=1e-6 * scale)
+    assert (np.diff(sims, axis=1) <= 0).all()
+    # the chosen set is the top-n_probe up to fp32 noise at the boundary
+    kth = -np.sort(-exact, axis=1)[:, n_probe - 1]
+    assert (got_at >= kth[:, None] - 2e-4 * scale).all()
+    assert all(len(set(r)) == n_probe for r in cells)
+    assert np.array_equal(N(cs), start[cells]) and np.array_equal(N(sz), sizes[cells])
+    if smart and n_probe > 1:
+        assert np.array_equal(N(npl), N(K.SmartProbingHip()(T(sims), 30.0)))
+    else:
+        assert np.array_equal(N(npl), np.full(nq, n_probe))

@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--residual", action="store_true")
     ap.add_argument("--no-fused", action="store_true")
     ap.add_argument("--ref-layout", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="also time a HIP-graph replay of search()")
     args = ap.parse_args()
     p = dict(PRESETS[args.preset])
     for key in ("nq", "k", "n_probe"):
@@ -108,6 +109,20 @@ def main():
            "qps": round(p["nq"] / t_total * 1e3, 1),
            "scan_GBps": round(algo / max(t_cells - t_tab, 1e-9) / 1e6, 1),
            "end_to_end_GBps": round(algo / t_total / 1e6, 1)}
+    if args.graph:
+        import time
+        g = idx.graphed_search(p["nq"], k=k)
+        t_graph, _ = timed(lambda: g(x), args.iters)
+        out["graph_total_ms"] = round(t_graph, 4)
+        out["graph_qps"] = round(p["nq"] / t_graph * 1e3, 1)
+        # host-visible latency of one call (submit + wait), eager vs graph
+        for name, fn in (("eager", lambda: idx.search(x, k=k)), ("graph", lambda: g(x))):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.iters):
+                fn()
+                torch.cuda.synchronize()
+            out[f"{name}_sync_latency_ms"] = round((time.perf_counter() - t0) / args.iters * 1e3, 4)
     print(json.dumps(out))
 
 

@@ -41,6 +41,9 @@ SIGNATURES = {
     "tpq_topk_select": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tpq_coarse_select": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tpq_smart_probing": (_i, [_vp, _vp, _i, _i, _f, _vp]),
+    "tpq_ivfpq_coarse_probe_workspace_bytes": (_sz, [_i, _i]),
+    "tpq_ivfpq_coarse_probe": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f,
+                                    _vp, _sz, _vp]),
     "tpq_get_id_by_address": (_i, [_vp, _i64, _vp, _vp, _i64, _vp]),
     "tpq_max_sim": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tpq_compute_centroids_workspace_bytes": (_sz, [_i, _i, _i]),

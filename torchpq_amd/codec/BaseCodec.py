@@ -16,7 +16,14 @@ class BaseCodec(CustomModule):
 
     @property
     def is_trained(self):
-        return bool(self._is_trained)
+        # bool() of a device tensor is a host sync: read the flag once per buffer object (train(),
+        # load_state_dict() and .to() all install a NEW tensor), so search() stays sync-free and
+        # can be captured in a HIP graph
+        cached = self.__dict__.get("_trained_seen")
+        if cached is None or cached[0] is not self._is_trained:
+            cached = (self._is_trained, bool(self._is_trained))
+            self.__dict__["_trained_seen"] = cached
+        return cached[1]
 
     def _trained(self, value):
         if not isinstance(value, bool):

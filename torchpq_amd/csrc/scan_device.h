@@ -839,40 +839,57 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(ScanArgs a) {
   write_final<R>(a, q, top);
 }
 
-// packed path, phase 2: merge the per-wave lists of a query (exact values) and write the result
+// packed path, phase 2: merge the per-wave lists of a query (exact values) and write the result.
+// W = blockDim.x / 64 waves per query (host: min(8, n_lists / 2)): wave w folds lists w, w+W, ...
+// rank-major (every list's best 64 first: once those are in, most later chunks fail the
+// wave-uniform early-exit test of insert_sorted) with the loads issued a group ahead of the
+// merges, then the W partial lists are tree-merged through LDS.  Small batches run with many
+// splits per query (512 lists at nq = 1): one wave folding them serially took 0.2 ms.
 template <int R, int M, bool RES>
-__global__ __launch_bounds__(64) void scan_merge_refine_kernel(ScanArgs a) {
+__global__ __launch_bounds__(512) void scan_merge_refine_kernel(ScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int q = blockIdx.x;
   const int lane = lane_id();
+  const int W = (int)(blockDim.x >> 6), wave = (int)(threadIdx.x >> 6);
   const int n_lists = a.n_split * packed_waves(M);  // a multiple of 8
+  const int n_mine = n_lists / W;
   WaveTopK<R> top;
   top.init();
-  // Rank-major order (every list's best 64 first): once those are in, most later chunks fail the
-  // wave-uniform early-exit test.  Loads are issued 8 chunks at a time, a group ahead of the
-  // merges, so the wave is not serialised on one global-load latency per chunk.
-  const float* __restrict__ bv = a.ws_vals + (int64_t)q * n_lists * (R * 64);
-  const int* __restrict__ bi = a.ws_idx + (int64_t)q * n_lists * (R * 64);
-  const int n_groups = (n_lists / 8) * R;  // group g: rank chunk g / (n_lists/8), lists 8*(g % ..)
-  auto load_group = [&](int g, Key (&kk)[8]) {
-    const int r = g / (n_lists / 8), l0 = (g % (n_lists / 8)) * 8;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int64_t o = (int64_t)(l0 + u) * (R * 64) + r * 64 + lane;
-      kk[u] = Key{reinterpret_cast<const unsigned*>(bv)[o], reinterpret_cast<const unsigned*>(bi)[o]};
-    }
+  const unsigned* __restrict__ bv =
+      reinterpret_cast<const unsigned*>(a.ws_vals) + (int64_t)q * n_lists * (R * 64);
+  const unsigned* __restrict__ bi =
+      reinterpret_cast<const unsigned*>(a.ws_idx) + (int64_t)q * n_lists * (R * 64);
+  const int T = n_mine * R;  // item t: rank chunk t / n_mine of my (t % n_mine)-th list
+  auto load_item = [&](int t) -> Key {
+    if (t >= T) return pad_key();
+    const int r = t / n_mine, l = (t - r * n_mine) * W + wave;
+    const int64_t o = (int64_t)l * (R * 64) + r * 64 + lane;
+    return Key{bv[o], bi[o]};
   };
-  Key k0[8], k1[8];
-  load_group(0, k0);
-  for (int g = 0; g < n_groups; g += 2) {
-    if (g + 1 < n_groups) load_group(g + 1, k1);
+  constexpr int G = 4;
+  Key k0[G], k1[G];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) top.insert_sorted(k0[u]);
-    if (g + 1 >= n_groups) break;
-    if (g + 2 < n_groups) load_group(g + 2, k0);
+  for (int u = 0; u < G; ++u) k0[u] = load_item(u);
+  for (int t = 0; t < T; t += 2 * G) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) top.insert_sorted(k1[u]);
+    for (int u = 0; u < G; ++u) k1[u] = load_item(t + G + u);
+#pragma unroll
+    for (int u = 0; u < G; ++u) top.insert_sorted(k0[u]);
+#pragma unroll
+    for (int u = 0; u < G; ++u) k0[u] = load_item(t + 2 * G + u);
+#pragma unroll
+    for (int u = 0; u < G; ++u) top.insert_sorted(k1[u]);
   }
-  finalize_and_write<R, RES>(a, q, top, a.ws_delta[q]);
+  float* lv = reinterpret_cast<float*>(smem);
+  int* li = reinterpret_cast<int*>(smem + (size_t)W * R * 64 * 4);
+  for (int stride = 1; stride < W; stride <<= 1) {
+    if ((wave & (2 * stride - 1)) == stride) store_list<R>(top, lv + wave * R * 64, li + wave * R * 64);
+    __syncthreads();
+    if ((wave & (2 * stride - 1)) == 0)
+      merge_list<R>(top, lv + (wave + stride) * R * 64, li + (wave + stride) * R * 64);
+    __syncthreads();
+  }
+  if (wave == 0) finalize_and_write<R, RES>(a, q, top, a.ws_delta[q]);
 }
 
 // ---- host side -----------------------------------------------------------------------------

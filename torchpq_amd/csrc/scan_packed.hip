@@ -19,7 +19,12 @@ static int launch_packed(ScanArgs a, ResidualArgs ra, hipStream_t st) {
   hipLaunchKernelGGL((scan_packed_kernel<R, M, RES>), dim3((unsigned)a.nq * a.n_split),
                      dim3(packed_waves(M) * 64), lds, st, a, ra, delta_rel);
   TPQ_LAUNCH_CHECK("scan_packed_kernel");
-  hipLaunchKernelGGL((scan_merge_refine_kernel<R, M, RES>), dim3(a.nq), dim3(64), 0, st, a);
+  const int n_lists = a.n_split * packed_waves(M);
+  const int W = n_lists / 2 < 8 ? n_lists / 2 : 8;  // 4 (one split, 8 waves) or 8
+  const size_t merge_lds = (size_t)W * R * 64 * 8;
+  rc = set_lds(scan_merge_refine_kernel<R, M, RES>, merge_lds, "scan_merge_refine_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL((scan_merge_refine_kernel<R, M, RES>), dim3(a.nq), dim3(W * 64), merge_lds, st, a);
   TPQ_LAUNCH_CHECK("scan_merge_refine_kernel");
   return TPQ_OK;
 }

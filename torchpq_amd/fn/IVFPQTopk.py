@@ -11,21 +11,21 @@ class IVFPQTopk:
         self._scan = IVFPQTopkHip(m=n_subvectors, n_cs=contiguous_size)
 
     def topk(self, data, precomputed, cell_start, cell_size, is_empty, n_probe_list, k=256,
-             packed=None, address2id=None):
+             packed=None, address2id=None, slots_hint=None):
         assert 0 < k <= 1024
         return self._scan.topk(data=data, precomputed=precomputed, is_empty=is_empty,
                                cell_start=cell_start, cell_size=cell_size,
                                n_probe_list=n_probe_list, n_candidates=k, packed=packed,
-                               address2id=address2id)
+                               address2id=address2id, slots_hint=slots_hint)
 
     def topk_fused(self, data, query, codebook, cell_start, cell_size, is_empty, n_probe_list, k=256,
-                   distance="euclidean", packed=None, address2id=None):
+                   distance="euclidean", packed=None, address2id=None, slots_hint=None):
         """PQCodec.precompute_adc + topk fused: the [m, n_query, 256] table never touches HBM"""
         assert 0 < k <= 1024
         return self._scan.topk_fused(data=data, query=query, codebook=codebook, is_empty=is_empty,
                                      cell_start=cell_start, cell_size=cell_size,
                                      n_probe_list=n_probe_list, n_candidates=k, distance=distance,
-                                     packed=packed, address2id=address2id)
+                                     packed=packed, address2id=address2id, slots_hint=slots_hint)
 
     def topk_residual(self, data, precomputed, cell_start, cell_size, base_sims, is_empty,
                       n_probe_list, k=256, address2id=None):

@@ -12,7 +12,7 @@ from .. import metric, util
 from ..codec import PQCodec, VQCodec
 from ..container import CellContainer
 from ..fn import IVFPQTopk, Topk
-from ..kernels import CoarseSelectHip, SmartProbingHip
+from ..kernels import CoarseProbeHip, CoarseSelectHip, SmartProbingHip
 
 
 class IVFPQIndex(CellContainer):
@@ -55,6 +55,7 @@ class IVFPQIndex(CellContainer):
         self._fp16_scale_mode = "a"
         self.use_packed_layout = True   # MI355X scan layout (bank-conflict-free LDS look-ups)
         self.use_fused_lut = True       # build the ADC LUT inside the scan workgroups (no HBM table)
+        self.use_fused_probe = True     # coarse sims + select + list extents + probe count: one call
         self.max_query_batch = 32768    # bounds the [m, nq, 256] LUT (m=64: 2 GiB per batch)
 
         self.vq_codec = VQCodec(n_clusters=n_cells, n_redo=1, max_iter=15, tol=1e-4,
@@ -65,6 +66,7 @@ class IVFPQIndex(CellContainer):
         self._topk = Topk()
         self._smart_probing = SmartProbingHip()
         self._coarse_select = CoarseSelectHip()
+        self._coarse_probe = CoarseProbeHip()
         self.to(device)
 
     # ---- knobs (reference :89-232) ---------------------------------------------------------------
@@ -273,13 +275,20 @@ class IVFPQIndex(CellContainer):
         return (part1[:, None] + part2.permute(1, 2, 0, 3)).contiguous()
 
     # ---- search (reference :407-524) ---------------------------------------------------------------
-    def search_cells(self, x, cells, base_sims=None, n_probe_list=None, k=1, return_address=False):
-        """Scan the given cells [n_query, n_probe] for each query; (values, ids[, address])."""
+    def search_cells(self, x, cells, base_sims=None, n_probe_list=None, k=1, return_address=False,
+                     _extents=None):
+        """Scan the given cells [n_query, n_probe] for each query; (values, ids[, address]).
+        (`_extents`: the cells' (start, size) when the coarse step already gathered them.)"""
         n_query = x.shape[1]
         if n_probe_list is None:
             n_probe_list = torch.full((n_query,), cells.shape[1], device=self.device, dtype=torch.long)
-        cell_start = self._cell_start[cells]
-        cell_size = self._cell_size[cells]
+        if _extents is None:
+            cell_start = self._cell_start[cells]
+            cell_size = self._cell_size[cells]
+        else:
+            cell_start, cell_size = _extents
+        # expected slots per query (host-side estimate, no sync): bounds the per-query split
+        slots_hint = cells.shape[1] * self.capacity // max(self.n_cells, 1)
         if self.pq_use_residual:
             assert base_sims is not None, "base_sims is required when pq_use_residual is True"
             is_empty = self._is_empty if self._has_holes else None
@@ -299,7 +308,7 @@ class IVFPQIndex(CellContainer):
                     n_probe_list=n_probe_list, n_candidates=k, part1=part1,
                     query=x if fused else None,
                     codebook=self.pq_codec.codebook if fused else None,
-                    address2id=self._address2id)
+                    address2id=self._address2id, slots_hint=slots_hint)
             elif self.use_precomputed:
                 part1, part2 = self.precomputed_adc_residual_precomputed(x)
                 topk_val, topk_address, topk_ids = self._ivfpq_topk.topk_residual_precomputed(
@@ -327,7 +336,7 @@ class IVFPQIndex(CellContainer):
                 data=self._storage, query=x, codebook=self.pq_codec.codebook, cell_start=cell_start,
                 cell_size=cell_size, is_empty=self._is_empty if self._has_holes else None,
                 n_probe_list=n_probe_list, k=k, distance=self.distance, packed=packed,
-                address2id=self._address2id)
+                address2id=self._address2id, slots_hint=slots_hint)
             if return_address:
                 return topk_val, topk_ids, topk_address
             return topk_val, topk_ids
@@ -335,13 +344,26 @@ class IVFPQIndex(CellContainer):
         topk_val, topk_address, topk_ids = self._ivfpq_topk.topk(
             data=self._storage, precomputed=precomputed, cell_start=cell_start,
             cell_size=cell_size, is_empty=self._is_empty if self._has_holes else None,
-            n_probe_list=n_probe_list, k=k, packed=packed, address2id=self._address2id)
+            n_probe_list=n_probe_list, k=k, packed=packed, address2id=self._address2id,
+            slots_hint=slots_hint)
         if return_address:
             return topk_val, topk_ids, topk_address
         return topk_val, topk_ids
 
+    def _probe_with_extents(self, x):
+        """probe() plus the (start, size) of every probed cell, or None when not gathered"""
+        if self.use_fused_probe and self.use_cublas and self.n_probe <= 1024:
+            smart = self.use_smart_probing and self.n_probe > 1
+            sims, cells, cs, sz, npl = self._coarse_probe(
+                x, self.vq_codec.codebook, self._cell_start, self._cell_size, self.n_probe,
+                self.smart_probing_temperature if smart else None)
+            return sims, cells, npl, (cs, sz)
+        return (*self.probe(x), None)
+
     def probe(self, x):
         """Coarse step: (topk_sims, cells [n_query, n_probe], n_probe_list [n_query])."""
+        if self.use_fused_probe and self.use_cublas and self.n_probe <= 1024:
+            return self._probe_with_extents(x)[:3]
         vq_codebook = self.vq_codec.codebook
         if self.use_cublas and self.n_probe <= 1024:
             # library GEMM, then the 2ab - a^2 - b^2 epilogue (reference rounding order) fused into
@@ -361,6 +383,11 @@ class IVFPQIndex(CellContainer):
                                       dtype=torch.long)
         return topk_sims, cells, n_probe_list
 
+    def graphed_search(self, n_query, k=1):
+        """search() for a fixed batch shape captured in one HIP graph (low-latency serving)"""
+        from .graphed import GraphedSearch
+        return GraphedSearch(self, n_query, k)
+
     def search(self, x, k=1, return_address=False):
         """x [d_vector, n_query] f32 -> (values f32 [n_query, k] descending, ids int64 [n_query, k]);
         values are -squared-L2 (euclidean) or cosine similarity of the PQ reconstruction.
@@ -377,9 +404,10 @@ class IVFPQIndex(CellContainer):
         vals, ids = [], []
         for q0 in range(0, max(n_query, 1), self.max_query_batch):
             xb = x[:, q0:q0 + self.max_query_batch].contiguous()
-            topk_sims, cells, n_probe_list = self.probe(xb)
+            topk_sims, cells, n_probe_list, extents = self._probe_with_extents(xb)
             v, i = self.search_cells(x=xb, cells=cells, base_sims=topk_sims,
-                                     n_probe_list=n_probe_list, k=k, return_address=False)
+                                     n_probe_list=n_probe_list, k=k, return_address=False,
+                                     _extents=extents)
             vals.append(v)
             ids.append(i)
         if len(vals) == 1:

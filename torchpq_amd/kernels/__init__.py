@@ -13,7 +13,7 @@ from .. import _lib
 from .._lib import check, load, ptr, require_gpu, stream_ptr
 
 __all__ = [
-    "IVFPQTopkHip", "IVFPQTop1Hip", "ResidualPart1Hip", "ResidualSlotTermsHip", "AdcLutHip", "TopkSelectHip", "CoarseSelectHip", "Top1SelectHip",
+    "IVFPQTopkHip", "IVFPQTop1Hip", "ResidualPart1Hip", "ResidualSlotTermsHip", "AdcLutHip", "TopkSelectHip", "CoarseSelectHip", "CoarseProbeHip", "Top1SelectHip",
     "Top32SelectHip", "SmartProbingHip", "MaxSimHip", "ComputeCentroidsHip", "GetIOAHip",
     "GetWriteAddressHip", "GetCellByAddressHip", "GetIdByAddressHip", "PQDecodeHip",
     "ScatterCodesHip", "PackCodesHip", "packed_chunk_width", "PACKED_M",
@@ -45,18 +45,24 @@ class IVFPQTopkHip:
         # timing events recorded on the launch stream around the scan kernel(s)
         self.record_events = None
 
-    def _n_split(self, n_query, device):
-        """Workgroups per query so that small batches still fill the chip (256 CUs x 2)."""
+    def _n_split(self, n_query, device, slots_hint=None):
+        """Workgroups per query so that small batches still fill the chip (256 CUs x 2).
+        ``slots_hint`` (expected slots scanned per query) caps the split so that every wave still
+        walks >= 4 tiles: a wave that sees a single tile admits all 64 slots and the merge drowns."""
         if self.n_cus is None:
             self.n_cus = torch.cuda.get_device_properties(device).multi_processor_count
         # two 8-wave workgroups per CU while the LUT is <= 64 KiB, one 16-wave workgroup above
         target = (2 if self.m <= 64 else 1) * self.n_cus
         if n_query >= target:
             return 1
-        return max(1, min(64, target // max(n_query, 1)))
+        split = max(1, min(64, target // max(n_query, 1)))
+        if slots_hint is not None:
+            waves = 8 if self.m <= 64 else 16
+            split = max(1, min(split, int(slots_hint) // (64 * waves * 4)))
+        return split
 
     def topk(self, data, precomputed, is_empty, cell_start, cell_size, n_probe_list,
-             n_candidates=None, packed=None, address2id=None, n_split=None):
+             n_candidates=None, packed=None, address2id=None, n_split=None, slots_hint=None):
         """
           data: [m // 4, n_data, 4] uint8           (CellContainer._storage)
           precomputed: [m, n_query, 256] float32    (PQCodec.precompute_adc)
@@ -96,7 +102,7 @@ class IVFPQTopkHip:
             return (values, address) if ids is None else (values, address, ids)
         lib = load()
         if n_split is None:
-            n_split = self._n_split(n_query, device)
+            n_split = self._n_split(n_query, device, slots_hint)
         ws_bytes = lib.tpq_ivfpq_scan_workspace_bytes(n_query, k, n_split, self.m)
         ws = torch.empty(max(ws_bytes, 1), device=device, dtype=torch.uint8) if ws_bytes else None
         ev = None
@@ -124,7 +130,8 @@ class IVFPQTopkHip:
 
 
     def topk_fused(self, data, query, codebook, is_empty, cell_start, cell_size, n_probe_list,
-                   n_candidates, distance="euclidean", packed=None, address2id=None, n_split=None):
+                   n_candidates, distance="euclidean", packed=None, address2id=None, n_split=None,
+                   slots_hint=None):
         """precompute_adc + topk in one pass: the LUT is built inside the scan workgroups
         (query [d, n_query] f32, codebook [m, ds, 256] f32); results identical to
         topk(precomputed=AdcLutHip()(query, codebook))."""
@@ -152,7 +159,7 @@ class IVFPQTopkHip:
             return (values, address) if ids is None else (values, address, ids)
         lib = load()
         if n_split is None:
-            n_split = self._n_split(n_query, device)
+            n_split = self._n_split(n_query, device, slots_hint)
         ws_bytes = lib.tpq_ivfpq_scan_workspace_bytes(n_query, k, n_split, self.m)
         ws = torch.empty(max(ws_bytes, 1), device=device, dtype=torch.uint8)
         metric = _lib.METRIC_NEG_SQ_L2 if distance == "euclidean" else _lib.METRIC_INNER
@@ -213,7 +220,8 @@ class IVFPQTopkHip:
 
     def topk_residual_packed(self, data, packed, part2, slot_term, cell_bound, cells, base_sims,
                              is_empty, cell_start, cell_size, n_probe_list, n_candidates,
-                             part1=None, query=None, codebook=None, address2id=None, n_split=None):
+                             part1=None, query=None, codebook=None, address2id=None, n_split=None,
+                             slots_hint=None):
         """Residual scan on the scan layout (tpq_ivfpq_scan_topk_residual_packed): results equal
         topk_residual_precomputed bit for bit.  part1 [n_query, m, 256] or (query [d, n_query],
         codebook [m, ds, 256]) from which the workgroup builds it; part2 [n_cells, m, 256]
@@ -255,7 +263,7 @@ class IVFPQTopkHip:
             return (values, address) if ids is None else (values, address, ids)
         lib = load()
         if n_split is None:
-            n_split = self._n_split(n_query, device)
+            n_split = self._n_split(n_query, device, slots_hint)
         ws_bytes = lib.tpq_ivfpq_scan_workspace_bytes(n_query, k, n_split, self.m)
         ws = torch.empty(max(ws_bytes, 1), device=device, dtype=torch.uint8)
         ev = None
@@ -407,6 +415,43 @@ class CoarseSelectHip:
 
 Top1SelectHip = TopkSelectHip
 Top32SelectHip = TopkSelectHip
+
+
+class CoarseProbeHip:
+    """The coarse step of IVFPQIndex.search in one call (tpq_ivfpq_coarse_probe): sims on the fp32
+    matrix cores, row top-n_probe, list extents of the chosen cells, per-query probe count."""
+
+    def __call__(self, query, centroids, cell_start, cell_size, n_probe, smart_temperature=None):
+        """query [d, n_query] f32, centroids [d, n_cells] f32, cell_start / cell_size [n_cells] i64
+        -> (topk_sims [n_query, n_probe] f32, cells, cell_start, cell_size [n_query, n_probe] i64,
+            n_probe_list [n_query] i64)"""
+        d, nq = query.shape
+        n_cells = centroids.shape[1]
+        assert centroids.shape[0] == d and query.dtype == centroids.dtype == torch.float32
+        assert cell_start.shape == cell_size.shape == (n_cells,)
+        assert cell_start.dtype == cell_size.dtype == torch.int64
+        assert 1 <= n_probe <= min(n_cells, 1024)
+        query = query.contiguous()
+        centroids = centroids.contiguous()
+        require_gpu(query, centroids, cell_start, cell_size)
+        dev = query.device
+        sims = torch.empty(nq, n_probe, device=dev, dtype=torch.float32)
+        cells = torch.empty(nq, n_probe, device=dev, dtype=torch.int64)
+        cs = torch.empty(nq, n_probe, device=dev, dtype=torch.int64)
+        sz = torch.empty(nq, n_probe, device=dev, dtype=torch.int64)
+        npl = torch.empty(nq, device=dev, dtype=torch.int64)
+        if nq == 0:
+            return sims, cells, cs, sz, npl
+        lib = load()
+        ws_bytes = lib.tpq_ivfpq_coarse_probe_workspace_bytes(nq, n_cells)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        t = float(smart_temperature) if smart_temperature else 0.0
+        with torch.cuda.device(dev):
+            check(lib.tpq_ivfpq_coarse_probe(
+                ptr(query), ptr(centroids), ptr(cell_start), ptr(cell_size), ptr(sims), ptr(cells),
+                ptr(cs), ptr(sz), ptr(npl), d, nq, n_cells, n_probe, t, ptr(ws), ws_bytes,
+                stream_ptr(dev)), "tpq_ivfpq_coarse_probe")
+        return sims, cells, cs, sz, npl
 
 
 class SmartProbingHip:
