@@ -42,3 +42,23 @@ def fx_kmeans():
 @pytest.fixture(scope="session")
 def fx_residual():
     return load_golden("fx_residual")
+
+
+@pytest.fixture(scope="session")
+def fx_c1():
+    return load_golden("fx_c1")
+
+
+@pytest.fixture(scope="session")
+def fx_ties():
+    return load_golden("fx_ties")
+
+
+@pytest.fixture(scope="session")
+def fx_tomb():
+    return load_golden("fx_tomb")
+
+
+@pytest.fixture(scope="session")
+def fx_layout():
+    return load_golden("fx_layout")

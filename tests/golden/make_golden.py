@@ -61,7 +61,9 @@ def build_reference_index(torch, tq, d, m, n_cells, n, initial_size, seed, dista
     return idx, base, rng
 
 
-def fx_index(torch, tq, name, d, m, n_cells, n, nq, initial_size, seed, n_probe, ks):
+def fx_index(torch, tq, name, d, m, n_cells, n, nq, initial_size, seed, n_probe, ks, slim=False):
+    """slim=True drops the bulky arrays (base vectors, the all-slots distance matrix) so that a
+    larger shape still fits a ~1 MB fixture; the small fixtures pin those."""
     idx, base, rng = build_reference_index(torch, tq, d, m, n_cells, n, initial_size, seed)
     xb = torch.from_numpy(base.copy())
     # reference add; the CPU encode never labels the LAST point (MultiKMeans.py:352-353):
@@ -102,6 +104,9 @@ def fx_index(torch, tq, name, d, m, n_cells, n, nq, initial_size, seed, n_probe,
         ref_decode=ref_decode[:, :256].copy(),
         ref_adc_exact=ref_adc_exact,
     )
+    if slim:
+        for key in ("base", "ref_adc_exact", "add_ids"):
+            out.pop(key)
     for k, v in sd.items():
         out["sd." + k] = v
 
@@ -231,17 +236,102 @@ def fx_residual(torch, tq):
     print("fx_residual ok", int(sd["_cell_size"].sum()))
 
 
+def fx_ties_and_tomb(torch, tq):
+    """fx_ties: the reference adds 400 vectors a second time (new ids): identical codes in the same
+    cell -> exact value ties; pins the tie policy (value desc, address asc).
+    fx_tomb: the same index with tombstones INSIDE the cells' occupied ranges.  The reference's
+    remove() never gets past its inverted guard (CellContainer.py:381-383), so the two buffer
+    writes it would make (`_is_empty[address] = 1; _address2id[address] = -1`, :387-388) are
+    applied to the reference object's buffers directly; `_cell_size` is left as is so that the
+    scan's per-slot `is_empty` test (ivfpq_topk.cu:883-884) is what removes them."""
+    d, m, n_cells, n, nq, n_probe = 32, 8, 16, 1500, 16, 6
+    idx, base, rng = build_reference_index(torch, tq, d, m, n_cells, n, 256, seed=21)
+    idx.add(torch.from_numpy(base.copy()))
+    idx.add(torch.from_numpy(base[:, :400].copy()))          # duplicates, ids n .. n+399
+    queries = np.concatenate([base[:, :8], sift_like(rng, d, nq - 8)], axis=1)  # 8 queries ARE stored vectors
+    xq = torch.from_numpy(queries.copy())
+    sims = tq.metric.negative_squared_l2_distance(xq.clone(), idx.vq_codec.codebook.clone())
+    topk_sims, cells = sims.topk(n_probe, dim=1)
+    lut = idx.pq_codec.precompute_adc(xq.clone()).numpy()
+    npl = np.full(nq, n_probe, np.int64)
+
+    def dump(name, extra):
+        sd = {k: v.numpy().copy() for k, v in idx.state_dict().items() if v is not None}
+        out = dict(d=d, m=m, n_cells=n_cells, nq=nq, n_probe=n_probe, ks=np.array([1, 10, 100]),
+                   queries=queries, ref_lut=lut, ref_cells=cells.numpy(),
+                   ref_topk_sims=topk_sims.numpy(), **extra)
+        for k, v in sd.items():
+            out["sd." + k] = v
+        cs, sz = sd["_cell_start"][out["ref_cells"]], sd["_cell_size"][out["ref_cells"]]
+        for k in (1, 10, 100):
+            v, a = orc.scan_topk(sd["_storage"], lut, sd["_is_empty"], cs, sz, npl, k)
+            out[f"orc_vals_k{k}"], out[f"orc_addr_k{k}"] = v, a
+            out[f"orc_ids_k{k}"] = orc.get_id_by_address(sd["_address2id"], a)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        return out
+
+    t = dump("fx_ties", {})
+    ties = int((np.diff(t["orc_vals_k100"], axis=1) == 0).sum())
+    assert ties > 50, ties
+    print("fx_ties ok, exact ties inside the top-100 lists:", ties)
+
+    occupied = np.nonzero(idx._is_empty.numpy() == 0)[0]
+    dead = torch.from_numpy(np.sort(rng.choice(occupied, 300, replace=False)))
+    dead_ids = idx._address2id[dead].clone()
+    idx._is_empty[dead] = 1          # CellContainer.py:387
+    idx._address2id[dead] = -1       # CellContainer.py:388
+    t = dump("fx_tomb", dict(dead_address=dead.numpy(), dead_ids=dead_ids.numpy()))
+    assert not np.isin(t["orc_addr_k100"], dead.numpy()).any()
+    print("fx_tomb ok")
+
+
+def fx_layout(torch, tq):
+    """[m, n] codes <-> _storage [m/4, cap, 4] through the reference's own
+    set_data_by_address / get_data_by_address (CellContainer.py:151-239)."""
+    rng = np.random.default_rng(31)
+    out = {}
+    for case, (m, cap_cells) in enumerate([(8, 5), (16, 3), (120, 2)]):
+        c = tq.container.CellContainer(code_size=m, n_cells=cap_cells, dtype="uint8", device="cpu",
+                                       initial_size=16, expand_step_size=8, expand_mode="double",
+                                       use_inverse_id_mapping=True, contiguous_size=4)
+        cap = c.capacity
+        nw = min(40, cap - 3)
+        adr = rng.choice(cap, nw, replace=False).astype(np.int64)
+        codes = rng.integers(0, 256, (m, nw), dtype=np.uint8)
+        c.set_data_by_address(torch.from_numpy(codes), torch.from_numpy(adr))
+        probe = np.concatenate([adr[::-1], np.array([-1, cap, cap + 7]), rng.integers(0, cap, 9)])
+        out[f"l{case}_m"] = np.int64(m)
+        out[f"l{case}_codes"] = codes
+        out[f"l{case}_adr"] = adr
+        out[f"l{case}_ref_storage"] = c._storage.numpy().copy()
+        out[f"l{case}_probe"] = probe.astype(np.int64)
+        out[f"l{case}_ref_gather"] = c.get_data_by_address(torch.from_numpy(probe.astype(np.int64))).numpy()
+    np.savez_compressed(os.path.join(OUT, "fx_layout.npz"), **out)
+    print("fx_layout ok")
+
+
 def main():
     tq = import_reference()
     import torch
     torch.set_num_threads(4)
-    fx_index(torch, tq, "fx_tiny", d=32, m=8, n_cells=16, n=2000, nq=16, initial_size=256,
-             seed=1, n_probe=4, ks=[1, 10, 100])
-    fx_index(torch, tq, "fx_m16", d=64, m=16, n_cells=32, n=6000, nq=24, initial_size=128,
-             seed=2, n_probe=8, ks=[10])
-    fx_container(torch, tq)
-    fx_kmeans(torch, tq)
-    fx_residual(torch, tq)
+    jobs = {
+        "fx_tiny": lambda: fx_index(torch, tq, "fx_tiny", d=32, m=8, n_cells=16, n=2000, nq=16,
+                                    initial_size=256, seed=1, n_probe=4, ks=[1, 10, 100]),
+        "fx_m16": lambda: fx_index(torch, tq, "fx_m16", d=64, m=16, n_cells=32, n=6000, nq=24,
+                                   initial_size=128, seed=2, n_probe=8, ks=[10]),
+        # BASELINE.json configs[0] shape (d=128, m=16, n_cells=256, nprobe=8, k=10), 20 000 of its
+        # 100 000 vectors so that the fixture stays ~1 MB
+        "fx_c1": lambda: fx_index(torch, tq, "fx_c1", d=128, m=16, n_cells=256, n=20000, nq=64,
+                                  initial_size=128, seed=3, n_probe=8, ks=[10], slim=True),
+        "fx_container": lambda: fx_container(torch, tq),
+        "fx_kmeans": lambda: fx_kmeans(torch, tq),
+        "fx_residual": lambda: fx_residual(torch, tq),
+        "fx_ties_tomb": lambda: fx_ties_and_tomb(torch, tq),
+        "fx_layout": lambda: fx_layout(torch, tq),
+    }
+    names = sys.argv[1:] or list(jobs)
+    for n in names:
+        jobs[n]()
 
 
 if __name__ == "__main__":

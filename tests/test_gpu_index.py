@@ -309,6 +309,28 @@ def test_residual_index_end_to_end(use_precomputed):
         assert torch.equal(va, vb) and torch.equal(ia, ib) and torch.equal(va, vc) and torch.equal(ia, ic)
 
 
+@pytest.mark.parametrize("name", ["fx_c1", "fx_ties", "fx_tomb"])
+def test_search_on_reference_built_state_dicts(name, request):
+    """load_state_dict of reference-built indexes (C1 shape; duplicates; tombstones inside cells)
+    and search: same ids as the oracle driven by the index's own coarse step."""
+    fx = request.getfixturevalue(name)
+    idx = _index_from_fixture(fx)
+    idx.n_probe = int(fx["n_probe"])
+    idx.use_smart_probing = False
+    if name == "fx_tomb":
+        assert idx._has_holes
+    for k in (1, 10):
+        v, i = idx.search(T(fx["queries"]), k=k)
+        ev, ei, cells, npl = _expected_search(idx, fx["queries"], k)
+        assert np.array_equal(N(v), ev) and np.array_equal(N(i), ei)
+        if name == "fx_tomb":
+            assert not np.isin(N(i), fx["dead_ids"]).any()
+    # the coarse step picks the reference's cells (as a set; order differs only inside fp32 ties)
+    _, cells, _ = idx.probe(T(fx["queries"]))
+    same = [set(a) == set(b) for a, b in zip(N(cells).tolist(), fx["ref_cells"].tolist())]
+    assert np.mean(same) > 0.9
+
+
 @pytest.mark.parametrize("residual", [False, True])
 def test_graphed_search_replays_search(residual):
     """search() is sync-free and captures into one HIP graph; replays equal eager calls."""

@@ -534,3 +534,51 @@ def test_coarse_probe_fused(K, d, nq, n_cells, n_probe, smart):
         assert np.array_equal(N(npl), N(K.SmartProbingHip()(T(sims), 30.0)))
     else:
         assert np.array_equal(N(npl), np.full(nq, n_probe))
+
+
+@pytest.mark.parametrize("name", ["fx_c1", "fx_ties", "fx_tomb"])
+@pytest.mark.parametrize("layout", ["ref", "packed"])
+def test_scan_on_reference_built_fixtures(K, name, layout, request):
+    """C1-shaped index, reference-made duplicates (exact ties) and tombstones inside cells: values,
+    addresses and ids equal the committed vectors for both code layouts and any split."""
+    fx = request.getfixturevalue(name)
+    m = int(fx["m"])
+    scan = K.IVFPQTopkHip(m=m)
+    storage = T(_sd(fx, "_storage"))
+    packed = K.PackCodesHip()(storage) if layout == "packed" else None
+    a2i = T(_sd(fx, "_address2id"))
+    cs = T(_sd(fx, "_cell_start")[fx["ref_cells"]])
+    sz = T(_sd(fx, "_cell_size")[fx["ref_cells"]])
+    nq = int(fx["nq"])
+    npl = T(np.full(nq, int(fx["n_probe"]), np.int64))
+    for k in fx["ks"]:
+        k = int(k)
+        key = "s0_k%d" % k if name == "fx_c1" else "k%d" % k
+        for n_split in (1, 4):
+            v, a, i = scan.topk(storage, T(fx["ref_lut"]), T(_sd(fx, "_is_empty")), cs, sz, npl,
+                                n_candidates=k, packed=packed, address2id=a2i, n_split=n_split)
+            assert np.array_equal(N(v), fx["orc_vals_" + key])
+            assert np.array_equal(N(a), fx["orc_addr_" + key])
+            assert np.array_equal(N(i), fx["orc_ids_" + key])
+
+
+def test_code_layout_scatter_gather_matches_reference(K, fx_layout):
+    """tpq_scatter_codes / get_data_by_address against the reference's own set/get (fx_layout)."""
+    from torchpq_amd.container import CellContainer
+    fx = fx_layout
+    for case in range(3):
+        m = int(fx[f"l{case}_m"])
+        ref_storage = fx[f"l{case}_ref_storage"]
+        cap = ref_storage.shape[1]
+        st = torch.zeros(m // 4, cap, 4, dtype=torch.uint8, device=DEV)
+        pk = K.PackCodesHip()(st)
+        K.ScatterCodesHip()(T(fx[f"l{case}_codes"]), T(fx[f"l{case}_adr"]), st, pk)
+        assert np.array_equal(N(st), ref_storage)
+        assert np.array_equal(N(pk), N(K.PackCodesHip()(T(ref_storage))))
+        n_cells = {0: 5, 1: 3, 2: 2}[case]
+        c = CellContainer(code_size=m, n_cells=n_cells, device=DEV, initial_size=16,
+                          expand_step_size=8, expand_mode="double", contiguous_size=4)
+        assert c.capacity == cap
+        c.set_data_by_address(T(fx[f"l{case}_codes"]), T(fx[f"l{case}_adr"]))
+        assert np.array_equal(N(c._storage), ref_storage)
+        assert np.array_equal(N(c.get_data_by_address(T(fx[f"l{case}_probe"]))), fx[f"l{case}_ref_gather"])

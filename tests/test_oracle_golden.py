@@ -12,7 +12,7 @@ def _sd(fx, key):
     return fx["sd." + key]
 
 
-@pytest.mark.parametrize("name", ["fx_tiny", "fx_m16"])
+@pytest.mark.parametrize("name", ["fx_tiny", "fx_m16", "fx_c1"])
 def test_coarse_sims_and_lut_match_reference(name, request):
     fx = request.getfixturevalue(name)
     vq = _sd(fx, "vq_codec.kmeans.centroids")
@@ -26,7 +26,7 @@ def test_coarse_sims_and_lut_match_reference(name, request):
     np.testing.assert_allclose(lut_c, fx["ref_lut"], rtol=RTOL, atol=1e-6 * scale)
 
 
-@pytest.mark.parametrize("name", ["fx_tiny", "fx_m16"])
+@pytest.mark.parametrize("name", ["fx_tiny", "fx_m16", "fx_c1"])
 def test_coarse_select_and_smart_probing(name, request):
     fx = request.getfixturevalue(name)
     v, c = orc.topk_desc(fx["ref_sims"], int(fx["n_probe"]))
@@ -188,3 +188,80 @@ def test_residual_tables_and_scan_against_reference(fx_residual):
             exact = np.sort(fx["ref_adc_exact"][q][slots])[::-1][:k]
             np.testing.assert_allclose(v[q][:exact.size], exact, rtol=1e-4,
                                        atol=2e-4 * np.abs(fx["ref_adc_exact"][q]).max())
+
+
+def test_c1_shape_scan_numpy_vs_c_vs_golden(fx_c1):
+    """BASELINE configs[0] shape (d=128, m=16, n_cells=256, nprobe=8, k=10) on a reference-trained
+    index: the C and numpy restatements agree with the committed vectors."""
+    fx = fx_c1
+    storage, is_empty = _sd(fx, "_storage"), _sd(fx, "_is_empty")
+    cs = _sd(fx, "_cell_start")[fx["ref_cells"]]
+    sz = _sd(fx, "_cell_size")[fx["ref_cells"]]
+    nq = int(fx["nq"])
+    for smart in (0, 1):
+        npl = fx["ref_nprobe_list"] if smart else np.full(nq, int(fx["n_probe"]), np.int64)
+        v, a = c_oracle.scan_topk(storage, fx["ref_lut"], is_empty, cs, sz, npl, 10)
+        assert np.array_equal(v, fx[f"orc_vals_s{smart}_k10"])
+        assert np.array_equal(a, fx[f"orc_addr_s{smart}_k10"])
+        v2, a2 = orc.scan_topk(storage, fx["ref_lut"], is_empty, cs[:6], sz[:6], npl[:6], 10)
+        assert np.array_equal(v2, v[:6]) and np.array_equal(a2, a[:6])
+
+
+def test_tie_policy_on_reference_duplicates(fx_ties):
+    """The reference added 400 vectors twice: both copies share a cell and a code, so their values
+    tie exactly; the restatement orders ties by ascending address and returns both ids."""
+    fx = fx_ties
+    storage, is_empty = _sd(fx, "_storage"), _sd(fx, "_is_empty")
+    cs = _sd(fx, "_cell_start")[fx["ref_cells"]]
+    sz = _sd(fx, "_cell_size")[fx["ref_cells"]]
+    npl = np.full(int(fx["nq"]), int(fx["n_probe"]), np.int64)
+    for k in (1, 10, 100):
+        v, a = c_oracle.scan_topk(storage, fx["ref_lut"], is_empty, cs, sz, npl, k)
+        assert np.array_equal(v, fx[f"orc_vals_k{k}"]) and np.array_equal(a, fx[f"orc_addr_k{k}"])
+        vn, an = orc.scan_topk(storage, fx["ref_lut"], is_empty, cs, sz, npl, k)
+        assert np.array_equal(vn, v) and np.array_equal(an, a)
+    v, a = fx["orc_vals_k100"], fx["orc_addr_k100"]
+    tie = (np.diff(v, axis=1) == 0) & (a[:, 1:] >= 0)
+    assert tie.sum() > 50
+    assert (np.diff(a, axis=1)[tie] > 0).all()           # ties: ascending address
+    ids = fx["orc_ids_k100"]
+    n = 1500
+    # the first 8 queries are stored vectors 0..7: each comes back twice (id q and id n + q), tied
+    for q in range(8):
+        top2 = set(ids[q, :2].tolist())
+        assert top2 == {q, n + q}, (q, top2)
+        assert v[q, 0] == v[q, 1]
+
+
+def test_tombstones_inside_cells(fx_tomb):
+    fx = fx_tomb
+    storage, is_empty = _sd(fx, "_storage"), _sd(fx, "_is_empty")
+    cs = _sd(fx, "_cell_start")[fx["ref_cells"]]
+    sz = _sd(fx, "_cell_size")[fx["ref_cells"]]
+    npl = np.full(int(fx["nq"]), int(fx["n_probe"]), np.int64)
+    dead = fx["dead_address"]
+    inside = np.zeros(storage.shape[1], bool)
+    for c in range(int(fx["n_cells"])):
+        s0 = _sd(fx, "_cell_start")[c]
+        inside[s0:s0 + _sd(fx, "_cell_size")[c]] = True
+    assert inside[dead].all() and (is_empty[dead] == 1).all()
+    for k in (1, 10, 100):
+        v, a = c_oracle.scan_topk(storage, fx["ref_lut"], is_empty, cs, sz, npl, k)
+        assert np.array_equal(v, fx[f"orc_vals_k{k}"]) and np.array_equal(a, fx[f"orc_addr_k{k}"])
+        assert not np.isin(a, dead).any()
+        assert np.array_equal(orc.get_id_by_address(_sd(fx, "_address2id"), a), fx[f"orc_ids_k{k}"])
+    # without the is_empty test the tombstoned slots would be returned
+    v0, a0 = c_oracle.scan_topk(storage, fx["ref_lut"], None, cs, sz, npl, 100)
+    assert np.isin(a0, dead).any()
+
+
+def test_code_layout_round_trip_matches_reference(fx_layout):
+    fx = fx_layout
+    for case in range(3):
+        m = int(fx[f"l{case}_m"])
+        ref_storage = fx[f"l{case}_ref_storage"]
+        storage = np.zeros_like(ref_storage)
+        orc.codes_to_storage(fx[f"l{case}_codes"], fx[f"l{case}_adr"], storage)
+        assert storage.shape[0] == m // 4 and np.array_equal(storage, ref_storage)
+        got = orc.storage_to_codes(ref_storage, fx[f"l{case}_probe"])
+        assert np.array_equal(got, fx[f"l{case}_ref_gather"])
