@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Phase breakdown of scan_packed_kernel from in-kernel timestamps (private instrumentation build).
+
+    EXTRA_FLAGS=-DTPQ_SCAN_PROFILE FORCE=1 bash torchpq_amd/csrc/build.sh
+    python tools/scan_phase_profile.py [--m 64] [--nq 10000] [--n-probe 32] [--fused]
+
+Prints the mean duration of each phase per workgroup (thread 0's view; 10 ns clock) and the share of
+the kernel it accounts for.  Rebuild without the flag afterwards.
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+PHASES = ["start->probe table", "LUT staged (+barrier)", "error bound", "scan loop", "final flush+publish",
+          "barrier (wait slowest wave)", "counting rounds", "exact refinement + sort", "store lists"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--m", type=int, default=64)
+    ap.add_argument("--nq", type=int, default=10000)
+    ap.add_argument("--n-cells", type=int, default=1024)
+    ap.add_argument("--cell", type=int, default=977)
+    ap.add_argument("--n-probe", type=int, default=32)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--fused", action="store_true")
+    args = ap.parse_args()
+    from torchpq_amd import kernels as K
+    from torchpq_amd import _lib
+    lib = _lib.load()
+    raw = ctypes.CDLL(lib._name)
+    dev = "cuda:0"
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    m, nc, nq = args.m, args.n_cells, args.nq
+    sizes = torch.full((nc,), args.cell, device=dev, dtype=torch.long)
+    cap = sizes + 47
+    start = torch.cumsum(cap, 0) - cap
+    n_slots = int(cap.sum().item())
+    storage = torch.randint(0, 256, (m // 4, n_slots, 4), generator=g, device=dev, dtype=torch.uint8)
+    cells = torch.rand(nq, nc, generator=g, device=dev).argsort(1)[:, :args.n_probe].contiguous()
+    cs, sz = start[cells].contiguous(), sizes[cells].contiguous()
+    npl = torch.full((nq,), args.n_probe, device=dev, dtype=torch.long)
+    scan = K.IVFPQTopkHip(m=m)
+    packed = K.PackCodesHip()(storage)
+    if args.fused:
+        cb = torch.randn(m, 2, 256, generator=g, device=dev) * 20
+        q = torch.randn(2 * m, nq, generator=g, device=dev) * 20
+        run = lambda: scan.topk_fused(storage, q, cb, None, cs, sz, npl, n_candidates=args.k, packed=packed)
+    else:
+        lut = torch.randn(m, nq, 256, generator=g, device=dev) * 50 - 300
+        run = lambda: scan.topk(storage, lut, None, cs, sz, npl, n_candidates=args.k, packed=packed)
+    for _ in range(2):
+        run()
+    prof = torch.zeros(nq * 64 * 16, device=dev, dtype=torch.int64)
+    raw.tpq_debug_set_scan_profile(ctypes.c_void_p(prof.data_ptr()))
+    run()
+    torch.cuda.synchronize()
+    raw.tpq_debug_set_scan_profile(None)
+    n_blocks = nq * scan._n_split(nq, dev)
+    t = prof.view(-1, 16)[:n_blocks, :10].double().cpu() * 10.0  # ns
+    d = (t[:, 1:] - t[:, :-1]) / 1e3  # us
+    total = (t[:, 9] - t[:, 0]) / 1e3
+    print(f"m={m} nq={nq} n_probe={args.n_probe} blocks={n_blocks}  mean block lifetime {total.mean():.1f} us")
+    for i, name in enumerate(PHASES):
+        print(f"  {name:32s} {d[:, i].mean():7.2f} us  {100 * d[:, i].mean() / total.mean():5.1f} %")
+    span = (t[:, 9].max() - t[:, 0].min()) / 1e3
+    print(f"  kernel span {span:.1f} us; sum of block lifetimes / (512 slots) = {total.sum() / 512:.1f} us")
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,11 @@ extern "C" size_t tpq_ivfpq_scan_workspace_bytes(int nq, int k, int n_split, int
 static int run_ref(ScanArgs a, void* workspace, size_t workspace_bytes, tpq_stream_t stream);
 static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_t workspace_bytes,
                       tpq_stream_t stream);
+#ifdef TPQ_SCAN_PROFILE
+// private instrumentation build: phase timestamps of scan_packed_kernel (tools/scan_phase_profile.py)
+static unsigned long long* g_scan_prof = nullptr;
+extern "C" void tpq_debug_set_scan_profile(void* buf) { g_scan_prof = (unsigned long long*)buf; }
+#endif
 static bool has_packed_kernel(int m) {
 #define TPQ_IS_M(M) if (m == M) return true;
   TPQ_PACKED_M_LIST(TPQ_IS_M)
@@ -188,6 +193,9 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
   rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, R, n_lists), "ivfpq_scan_packed");
   if (rc) return rc;
   fill_ws(a, workspace, R, n_lists);
+#ifdef TPQ_SCAN_PROFILE
+  a.prof = g_scan_prof;
+#endif
   if (ra) {  // residual: the scan kernel may raise a flag itself (slot covered by two probes)
     rc = check_hip(hipMemsetAsync(a.flags, 0, (size_t)nq * 4, st), "ivfpq_scan_packed memset");
     if (rc) return rc;

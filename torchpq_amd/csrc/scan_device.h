@@ -31,7 +31,17 @@ struct ScanArgs {
   const int* only_flagged;  // reference kernel: when set, only queries with a non-zero flag run
   int64_t n_slots;
   int nq, max_nprobe, m, k, n_split;
+  unsigned long long* prof;  // -DTPQ_SCAN_PROFILE builds: [nq][16] phase timestamps (10 ns ticks)
 };
+
+#ifdef TPQ_SCAN_PROFILE
+#define TPQ_PROF(a, q, i)                                                        \
+  do {                                                                           \
+    if ((a).prof && threadIdx.x == 0) (a).prof[(int64_t)(q) * 16 + (i)] = wall_clock64(); \
+  } while (0)
+#else
+#define TPQ_PROF(a, q, i) ((void)0)
+#endif
 
 // ---- shared pieces -----------------------------------------------------------------------
 
@@ -139,33 +149,26 @@ __device__ __forceinline__ void finish_query(const ScanArgs& a, int q, int part,
 // stays L2-resident (m*ds KiB).  The arithmetic is adc_lut_kernel's, operation for operation --
 // dot, |q|^2 and |c|^2 as ascending-dimension fma chains, then 2*dot, -|q|^2, -|c|^2 -- so the
 // entries are bit-identical to tpq_adc_lut's.
-__device__ __forceinline__ void stage_query(const ScanArgs& a, int q, float* xq, float* q2s,
-                                            int n_threads) {
+__device__ __forceinline__ void stage_query(const ScanArgs& a, int q, float* xq, int n_threads) {
   const int d = a.m * a.ds;
   for (int i = threadIdx.x; i < d; i += n_threads) xq[i] = a.query[(int64_t)i * a.nq + q];
   __syncthreads();
-  for (int j = threadIdx.x; j < a.m; j += n_threads) {
-    float s = 0.f;
-    for (int e = 0; e < a.ds; ++e) s = fmaf(xq[j * a.ds + e], xq[j * a.ds + e], s);
-    q2s[j] = s;
-  }
-  __syncthreads();
 }
 
-__device__ __forceinline__ float4 fused_lut4(const ScanArgs& a, int j, int c4, const float* xq,
-                                             const float* q2s) {
+__device__ __forceinline__ float4 fused_lut4(const ScanArgs& a, int j, int c4, const float* xq) {
   const float4* __restrict__ cb = reinterpret_cast<const float4*>(a.codebook) + (int64_t)j * a.ds * 64 + c4;
   float4 dot = make_float4(0.f, 0.f, 0.f, 0.f), c2 = dot;
+  float q2 = 0.f;  // |q_j|^2, the same ascending-dimension chain in every thread that needs it
   for (int e = 0; e < a.ds; ++e) {
     const float4 y = cb[e * 64];
     const float x = xq[j * a.ds + e];
+    q2 = fmaf(x, x, q2);
     dot.x = fmaf(x, y.x, dot.x); dot.y = fmaf(x, y.y, dot.y);
     dot.z = fmaf(x, y.z, dot.z); dot.w = fmaf(x, y.w, dot.w);
     c2.x = fmaf(y.x, y.x, c2.x); c2.y = fmaf(y.y, y.y, c2.y);
     c2.z = fmaf(y.z, y.z, c2.z); c2.w = fmaf(y.w, y.w, c2.w);
   }
   if (!a.euclid) return dot;
-  const float q2 = q2s[j];
   float4 v;
   v.x = 2.f * dot.x; v.y = 2.f * dot.y; v.z = 2.f * dot.z; v.w = 2.f * dot.w;
   if (a.euclid == 2) return v;  // residual part1 = 2 q_j.r_jc (residual_part1_kernel)
@@ -175,13 +178,13 @@ __device__ __forceinline__ float4 fused_lut4(const ScanArgs& a, int j, int c4, c
 }
 
 __device__ __forceinline__ void stage_lut_linear(const ScanArgs& a, int q, float* lut,
-                                                 const float* xq, const float* q2s) {
+                                                 const float* xq) {
   // lut[j*256 + c] <- a.lut[(j*nq + q)*256 + c]; 16-byte loads, 1 KiB rows
   const float4* __restrict__ src = reinterpret_cast<const float4*>(a.lut);
   float4* dst = reinterpret_cast<float4*>(lut);
   for (int i = threadIdx.x; i < a.m * 64; i += kScanThreads) {
     const int j = i >> 6, c4 = i & 63;
-    dst[i] = a.lut ? src[((int64_t)j * a.nq + q) * 64 + c4] : fused_lut4(a, j, c4, xq, q2s);
+    dst[i] = a.lut ? src[((int64_t)j * a.nq + q) * 64 + c4] : fused_lut4(a, j, c4, xq);
   }
 }
 
@@ -200,7 +203,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_ref_kernel(ScanArgs a) {
   ProbeTable tab{ptab, ptab + a.max_nprobe, ptab + 2 * a.max_nprobe};
   unsigned* tau_key = reinterpret_cast<unsigned*>(ptab + 3 * a.max_nprobe + 1);
   float* xq = reinterpret_cast<float*>(tau_key + 1);  // fused LUT: query [m*ds], then |q_j|^2 [m]
-  float* q2s = xq + a.m * a.ds;
 
   const int q = blockIdx.x / a.n_split;
   const int part = blockIdx.x - q * a.n_split;
@@ -214,8 +216,8 @@ __global__ __launch_bounds__(kScanThreads) void scan_ref_kernel(ScanArgs a) {
     build_probe_table(a, q, n_probe, tab);
     if (lane == 0) *tau_key = f2key(-INFINITY);
   }
-  if (!a.lut) stage_query(a, q, xq, q2s, kScanThreads);
-  stage_lut_linear(a, q, lut, xq, q2s);
+  if (!a.lut) stage_query(a, q, xq, kScanThreads);
+  stage_lut_linear(a, q, lut, xq);
   __syncthreads();
 
   WaveSelector<R> sel;
@@ -307,7 +309,6 @@ __global__ __launch_bounds__(kScanThreads) void scan_residual_kernel(ScanArgs a,
   unsigned* tau_key = reinterpret_cast<unsigned*>(ptab + 3 * a.max_nprobe + 1);
 
   float* xq = reinterpret_cast<float*>(tau_key + 1);  // part1 built here: query [m*ds], |q_j|^2 [m]
-  float* q2s = xq + a.m * a.ds;
 
   const int q = blockIdx.x;
   if (a.only_flagged && a.only_flagged[q] == 0) return;  // exact redo of flagged queries only
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_residual_kernel(ScanArgs a,
     if (lane == 0) *tau_key = f2key(-INFINITY);
   }
   const bool build_part1 = !ra.full && !ra.part1;
-  if (build_part1) stage_query(a, q, xq, q2s, kScanThreads);
+  if (build_part1) stage_query(a, q, xq, kScanThreads);
   __syncthreads();
 
   WaveSelector<R> sel;
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_residual_kernel(ScanArgs a,
       const float4* __restrict__ s2 = reinterpret_cast<const float4*>(ra.part2) +
                                       ra.cells[(int64_t)q * a.max_nprobe + p] * (int64_t)n4;
       for (int i = threadIdx.x; i < n4; i += kScanThreads) {
-        const float4 x = build_part1 ? fused_lut4(a, i >> 6, i & 63, xq, q2s) : s1[i];
+        const float4 x = build_part1 ? fused_lut4(a, i >> 6, i & 63, xq) : s1[i];
         const float4 y = s2[i];
         dst[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
       }
@@ -398,9 +399,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_residual_kernel(ScanArgs a,
 // full of near-ties (more than 64R candidates within 2*delta of the k-th) that a member of the
 // exact top-k may have been evicted, the query is flagged and redone by scan_ref_kernel.
 
+// jmax[j] (zeroed by the caller) collects max_c |LUT[j][c]| as the IEEE bit pattern of a
+// non-negative float -- order-preserving as an unsigned, and LDS integer atomics are fast
+// (float ones are not: DESIGN 3.5)
 __device__ __forceinline__ void stage_lut_blocked(const ScanArgs& a, int q, float* lut,
-                                                  int n_threads, const float* xq,
-                                                  const float* q2s, const float* part1 = nullptr) {
+                                                  int n_threads, unsigned* jmax, const float* xq,
+                                                  const float* part1 = nullptr) {
   // thread handles (j, 4 consecutive c): 16-byte global load, 4 scalar LDS stores.
   // Consecutive threads take consecutive j for the same c-group so that the LDS stores of a
   // half-wave land in distinct banks.
@@ -410,12 +414,14 @@ __device__ __forceinline__ void stage_lut_blocked(const ScanArgs& a, int q, floa
     const int c4 = i / m, j = i - c4 * m;
     const float4 x = part1 ? reinterpret_cast<const float4*>(part1)[((int64_t)q * m + j) * 64 + c4]
                      : a.lut ? src[((int64_t)j * a.nq + q) * 64 + c4]
-                             : fused_lut4(a, j, c4, xq, q2s);
+                             : fused_lut4(a, j, c4, xq);
     const int c = c4 * 4;
     lut[scan_layout::lut_dword(m, j, c + 0)] = x.x;
     lut[scan_layout::lut_dword(m, j, c + 1)] = x.y;
     lut[scan_layout::lut_dword(m, j, c + 2)] = x.z;
     lut[scan_layout::lut_dword(m, j, c + 3)] = x.w;
+    const float mx = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+    atomicMax(&jmax[j], __float_as_uint(mx));
   }
 }
 
@@ -535,23 +541,26 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
   float* pbase = wave_q + NW;                  // RES: [max_nprobe] base_sims of the probe
   int* pcell = reinterpret_cast<int*>(pbase + (RES ? a.max_nprobe : 0));  // RES: [max_nprobe] cell
   float* xq = reinterpret_cast<float*>(pcell + (RES ? a.max_nprobe : 0));
-  float* q2s = xq + M * a.ds;                  // fused LUT: query [M*ds], then |q_j|^2 [M]
-
-  const int q = blockIdx.x / a.n_split;
-  const int part = blockIdx.x - q * a.n_split;
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
+  const int q = blockIdx.x / a.n_split;
+  const int part = blockIdx.x - q * a.n_split;
+  TPQ_PROF(a, blockIdx.x, 0);
   int n_probe = (int)a.n_probe_list[q];
   n_probe = n_probe < 0 ? 0 : (n_probe > a.max_nprobe ? a.max_nprobe : n_probe);
 
+  unsigned* jmax = reinterpret_cast<unsigned*>(qv_all);  // [M] (the queues are not live yet)
+  if (threadIdx.x < M) jmax[threadIdx.x] = 0u;
+  __syncthreads();
   if (wave == 0) {
     build_probe_table(a, q, n_probe, tab);
     if (lane == 0) *tau_key = f2key(-INFINITY);
     if (lane < NW) wave_q[lane] = -INFINITY;
   }
+  TPQ_PROF(a, blockIdx.x, 1);
   const float* part1 = RES ? ra.part1 : nullptr;
-  if (!a.lut && !part1) stage_query(a, q, xq, q2s, NW * 64);
-  stage_lut_blocked(a, q, lut, NW * 64, xq, q2s, part1);
+  if (!a.lut && !part1) stage_query(a, q, xq, NW * 64);
+  stage_lut_blocked(a, q, lut, NW * 64, jmax, xq, part1);
   float probe_mx = 0.f;
   if constexpr (RES) {
     for (int pp = threadIdx.x; pp < n_probe; pp += NW * 64) {
@@ -566,6 +575,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
     if (lane == 0) red[NW + wave] = probe_mx;
   }
   __syncthreads();
+  TPQ_PROF(a, blockIdx.x, 2);
 
   // delta >= |fast - exact|: both are fp32 sums of the same M terms in different orders, each
   // within (M-1) u * sum|x_i| of the real sum (u = 2^-24), and sum|x_i| <= sum_j max_c|LUT[j][c]|.
@@ -573,20 +583,15 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
   // onto base_p, fast = (M-1)-add sums of the part1's and of the part2's plus two more adds: each
   // within (M+1) u A of the real sum, A = |base_p| + sum_j max|part1_j| + cell_bound[cell_p]
   // (the host passes delta_rel with M+1 in place of M-1).
-  float part_sum = 0.f;
-  for (int j = wave; j < M; j += NW) {
-    float mx = 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) mx = fmaxf(mx, fabsf(lut[scan_layout::lut_dword(M, j, lane * 4 + u)]));
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
-    part_sum += mx;
-  }
-  if (lane == 0) red[wave] = part_sum;
-  __syncthreads();
+  // (sum_j max_c|LUT[j][c]| from the maxima collected while staging; every wave reduces the same
+  // M words in the same order, so all of them hold the identical bound)
   float bound = 0.f;
 #pragma unroll
-  for (int w = 0; w < NW; ++w) bound += red[w];
+  for (int j0 = 0; j0 < M; j0 += 64)
+    if (j0 + lane < M) bound += __uint_as_float(jmax[j0 + lane]);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) bound += __shfl_xor(bound, d, 64);
+  __syncthreads();  // jmax lives in the queue area: everyone has read it before the first push
   if constexpr (RES) {
     float mx = 0.f;
 #pragma unroll
@@ -594,6 +599,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
     bound += mx;
   }
   const float delta2 = 2.f * delta_rel * bound;  // 2*delta: width of the candidate band
+  TPQ_PROF(a, blockIdx.x, 3);
 
   WaveSelector<R> sel;
   sel.init(qv_all + wave * 64, qi_all + wave * 64, a.k);
@@ -660,7 +666,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
   // (m <= 64; larger m runs 16 waves per workgroup under a 128-VGPR cap and relies on them)
   if constexpr (M <= 64) {
     typename L::chunk_t w0[L::kChunks], w1[L::kChunks];
-    Tile m0{0, false}, m1{0, false};
+    Tile m0{0, false, 0.f}, m1{0, false, 0.f};
     int T = t_begin + wave;
     if (T < t_end) {
       m0 = locate(T);
@@ -691,11 +697,13 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
       consume(w0, m0);
     }
   }
+  TPQ_PROF(a, blockIdx.x, 4);
   {
     const float tau_before = sel.tau;
     sel.flush();
     publish(tau_before);
   }
+  TPQ_PROF(a, blockIdx.x, 5);
 
   // End of query, per wave and without any barrier: re-evaluate the surviving candidates of
   // this wave's list exactly (ascending j, LUT still in LDS), re-rank them by exact value and
@@ -708,6 +716,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
     // admits only ~k*ln(N/k)/NW candidates in its whole life and folds them in 64 at a time), so
     // the running threshold leaves ~100 entries per wave above it; the fresh bound leaves ~2k/NW.
     __syncthreads();
+    TPQ_PROF(a, blockIdx.x, 6);
     float shared_tau;  // identical in every wave (the loop below must be workgroup-uniform)
     {
       float qmin = reinterpret_cast<volatile float*>(wave_q)[0];
@@ -773,6 +782,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
       }
       sel.tau = fmaxf(sel.tau, key2f(lo));
     }
+    TPQ_PROF(a, blockIdx.x, 7);
     const float cut = sel.tau - delta2;
     constexpr int RR = refine_rows(M);
     uint32_t* scratch = scratch_all + wave * RR * (M / 4 + 1);
@@ -818,8 +828,10 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
       }
       ex.insert_unsorted(want ? make_key(e, idx) : pad_key());
     }
+    TPQ_PROF(a, blockIdx.x, 8);
     const int64_t o = (((int64_t)q * a.n_split + part) * NW + wave) * (R * 64);
     store_list<R>(ex, a.ws_vals + o, a.ws_idx + o);
+    TPQ_PROF(a, blockIdx.x, 9);
     if (part == 0 && wave == 0 && lane == 0) a.ws_delta[q] = delta2;
   }
 }
