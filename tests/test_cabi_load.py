@@ -3,6 +3,8 @@
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -50,3 +52,30 @@ def test_product_refuses_cpu_tensors_and_has_no_oracle_import():
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "/root/reference" not in src, f
+
+
+def test_torchpq_import_alias():
+    """torchpq_amd.compat.install_as_torchpq(): reference import paths and wrapper names resolve to
+    this package (CPU: names only)."""
+    import sys
+    import torchpq_amd.compat as compat
+    assert "torchpq" not in sys.modules
+    compat.install_as_torchpq()
+    try:
+        from torchpq.index import IVFPQIndex
+        from torchpq.kernels import (ComputeCentroidsCuda, GetDivByAddressV2Cuda, GetIOACuda,
+                                     GetWriteAddressV2Cuda, IVFPQTop1Cuda, IVFPQTopkCuda, MaxSimCuda,
+                                     PQDecodeCuda, Top1SelectCuda, Top32SelectCuda, TopkSelectCuda)
+        import torchpq
+        from torchpq_amd import kernels as K
+        assert IVFPQIndex.__module__ == "torchpq_amd.index.IVFPQIndex"
+        assert IVFPQTopkCuda is K.IVFPQTopkHip and MaxSimCuda is K.MaxSimHip
+        assert torchpq.codec.PQCodec.__module__.startswith("torchpq_amd")
+        assert callable(torchpq.metric.negative_squared_l2_distance)
+        with pytest.raises(RuntimeError):
+            sys.modules["torchpq"].__torchpq_amd_alias__ = False
+            compat.install_as_torchpq()          # would shadow a "foreign" torchpq
+        sys.modules["torchpq"].__torchpq_amd_alias__ = True
+    finally:
+        compat.uninstall()
+    assert "torchpq" not in sys.modules and "torchpq.index" not in sys.modules

@@ -1,0 +1,138 @@
+"""GPU: the cases of the reference's own container test-suite (tests/CellContainerTestCase.py:92-241
+-- init, expand, add with / without ids, remove by address / by ids, add-remove interaction,
+empty), written against the same public methods and imported through the `torchpq` alias, so a
+TorchPQ maintainer reads the test they know.  (The reference's files cannot run as shipped --
+SURVEY section 4 -- and its remove() is unreachable behind an inverted guard,
+container/CellContainer.py:381-383; these are the behaviours its tests *assert*.)
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CODE_SIZE, N_CELLS = 16, 64
+
+
+@pytest.fixture(params=["double", "step"])
+def module(request):
+    import torchpq_amd.compat as compat
+    compat.install_as_torchpq()
+    try:
+        from torchpq.container import CellContainer
+        torch.manual_seed(0)
+        np.random.seed(0)
+        yield CellContainer(code_size=CODE_SIZE, n_cells=N_CELLS, dtype="uint8", device=DEV,
+                            initial_size=32, expand_step_size=32, expand_mode=request.param,
+                            use_inverse_id_mapping=True, contiguous_size=4)
+    finally:
+        compat.uninstall()
+
+
+def make_data(n):
+    return torch.randint(0, 256, (CODE_SIZE, n), device=DEV, dtype=torch.uint8)
+
+
+def make_cells(module, n):
+    return torch.randint(module.n_cells, (n,), device=DEV, dtype=torch.long)
+
+
+def make_unique_ids(n):
+    # distinct, sparse, far beyond n (NB: never np.random.choice(huge, replace=False): it
+    # materialises a permutation of the whole population)
+    ids = np.random.choice(1 << 22, size=n, replace=False).astype(np.int64) * 262147 + 5
+    return torch.from_numpy(ids).to(DEV).long()
+
+
+def test_init(module):
+    assert module.capacity == N_CELLS * 32
+    assert module._storage.shape == (CODE_SIZE // 4, module.capacity, 4)
+
+
+def test_expand(module):
+    cells = torch.from_numpy(np.random.choice(N_CELLS, 17, replace=False)).to(DEV).long()
+    old_cap = module._cell_capacity[cells].clone()
+    others = torch.ones(N_CELLS, dtype=torch.bool, device=DEV)
+    others[cells] = False
+    old_other = module._cell_capacity[others].clone()
+    module.expand(cells)
+    new_cap = module._cell_capacity[cells]
+    if module.expand_mode == "double":
+        assert torch.equal(new_cap, old_cap * 2)
+    else:
+        assert torch.equal(new_cap, old_cap + module.expand_step_size)
+    assert torch.equal(module._cell_capacity[others], old_other)
+    assert module.capacity == int(module._cell_capacity.sum())
+    assert torch.equal(module._cell_start, torch.cumsum(module._cell_capacity, 0) - module._cell_capacity)
+
+
+def test_add_with_ids(module):
+    n = 10000
+    data, cells, ids = make_data(n), make_cells(module, n), make_unique_ids(n)
+    returned_ids, returned_adr = module.add(data, cells=cells, ids=ids, return_address=True)
+    assert torch.equal(ids, returned_ids)
+    assert torch.equal(module.get_address_by_id(ids), returned_adr)
+    assert torch.equal(module.get_data_by_address(returned_adr), data)
+    assert (module._is_empty[returned_adr] == 0).all()
+    assert torch.equal(module.get_cell_by_address(returned_adr), cells)
+    assert module.n_items == n
+
+
+def test_add_without_ids(module):
+    n = 10000
+    data, cells = make_data(n), make_cells(module, n)
+    returned_ids, returned_adr = module.add(data, cells=cells, return_address=True)
+    assert torch.equal(module.get_id_by_address(returned_adr), returned_ids)
+    assert torch.equal(module.get_address_by_id(returned_ids), returned_adr)
+    assert torch.equal(module.get_data_by_address(returned_adr), data)
+    assert (module._is_empty[returned_adr] == 0).all()
+    assert torch.equal(returned_ids, torch.arange(n, device=DEV))
+
+
+def test_remove_by_address(module):
+    n = 10000
+    data, cells, ids = make_data(n), make_cells(module, n), make_unique_ids(n)
+    _, returned_adr = module.add(data, cells=cells, ids=ids, return_address=True)
+    module.remove(address=returned_adr)
+    assert (module.get_id_by_address(returned_adr) == -1).all()
+    assert (module._is_empty[returned_adr] == 1).all()
+    assert module.n_items == 0
+
+
+def test_remove_by_ids(module):
+    n = 10000
+    data, cells, ids = make_data(n), make_cells(module, n), make_unique_ids(n)
+    _, returned_adr = module.add(data, cells=cells, ids=ids, return_address=True)
+    module.remove(ids=ids)
+    assert (module._is_empty[returned_adr] == 1).all()
+    assert (module.get_address_by_id(ids) == -1).all()
+    assert (module.get_id_by_address(returned_adr) == -1).all()
+
+
+def test_add_remove_interaction(module):
+    n = 1000
+    data, cells, ids = make_data(n), make_cells(module, n), make_unique_ids(n)
+    _, returned_adr = module.add(data, cells=cells, ids=ids, return_address=True)
+    remove_idx = torch.from_numpy(np.random.choice(n, n // 2, replace=False)).to(DEV)
+    keep = torch.ones(n, dtype=torch.bool, device=DEV)
+    keep[remove_idx] = False
+    module.remove(address=returned_adr[remove_idx])
+    assert module.n_items == n - n // 2
+    # the survivors are still found by id, with their codes
+    adr = module.get_address_by_id(ids[keep])
+    assert (adr >= 0).all() and torch.equal(module.get_data_by_address(adr), data[:, keep])
+    assert (module.get_address_by_id(ids[~keep]) == -1).all()
+    new_data, new_cells = make_data(n // 2), make_cells(module, n // 2)
+    new_ids, new_adr = module.add(new_data, cells=new_cells, return_address=True)
+    assert torch.equal(module.get_data_by_address(new_adr), new_data)
+    assert torch.equal(module.get_id_by_address(new_adr), new_ids)
+    assert torch.equal(module.get_address_by_id(new_ids), new_adr)
+    assert module.n_items == n
+
+
+def test_empty(module):
+    assert module.n_items == 0
+    assert (module._cell_size == 0).all()
+    module.add(make_data(100), cells=make_cells(module, 100))
+    module.empty()
+    assert module.n_items == 0 and (module._cell_size == 0).all() and (module._is_empty == 1).all()

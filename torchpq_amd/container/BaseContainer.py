@@ -31,6 +31,7 @@ class BaseContainer(CustomModule, ABC):
         self.register_buffer("_address2id",
                              torch.full((initial_size,), -1, device=device, dtype=torch.long))
         self.register_buffer("_id2address", None)
+        self._sparse_id_map = None  # (sorted ids, their addresses) when ids are too sparse for a table
         self._get_id_by_address_hip = GetIdByAddressHip()
 
     @property
@@ -48,6 +49,7 @@ class BaseContainer(CustomModule, ABC):
     def _drop_inverse_id_mapping(self):
         del self._id2address
         self.register_buffer("_id2address", None)
+        self._sparse_id_map = None
 
     def get_id_by_address(self, address):
         """int64 addresses (any shape) -> ids, -1 where the address is out of range or free."""
@@ -56,12 +58,20 @@ class BaseContainer(CustomModule, ABC):
         return self._get_id_by_address_hip(self._address2id, address)
 
     def create_inverse_id_mapping(self):
-        """_id2address [max_id + 1]: address of every stored id, -1 elsewhere (:100-110)."""
+        """_id2address [max_id + 1]: address of every stored id, -1 elsewhere (:100-110).
+        The reference's dense table needs max_id + 1 entries whatever the number of items (its own
+        tests draw ids below 2**62, tests/CellContainerTestCase.py:60-66: 32 EiB); ids much sparser
+        than the capacity are served from a sorted (id, address) list by binary search instead."""
         a2i = self._address2id
         adr = torch.nonzero(a2i >= 0)[:, 0]
+        del self._id2address
+        if self.max_id + 1 > 8 * self.capacity + (1 << 20):
+            ids, order = torch.sort(a2i[adr])
+            self.register_buffer("_id2address", None)
+            self._sparse_id_map = (ids, adr[order])
+            return
         id2a = torch.full((self.max_id + 1,), -1, device=self.device, dtype=torch.long)
         id2a[a2i[adr]] = adr
-        del self._id2address
         self.register_buffer("_id2address", id2a)
 
     def get_address_by_id(self, ids):
@@ -69,8 +79,14 @@ class BaseContainer(CustomModule, ABC):
         after every add/remove (the reference keeps serving a stale one)."""
         assert util.check_dtype(ids, torch.int64)
         ids = ids.to(self.device)
-        if self._id2address is None:
+        if self._id2address is None and self._sparse_id_map is None:
             self.create_inverse_id_mapping()
+        if self._sparse_id_map is not None:
+            known, known_adr = self._sparse_id_map
+            if known.numel() == 0:
+                return torch.full_like(ids, -1)
+            pos = torch.searchsorted(known, ids).clamp_(max=known.numel() - 1)
+            return torch.where(known[pos] == ids, known_adr[pos], torch.full_like(ids, -1))
         mask = (0 <= ids) & (ids <= self.max_id)
         address = torch.full_like(ids, -1)
         address[mask] = self._id2address[ids[mask]]
