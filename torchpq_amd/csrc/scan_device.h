@@ -536,7 +536,8 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
   int* ptab = reinterpret_cast<int*>(smem + lut_bytes + aux_bytes + NW * 512);
   ProbeTable tab{ptab, ptab + a.max_nprobe, ptab + 2 * a.max_nprobe};
   unsigned* tau_key = reinterpret_cast<unsigned*>(ptab + 3 * a.max_nprobe + 1);
-  float* red = reinterpret_cast<float*>(tau_key + 1);  // [2 NW] reduction scratch
+  int* tile_ctr = reinterpret_cast<int*>(tau_key + 1);  // m > 64: next tile to hand out
+  float* red = reinterpret_cast<float*>(tile_ctr + 1);  // [2 NW] reduction scratch
   float* wave_q = red + 2 * NW;                // [NW] each wave's r-th best
   float* pbase = wave_q + NW;                  // RES: [max_nprobe] base_sims of the probe
   int* pcell = reinterpret_cast<int*>(pbase + (RES ? a.max_nprobe : 0));  // RES: [max_nprobe] cell
@@ -554,7 +555,10 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
   __syncthreads();
   if (wave == 0) {
     build_probe_table(a, q, n_probe, tab);
-    if (lane == 0) *tau_key = f2key(-INFINITY);
+    if (lane == 0) {
+      *tau_key = f2key(-INFINITY);
+      *tile_ctr = 0;
+    }
     if (lane < NW) wave_q[lane] = -INFINITY;
   }
   TPQ_PROF(a, blockIdx.x, 1);
@@ -690,11 +694,25 @@ __global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_p
       T = Tn;
     }
   } else {
+    // One 16-wave workgroup per CU and one tile in flight per wave: with a static deal the waves
+    // drift apart (the oldest wave of a SIMD wins the issue arbitration), the early finishers
+    // idle at the end-of-query barrier and the stragglers run alone, latency-bound -- 37-41 % of
+    // the workgroup's life at m = 120.  Tiles are therefore handed out from an LDS counter (one
+    // integer atomic per tile, fetched while the previous tile is consumed); a wave's tile
+    // indices still increase, which is all locate() needs.
+    auto grab = [&]() -> int {
+      int t = 0;
+      if (lane == 0) t = atomicAdd(tile_ctr, 1);
+      return t_begin + __builtin_amdgcn_readfirstlane(t);
+    };
     typename L::chunk_t w0[L::kChunks];
-    for (int T = t_begin + wave; T < t_end; T += NW) {
+    int T = grab();
+    while (T < t_end) {
       const Tile m0 = locate(T);
       if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
+      const int Tn = grab();
       consume(w0, m0);
+      T = Tn;
     }
   }
   TPQ_PROF(a, blockIdx.x, 4);
@@ -926,7 +944,7 @@ static size_t scan_lds_bytes_ref(int m, int R, int max_nprobe, int fused_floats)
 static size_t scan_lds_bytes_packed(int m, int R, int max_nprobe, int fused_floats, bool res) {
   const int nw = packed_waves(m);
   size_t b = (size_t)m * 1024 + packed_aux_bytes(R, m) + nw * 512 +
-             (size_t)(3 * max_nprobe + 1) * 4 + 4 + 3 * nw * 4 + (res ? 8 * (size_t)max_nprobe : 0) +
+             (size_t)(3 * max_nprobe + 1) * 4 + 8 + 3 * nw * 4 + (res ? 8 * (size_t)max_nprobe : 0) +
              (size_t)fused_floats * 4;
   return (b + 15) & ~(size_t)15;
 }
