@@ -510,7 +510,9 @@ constexpr int packed_aux_bytes(int /*R*/, int M) {
   return packed_waves(M) * refine_rows(M) * (M / 4 + 1) * 4;
 }
 
-// 2 workgroups per CU (LDS: 2 x (64 KiB LUT + ~14 KiB)) need <= 128 VGPRs: 4 waves per SIMD
+// 2 workgroups per CU (LDS: 2 x (64 KiB LUT + ~14 KiB)) need <= 128 VGPRs: 4 waves per SIMD.
+// Long lists (R = 8, 16) are held to the same cap: a handful of spilled registers in the (cold)
+// flush path cost far less than running one workgroup per CU (k = 300: 8.9 -> 6.4 ms).
 //
 // RES = residual PQ (replaces ivfpq_topk_residual_precomputed, ivfpq_topk.cu:1039-1208, at full
 // scan speed): the reference rebuilds LUT_p = part1[q] + part2[cell_p] in shared memory for every
@@ -521,7 +523,7 @@ constexpr int packed_aux_bytes(int /*R*/, int M) {
 // f is again a selection key only (|f - e| <= delta with the bound below); survivors are
 // re-evaluated with the reference's arithmetic: v = base_p; v += fl(part1 + part2) ascending j.
 template <int R, int M, bool RES>
-__global__ __launch_bounds__(packed_waves(M) * 64, (R <= 4 ? 4 : 2)) void scan_packed_kernel(ScanArgs a,
+__global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(ScanArgs a,
                                                                                     ResidualArgs ra,
                                                                                     float delta_rel) {
   using L = scan_layout::Layout<M>;
