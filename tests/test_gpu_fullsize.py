@@ -79,3 +79,78 @@ def test_c4_shape_100m_slots():
                                 cs[sel].cpu().numpy(), sz[sel].cpu().numpy(), npl[sel].cpu().numpy(), k)
     assert np.array_equal(v_ref[sel].cpu().numpy(), ev)
     assert np.array_equal(a_ref[sel].cpu().numpy(), ea)
+
+
+def test_c5_kmeans_full_size_properties():
+    """configs[4] (MultiKMeans, 64 sub-problems x 64 dims x 1 M points, 256 clusters: 16.4 GB):
+    identity on the centroids, sampled bit-exact oracle check, linearity of the update
+    (sum_c count_c * centroid_c == sum_i x_i), Lloyd monotonicity."""
+    import torchpq_amd.kernels as K
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2 ** 30:
+        pytest.skip("needs ~35 GB of HBM")
+    l, d, n, k = 64, 64, 1_000_000, 256
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    data = torch.randn(l, d, n, generator=g, device=DEV)
+    cent = data[:, :, torch.randperm(n, generator=g, device=DEV)[:k]].contiguous()
+    ms = K.MaxSimHip(distance="euclidean")
+    # the centroids are their own nearest centroid, at similarity exactly 0 (2s - s - s)
+    v_c, i_c = ms(cent, cent, dim=2)
+    assert torch.equal(i_c, torch.arange(k, device=DEV).expand(l, k)) and bool((v_c == 0).all())
+    vals, labels = ms(data, cent, dim=2)
+    assert labels.dtype == torch.int64 and int(labels.min()) >= 0 and int(labels.max()) < k
+    assert bool((vals <= 0).all())
+    # sampled oracle check: 4 sub-problems x 64 points, bit-exact (fma chains)
+    for b in (0, 21, 42, 63):
+        pts = torch.arange(b * 997, n, n // 64, device=DEV)[:64]
+        ev, ei = c_oracle.max_sim(data[b:b + 1][:, :, pts].cpu().numpy(), cent[b:b + 1].cpu().numpy(),
+                                  "euclidean", "expanded")
+        assert np.array_equal(vals[b, pts].cpu().numpy(), ev[0])
+        assert np.array_equal(labels[b, pts].cpu().numpy(), ei[0])
+    new_cent = K.ComputeCentroidsHip()(data, labels, k)
+    counts = torch.zeros(l, k, device=DEV).scatter_add_(1, labels, torch.ones(l, n, device=DEV))
+    assert bool((counts > 0).all())
+    total = data.sum(-1)                                        # [l, d]
+    recon = (new_cent * counts[:, None, :]).sum(-1)             # sum_c count_c * centroid_c
+    scale = float(data.abs().sum(-1).max())
+    assert float((total - recon).abs().max()) <= 2e-4 * scale
+    vals2, _ = ms(data, new_cent, dim=2)
+    assert float(vals2.double().sum()) > float(vals.double().sum())   # inertia went down
+
+
+def test_c2_index_full_size_round_trip():
+    """configs[1] shape through the index: train on 100 k, add 1 M, query with stored vectors:
+    a vector finds itself (encode -> scan -> id), its value is -|x - decode(encode(x))|^2, and
+    removing it makes it disappear."""
+    from torchpq_amd.index import IVFPQIndex
+    g = torch.Generator(device=DEV)
+    g.manual_seed(2)
+    d, n, nq = 128, 1_000_000, 4096
+    centers = torch.rand(d, 256, generator=g, device=DEV) * 120
+    base = (centers[:, torch.randint(0, 256, (n,), generator=g, device=DEV)]
+            + torch.randn(d, n, generator=g, device=DEV) * 25).abs().round().contiguous()
+    np.random.seed(2)
+    idx = IVFPQIndex(d_vector=d, n_subvectors=64, n_cells=1024, initial_size=2048, device=DEV)
+    idx.train(base[:, :100_000].contiguous())
+    ids = idx.add(base)
+    assert idx.n_items == n and torch.equal(ids, torch.arange(n, device=DEV))
+    idx.n_probe = 32
+    idx.use_smart_probing = False
+    q = base[:, :nq].contiguous()
+    v, i = idx.search(q, k=100)
+    assert bool((v[:, 1:] <= v[:, :-1]).all())
+    self_hit = (i == torch.arange(nq, device=DEV)[:, None]).any(1)
+    assert float(self_hit.float().mean()) > 0.99
+    # value of the self hit == -|x - decode(encode(x))|^2 (ADC identity), to fp32 accuracy
+    codes = idx.encode(q)
+    recon = idx.decode(codes)
+    exact = -((q - recon) ** 2).sum(0)
+    pos = (i == torch.arange(nq, device=DEV)[:, None]).float().argmax(1)
+    got = v.gather(1, pos[:, None])[:, 0]
+    rel = ((got - exact).abs() / exact.abs().clamp(min=1))[self_hit]
+    assert float(rel.max()) < 1e-4
+    idx.remove(ids=torch.arange(0, nq, 2, device=DEV))
+    v2, i2 = idx.search(q, k=100)
+    assert not bool((i2[0::2] == torch.arange(0, nq, 2, device=DEV)[:, None]).any())
+    assert bool((i2[1::2] == torch.arange(1, nq, 2, device=DEV)[:, None]).any(1).float().mean() > 0.99)
