@@ -67,6 +67,10 @@ def main():
     ap.add_argument("--nq", type=int)
     ap.add_argument("--k", type=int)
     ap.add_argument("--n-probe", type=int)
+    ap.add_argument("--m", type=int)
+    ap.add_argument("--d", type=int)
+    ap.add_argument("--n-cells", type=int)
+    ap.add_argument("--cell", type=int, help="vectors per cell")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--residual", action="store_true")
     ap.add_argument("--no-fused", action="store_true")
@@ -74,7 +78,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="also time a HIP-graph replay of search()")
     args = ap.parse_args()
     p = dict(PRESETS[args.preset])
-    for key in ("nq", "k", "n_probe"):
+    for key in ("nq", "k", "n_probe", "m", "d", "n_cells", "cell"):
         if getattr(args, key) is not None:
             p[key] = getattr(args, key)
     from torchpq_amd.index import IVFPQIndex

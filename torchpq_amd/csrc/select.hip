@@ -152,83 +152,85 @@ __global__ __launch_bounds__(256) void id_by_address_kernel(const int64_t* __res
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Coarse similarities sims[q][c] = 2 x_q.C_c - |x_q|^2 - |C_c|^2 (metric.negative_squared_l2_distance,
-// torchpq/metric.py:31-98: library GEMM + three element-wise passes) as one fp32-MFMA kernel:
-// block = 64 queries x 256 centroids, wave = 32 x 128 (four 32x32 accumulator tiles on
-// v_mfma_f32_32x32x2_f32), operands straight from global memory (both matrices are L2-resident:
-// 20 B/clk/CU of L1 traffic against 4 MFMAs per k-pair), norms accumulated from the operand
-// registers on the way (even-k chain + odd-k chain), epilogue in the reference's rounding order.
+// torchpq/metric.py:31-98: library GEMM + three element-wise passes) as one fp32-MFMA kernel.
+// Block = 64 queries x 256 centroids, wave = 32 x 128 (four 32x32 accumulator tiles on
+// v_mfma_f32_32x32x2_f32).  Operands are staged through LDS in k-batches of 16, double-buffered
+// (global -> registers one batch ahead -> LDS), so each element is fetched once per block with
+// coalesced row loads and the MFMA operands come from conflict-free LDS reads; the norms are
+// accumulated from the operand registers on the way (even-k chain + odd-k chain), epilogue in the
+// reference's rounding order.  In the reference's own benchmark grid (IVF4096 / IVF16384, n_probe
+// 1..128) this step is 50-85 % of a search, not the scan.
 // x [d][nq], C [d][n_cells] -> sims [nq][n_cells]
+constexpr int kCsKB = 16;
+
 __global__ __launch_bounds__(256) void coarse_sims_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ C,
                                                          float* __restrict__ sims, int d, int nq,
                                                          int n_cells) {
+  __shared__ float As[2][kCsKB][64];
+  __shared__ float Bs[2][kCsKB][256];
   __shared__ float q2s[64];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
   const int l31 = lane & 31, half = lane >> 5;
-  const int qb = blockIdx.x * 64 + 32 * (wave & 1);
-  const int cb = blockIdx.y * 256 + 128 * (wave >> 1);
-  const int q = qb + l31;
-  const bool qok = q < nq;
+  const int qb = blockIdx.x * 64, cb = blockIdx.y * 256;
+  const int wq = 32 * (wave & 1), wc = 128 * (wave >> 1);
+
+  // staging: A batch = 16 rows x 64 queries (4 elements per thread), B batch = 16 rows x 256
+  // centroids (16 per thread); a thread's elements of one row are contiguous across the wave
+  const int a_col = tid & 63, a_row0 = tid >> 6;  // rows a_row0 + 4u
+  const bool a_ok = qb + a_col < nq;
+  const bool b_ok = cb + tid < n_cells;
+  const float* __restrict__ xa = x + (a_ok ? qb + a_col : 0);
+  const float* __restrict__ cbp = C + (b_ok ? cb + tid : 0);
+  float ra[4], rb[kCsKB];
+  auto load_batch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + a_row0 + 4 * u;
+      ra[u] = (a_ok && k < d) ? xa[(int64_t)k * nq] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kCsKB; ++u) {
+      const int k = k0 + u;
+      rb[u] = (b_ok && k < d) ? cbp[(int64_t)k * n_cells] : 0.f;
+    }
+  };
+  auto store_batch = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) As[buf][a_row0 + 4 * u][a_col] = ra[u];
+#pragma unroll
+    for (int u = 0; u < kCsKB; ++u) Bs[buf][u][tid] = rb[u];
+  };
+
   f32x16 acc[4];
-  float b2[4];
+  float b2[4], a2 = 0.f;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     b2[t] = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   }
-  float a2 = 0.f;
-  // out-of-range rows / columns read row 0 / column 0 instead (always in bounds); an MFMA output
-  // depends only on its own A row and B column, and those outputs are never stored
-  const float* __restrict__ xq = x + (qok ? q : 0);
-  const float* __restrict__ cc[4];
+  const int n_batches = (d + kCsKB - 1) / kCsKB;
+  load_batch(0);
+  store_batch(0);
+  __syncthreads();
+  for (int bt = 0; bt < n_batches; ++bt) {
+    const int buf = bt & 1;
+    if (bt + 1 < n_batches) load_batch((bt + 1) * kCsKB);
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int c = cb + 32 * t + l31;
-    cc[t] = C + (c < n_cells ? c : 0);
-  }
-  constexpr int KU = 4;  // k-pairs per batch: 20 loads in flight per lane, one batch ahead
-  float av[2][KU], bv[2][KU][4];
-  auto load_batch = [&](int k0, float (&a)[KU], float (&b)[KU][4]) {
-#pragma unroll
-    for (int u = 0; u < KU; ++u) {
-      const int64_t k = k0 + 2 * u + half;
-      a[u] = xq[k * nq];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) b[u][t] = cc[t][k * n_cells];
-    }
-  };
-  auto mma_batch = [&](const float (&a)[KU], const float (&b)[KU][4]) {
-#pragma unroll
-    for (int u = 0; u < KU; ++u) {
-      a2 = fmaf(a[u], a[u], a2);
+    for (int kk = 0; kk < kCsKB / 2; ++kk) {
+      const float a = As[buf][2 * kk + half][wq + l31];
+      a2 = fmaf(a, a, a2);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        b2[t] = fmaf(b[u][t], b[u][t], b2[t]);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][t], acc[t], 0, 0, 0);
+        const float b = Bs[buf][2 * kk + half][wc + 32 * t + l31];
+        b2[t] = fmaf(b, b, b2[t]);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
       }
     }
-  };
-  const int n_batches = d / (2 * KU);
-  if (n_batches > 0) load_batch(0, av[0], bv[0]);
-  for (int bt = 0; bt < n_batches; bt += 2) {
-    if (bt + 1 < n_batches) load_batch((bt + 1) * 2 * KU, av[1], bv[1]);
-    mma_batch(av[0], bv[0]);
-    if (bt + 1 >= n_batches) break;
-    if (bt + 2 < n_batches) load_batch((bt + 2) * 2 * KU, av[0], bv[0]);
-    mma_batch(av[1], bv[1]);
-  }
-  for (int k0 = n_batches * 2 * KU; k0 < d; k0 += 2) {  // tail of d % 8
-    const int k = k0 + half;
-    const bool kok = k < d;
-    const float a = kok ? xq[(int64_t)k * nq] : 0.f;
-    a2 = fmaf(a, a, a2);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float b = kok ? cc[t][(int64_t)k * n_cells] : 0.f;
-      b2[t] = fmaf(b, b, b2[t]);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-    }
+    if (bt + 1 < n_batches) store_batch(buf ^ 1);
+    __syncthreads();
   }
   a2 += __shfl_xor(a2, 32, 64);
 #pragma unroll
@@ -237,15 +239,15 @@ __global__ __launch_bounds__(256) void coarse_sims_kernel(const float* __restric
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const int c = cb + 32 * t + l31;
+    const int c = cb + wc + 32 * t + l31;
     if (c >= n_cells) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int qq = qb + row;
+      const int qq = qb + wq + row;
       if (qq < nq) {
         float v = 2.f * acc[t][r];
-        v = v - q2s[32 * (wave & 1) + row];
+        v = v - q2s[wq + row];
         v = v - b2[t];
         sims[(int64_t)qq * n_cells + c] = v;
       }
