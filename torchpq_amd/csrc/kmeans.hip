@@ -18,71 +18,128 @@ namespace tpq {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kMsCent = 256;  // centroids per pass (8 MFMA row tiles)
-constexpr int kMsKC = 32;     // k rows staged in LDS per step
+constexpr int kMsKC = 16;     // k rows staged in LDS per step (per buffer)
 
-// grid (ceil(m/128), l), block 256 = 4 waves x 32 points
-__global__ __launch_bounds__(256) void max_sim_kernel(const float* __restrict__ A,
-                                                      const float* __restrict__ B,
-                                                      float* __restrict__ vals,
-                                                      int64_t* __restrict__ inds, int d, int m,
-                                                      int n, int euclidean) {
-  __shared__ float cs[kMsKC * kMsCent];
-  __shared__ float b2s[kMsCent];
+// grid (ceil(m/128), l), block 256 = 4 waves x 32 points.  Centroid chunk (256 rows) x k-slab (16)
+// tiles are double-buffered in LDS: the next slab goes global -> registers while the MFMAs of
+// the current one run, then registers -> the other buffer, one barrier per slab; the wave's own
+// point operand for the next slab is prefetched the same way.  (The first version staged and
+// consumed each slab between two barriers and loaded its point operand inside the MFMA loop:
+// 17-23 TF/s.)
+constexpr int kMsSlab = kMsKC * kMsCent;  // floats per LDS buffer (16 KiB)
+
+__global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict__ A,
+                                                         const float* __restrict__ B,
+                                                         float* __restrict__ vals,
+                                                         int64_t* __restrict__ inds, int d, int m,
+                                                         int n, int euclidean) {
+  extern __shared__ __attribute__((aligned(16))) float ms_smem[];
+  float* cs = ms_smem;                  // [2][kMsKC][kMsCent]
+  float* b2s = ms_smem + 2 * kMsSlab;   // [kMsCent]
   const int b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l31 = lane & 31, half = lane >> 5;
   const int i = blockIdx.x * 128 + wave * 32 + l31;  // this lane's point
   const bool iv = i < m;
-  const float* __restrict__ Ab = A + (int64_t)b * d * m;
+  const float* __restrict__ Ab = A + (int64_t)b * d * m + (iv ? i : 0);
   const float* __restrict__ Bb = B + (int64_t)b * d * n;
 
+  // |a|^2, one ascending-k fma chain per point; 16 loads in flight per step (a plain loop waits
+  // out one memory latency per dimension)
   float a2 = 0.f;
-  if (euclidean && iv)
-    for (int k = 0; k < d; ++k) {
-      const float x = Ab[(int64_t)k * m + i];
-      a2 = fmaf(x, x, a2);
+  if (euclidean && iv) {
+    const float* __restrict__ p = Ab;
+    int k = 0;
+    for (; k + 16 <= d; k += 16) {
+      float x[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) x[u] = p[(int64_t)u * m];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a2 = fmaf(x[u], x[u], a2);
+      p += 16 * (int64_t)m;
     }
+    for (; k < d; ++k) {
+      const float x = *p;
+      a2 = fmaf(x, x, a2);
+      p += m;
+    }
+  }
 
   float best = -INFINITY;
   int besti = 0;
+  const int n_slabs = (d + kMsKC - 1) / kMsKC;
 
   for (int c0 = 0; c0 < n; c0 += kMsCent) {
     const int nc = (n - c0) < kMsCent ? (n - c0) : kMsCent;
     const int nt = (nc + 31) >> 5;
-    __syncthreads();  // every wave finished the previous chunk's epilogue (reads b2s)
-    if (euclidean) {  // |b|^2 of this chunk's centroids, ascending-k fma chain
-      const int c = c0 + threadIdx.x;
-      float s = 0.f;
-      if (threadIdx.x < nc)
-        for (int k = 0; k < d; ++k) {
-          const float y = Bb[(int64_t)k * n + c];
-          s = fmaf(y, y, s);
-        }
-      b2s[threadIdx.x] = s;
-    }
+    const bool cv = (int)threadIdx.x < nc;  // this thread's centroid column of the chunk exists
+    const float* __restrict__ Bc = Bb + c0 + (cv ? (int)threadIdx.x : 0);
+    float rs[kMsKC];       // staged slab: row u, column threadIdx.x
+    float xc[kMsKC / 2], xn[kMsKC / 2];
+    auto load_slab = [&](int kb) {
+      const float* __restrict__ p = Bc + (int64_t)kb * n;  // one running pointer, not 16 addresses
+#pragma unroll
+      for (int u = 0; u < kMsKC; ++u) {
+        rs[u] = (cv && kb + u < d) ? *p : 0.f;
+        p += n;
+      }
+    };
+    auto store_slab = [&](float* dst) {
+#pragma unroll
+      for (int u = 0; u < kMsKC; ++u) dst[u * kMsCent + threadIdx.x] = rs[u];
+    };
+    auto load_x = [&](int kb, float (&x)[kMsKC / 2]) {
+      const float* __restrict__ p = Ab + (int64_t)(kb + half) * m;
+#pragma unroll
+      for (int j = 0; j < kMsKC / 2; ++j) {
+        x[j] = (iv && kb + 2 * j + half < d) ? *p : 0.f;  // B operand [k][col=point]
+        p += 2 * (int64_t)m;
+      }
+    };
+    // |b|^2 of the chunk's centroids comes for free: thread t stages column t of every slab, in
+    // ascending k, so the squares of what it stages form the ascending-k fma chain of centroid t
+    float bsq = 0.f;
+    auto square_slab = [&]() {
+#pragma unroll
+      for (int u = 0; u < kMsKC; ++u) bsq = fmaf(rs[u], rs[u], bsq);
+    };
+    load_slab(0);
+    load_x(0, xc);
+    __syncthreads();  // every wave finished the previous chunk (reads of cs and b2s)
+    square_slab();
+    if (n_slabs == 1) b2s[threadIdx.x] = bsq;
+    store_slab(cs);
     f32x16 acc[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    __syncthreads();
 
-    for (int kb = 0; kb < d; kb += kMsKC) {
-      __syncthreads();  // previous cs consumers done (also orders b2s)
-      for (int e = threadIdx.x; e < kMsKC * kMsCent; e += 256) {
-        const int kk = e >> 8, cc = e & 255;
-        const int k = kb + kk;
-        cs[e] = (k < d && cc < nc) ? Bb[(int64_t)k * n + c0 + cc] : 0.f;
+    for (int sb = 0; sb < n_slabs; ++sb) {
+      const float* cur = cs + (sb & 1) * kMsSlab;
+      const bool more = sb + 1 < n_slabs;
+      if (more) {
+        load_slab((sb + 1) * kMsKC);
+        load_x((sb + 1) * kMsKC, xn);
       }
-      __syncthreads();
-      const int kend = (d - kb) < kMsKC ? (d - kb) : kMsKC;
-      for (int kk = 0; kk < kend; kk += 2) {
-        const int k = kb + kk + half;
-        const float x = (iv && k < d) ? Ab[(int64_t)k * m + i] : 0.f;  // B operand [k][col=point]
-        const float* crow = cs + (kk + half) * kMsCent + l31;          // A operand [row=centroid][k]
+      // (rows beyond the chunk's last centroid are staged as zeros and masked in the epilogue, so
+      // all 8 row tiles are always multiplied: no per-MFMA predicate in the hot loop)
+#pragma unroll
+      for (int j = 0; j < kMsKC / 2; ++j) {
+        const float* crow = cur + (2 * j + half) * kMsCent + l31;  // A operand [row=centroid][k]
 #pragma unroll
         for (int t = 0; t < 8; ++t)
-          if (t < nt) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(crow[t * 32], x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(crow[t * 32], xc[j], acc[t], 0, 0, 0);
       }
+      if (more) {
+        square_slab();
+        if (sb + 2 == n_slabs) b2s[threadIdx.x] = bsq;  // the chain is complete
+        store_slab(cs + ((sb + 1) & 1) * kMsSlab);
+#pragma unroll
+        for (int j = 0; j < kMsKC / 2; ++j) xc[j] = xn[j];
+      }
+      __syncthreads();
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
@@ -115,8 +172,8 @@ __global__ __launch_bounds__(256) void max_sim_kernel(const float* __restrict__ 
     besti = oi;
   }
   if (half == 0 && iv) {
-    vals[(int64_t)b * m + i] = best;
-    inds[(int64_t)b * m + i] = besti;
+    vals[(int64_t)b * m + blockIdx.x * 128 + wave * 32 + l31] = best;
+    inds[(int64_t)b * m + blockIdx.x * 128 + wave * 32 + l31] = besti;
   }
 }
 
@@ -496,7 +553,9 @@ extern "C" int tpq_max_sim(const float* A, const float* B, float* vals, int64_t*
   const int euclid = metric == TPQ_METRIC_NEG_SQ_L2 ? 1 : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // centroids resident in LDS, 256 at a time (one launch per chunk; PQ codebooks need one)
-  if (d <= 128 && n <= 65536) {
+  // (beyond one chunk of centroids the double-buffered generic kernel wins from d > 64 on:
+  // 1 M x 1024: d=64 84 vs 62 TF/s, d=96 47 vs 71, d=128 60 vs 78)
+  if (d <= 128 && n <= 65536 && (n <= 256 || d <= 64)) {
     const int dh = (d + 1) / 2;
     if (dh <= 1) return launch_codebook<1>(A, B, vals, inds, l, d, m, n, euclid, st);
     if (dh <= 2) return launch_codebook<2>(A, B, vals, inds, l, d, m, n, euclid, st);
@@ -506,8 +565,13 @@ extern "C" int tpq_max_sim(const float* A, const float* B, float* vals, int64_t*
     if (dh <= 32) return launch_codebook<32>(A, B, vals, inds, l, d, m, n, euclid, st);
     return launch_codebook<64>(A, B, vals, inds, l, d, m, n, euclid, st);
   }
-  hipLaunchKernelGGL(max_sim_kernel, dim3((m + 127) / 128, l), dim3(256), 0, st, A, B, vals, inds,
-                     d, m, n, euclid);
+  const size_t ms_lds = (size_t)(2 * kMsSlab + kMsCent) * sizeof(float);
+  int rc_attr = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(max_sim_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ms_lds),
+                          "max_sim_kernel attr");
+  if (rc_attr) return rc_attr;
+  hipLaunchKernelGGL(max_sim_kernel, dim3((m + 127) / 128, l), dim3(256), ms_lds, st, A, B, vals,
+                     inds, d, m, n, euclid);
   TPQ_LAUNCH_CHECK("max_sim_kernel");
   return TPQ_OK;
 }
