@@ -42,20 +42,34 @@ __global__ __launch_bounds__(kSelWaves * 64) void topk_select_kernel(const float
   sel.init(qv + wave * 64, qi + wave * 64, k);
   const float* __restrict__ xr = x + (int64_t)row * cols;
   const float ra2 = a2 ? a2[row] : 0.f;
-  for (int base = 0; base < cols; base += 64) {
-    const int c = base + lane;
-    const bool valid = c < cols;
-    float v = -INFINITY;
-    if (valid) {
-      v = xr[c];
-      if (a2) {
-        v = 2.f * v;
-        v = v - ra2;
-        v = v - b2[c];
-      }
-      v = v + 0.0f;  // -0.0 -> +0.0 (key order)
+  // kSelAhead 64-column groups are loaded before any of them is pushed: with one load per
+  // iteration a wave waits out a full memory latency per 256 bytes (1.9 TB/s on a
+  // [10 000 x 16 384] matrix); 16 waves x 4 KiB in flight per CU cover the latency
+  constexpr int kSelAhead = 16;
+  for (int base = 0; base < cols; base += 64 * kSelAhead) {
+    float va[kSelAhead];
+#pragma unroll
+    for (int u = 0; u < kSelAhead; ++u) {
+      const int c = base + 64 * u + lane;
+      va[u] = c < cols ? xr[c] : -INFINITY;
     }
-    sel.push(valid && (v >= sel.tau), v, c);
+#pragma unroll
+    for (int u = 0; u < kSelAhead; ++u) {
+      const int c = base + 64 * u + lane;
+      if (base + 64 * u < cols) {  // wave-uniform
+        const bool valid = c < cols;
+        float v = va[u];
+        if (valid) {
+          if (a2) {
+            v = 2.f * v;
+            v = v - ra2;
+            v = v - b2[c];
+          }
+          v = v + 0.0f;  // -0.0 -> +0.0 (key order)
+        }
+        sel.push(valid && (v >= sel.tau), v, c);
+      }
+    }
   }
   sel.flush();
 #pragma unroll
@@ -152,18 +166,142 @@ __global__ __launch_bounds__(256) void id_by_address_kernel(const int64_t* __res
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Coarse similarities sims[q][c] = 2 x_q.C_c - |x_q|^2 - |C_c|^2 (metric.negative_squared_l2_distance,
-// torchpq/metric.py:31-98: library GEMM + three element-wise passes) as one fp32-MFMA kernel.
-// Block = 64 queries x 256 centroids, wave = 32 x 128 (four 32x32 accumulator tiles on
-// v_mfma_f32_32x32x2_f32).  Operands are staged through LDS in k-batches of 16, double-buffered
-// (global -> registers one batch ahead -> LDS), so each element is fetched once per block with
-// coalesced row loads and the MFMA operands come from conflict-free LDS reads; the norms are
-// accumulated from the operand registers on the way (even-k chain + odd-k chain), epilogue in the
-// reference's rounding order.  In the reference's own benchmark grid (IVF4096 / IVF16384, n_probe
-// 1..128) this step is 50-85 % of a search, not the scan.
-// x [d][nq], C [d][n_cells] -> sims [nq][n_cells]
+// torchpq/metric.py:31-98: library GEMM + three element-wise passes) as one fp32-MFMA kernel, built
+// like max_sim_kernel (kmeans.hip): a block owns 128 centroids (4 waves x 32 MFMA columns, operand
+// in registers, prefetched one k-slab ahead) and walks query chunks of 256 MFMA rows whose 16-row
+// k-slabs are double-buffered in LDS (global -> registers while the previous slab's 8 x 8 MFMAs
+// run -> the other buffer, one barrier per slab).  |x|^2 is accumulated from the values each
+// thread stages (its query, every slab, ascending k), |C|^2 by each lane for its own centroid;
+// epilogue in the reference's rounding order; the stores of a half-wave cover 128 contiguous bytes
+// of a sims row.  In the reference's own benchmark grid (IVF4096 / IVF16384, n_probe 1..128) this
+// step is 40-85 % of a search, not the scan.
+// x [d][nq], C [d][n_cells] -> sims [nq][n_cells];  grid (ceil(n_cells/128), query-chunk groups)
+constexpr int kCsRows = 256;  // queries per chunk (8 MFMA row tiles)
+constexpr int kCsKC = 16;     // k rows per LDS slab
+constexpr int kCsSlab = kCsKC * kCsRows;
+
+__global__ __launch_bounds__(256, 2) void coarse_sims_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ C,
+                                                            float* __restrict__ sims, int d, int nq,
+                                                            int n_cells, int chunks_per_block) {
+  __shared__ float qs[2 * kCsSlab];  // [2][kCsKC][kCsRows]
+  __shared__ float q2s[kCsRows];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int c = blockIdx.x * 128 + wave * 32 + l31;  // this lane's centroid
+  const bool cvalid = c < n_cells;
+  const float* __restrict__ Cc = C + (cvalid ? c : 0);
+
+  float c2 = 0.f;  // |C_c|^2, one ascending-k chain, 16 loads in flight per step
+  {
+    const float* __restrict__ p = Cc;
+    int k = 0;
+    for (; k + 16 <= d; k += 16) {
+      float y[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) y[u] = p[(int64_t)u * n_cells];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) c2 = fmaf(y[u], y[u], c2);
+      p += 16 * (int64_t)n_cells;
+    }
+    for (; k < d; ++k) {
+      c2 = fmaf(*p, *p, c2);
+      p += n_cells;
+    }
+  }
+
+  const int n_slabs = (d + kCsKC - 1) / kCsKC;
+  const int chunk0 = blockIdx.y * chunks_per_block;
+  for (int ch = chunk0; ch < chunk0 + chunks_per_block; ++ch) {
+    const int q0 = ch * kCsRows;
+    if (q0 >= nq) break;
+    const int nr = (nq - q0) < kCsRows ? (nq - q0) : kCsRows;
+    const bool qv = (int)threadIdx.x < nr;  // this thread's query row of the chunk exists
+    const float* __restrict__ xq = x + q0 + (qv ? (int)threadIdx.x : 0);
+    float rs[kCsKC], yc[kCsKC / 2], yn[kCsKC / 2];
+    float qsq = 0.f;
+    auto load_slab = [&](int kb) {
+      const float* __restrict__ p = xq + (int64_t)kb * nq;
+#pragma unroll
+      for (int u = 0; u < kCsKC; ++u) {
+        rs[u] = (qv && kb + u < d) ? *p : 0.f;
+        p += nq;
+      }
+    };
+    auto square_slab = [&]() {
+#pragma unroll
+      for (int u = 0; u < kCsKC; ++u) qsq = fmaf(rs[u], rs[u], qsq);
+    };
+    auto store_slab = [&](float* dst) {
+#pragma unroll
+      for (int u = 0; u < kCsKC; ++u) dst[u * kCsRows + threadIdx.x] = rs[u];
+    };
+    auto load_y = [&](int kb, float (&y)[kCsKC / 2]) {
+      const float* __restrict__ p = Cc + (int64_t)(kb + half) * n_cells;
+#pragma unroll
+      for (int j = 0; j < kCsKC / 2; ++j) {
+        y[j] = (cvalid && kb + 2 * j + half < d) ? *p : 0.f;
+        p += 2 * (int64_t)n_cells;
+      }
+    };
+    load_slab(0);
+    load_y(0, yc);
+    __syncthreads();  // every wave finished the previous chunk (reads of qs and q2s)
+    square_slab();
+    if (n_slabs == 1) q2s[threadIdx.x] = qsq;
+    store_slab(qs);
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    __syncthreads();
+    for (int sb = 0; sb < n_slabs; ++sb) {
+      const float* cur = qs + (sb & 1) * kCsSlab;
+      const bool more = sb + 1 < n_slabs;
+      if (more) {
+        load_slab((sb + 1) * kCsKC);
+        load_y((sb + 1) * kCsKC, yn);
+      }
+#pragma unroll
+      for (int j = 0; j < kCsKC / 2; ++j) {
+        const float* qrow = cur + (2 * j + half) * kCsRows + l31;  // A operand [row=query][k]
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[t * 32], yc[j], acc[t], 0, 0, 0);
+      }
+      if (more) {
+        square_slab();
+        if (sb + 2 == n_slabs) q2s[threadIdx.x] = qsq;
+        store_slab(qs + ((sb + 1) & 1) * kCsSlab);
+#pragma unroll
+        for (int j = 0; j < kCsKC / 2; ++j) yc[j] = yn[j];
+      }
+      __syncthreads();
+    }
+    if (cvalid) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (row < nr) {
+            float v = 2.f * acc[t][r];
+            v = v - q2s[row];
+            v = v - c2;
+            sims[(int64_t)(q0 + row) * n_cells + c] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// Small problems (few centroid groups x query chunks): 64-query x 256-centroid tiles, both
+// operands through LDS in double-buffered k-batches of 16 -- twice the blocks of the kernel above.
 constexpr int kCsKB = 16;
 
-__global__ __launch_bounds__(256) void coarse_sims_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(256) void coarse_sims_small_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ C,
                                                          float* __restrict__ sims, int d, int nq,
                                                          int n_cells) {
@@ -324,8 +462,20 @@ extern "C" int tpq_ivfpq_coarse_probe(const float* query, const float* centroids
     return TPQ_ERR_WORKSPACE;
   }
   float* sims = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(coarse_sims_kernel, dim3((nq + 63) / 64, (n_cells + 255) / 256), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), query, centroids, sims, d, nq, n_cells);
+  // blocks = centroid groups of 128 x query-chunk groups; a block walks several 256-query chunks
+  // once there are enough blocks to fill the chip a few times over
+  const int cgroups = (n_cells + 127) / 128, chunks = (nq + kCsRows - 1) / kCsRows;
+  if ((long long)cgroups * chunks < 512) {  // too few big blocks to fill 256 CUs twice over
+    hipLaunchKernelGGL(coarse_sims_small_kernel, dim3((nq + 63) / 64, (n_cells + 255) / 256),
+                       dim3(256), 0, reinterpret_cast<hipStream_t>(stream), query, centroids, sims,
+                       d, nq, n_cells);
+  } else {
+    int per_block = (int)(((long long)cgroups * chunks) / 1024);
+    per_block = per_block < 1 ? 1 : (per_block > 8 ? 8 : per_block);
+    hipLaunchKernelGGL(coarse_sims_kernel, dim3(cgroups, (chunks + per_block - 1) / per_block),
+                       dim3(256), 0, reinterpret_cast<hipStream_t>(stream), query, centroids, sims,
+                       d, nq, n_cells, per_block);
+  }
   TPQ_LAUNCH_CHECK("coarse_sims_kernel");
   ProbeEpilogue pe{cell_start_tbl, cell_size_tbl, cell_start, cell_size, n_probe_list,
                    smart_temperature > 0.f ? 1.0f / smart_temperature : 0.f};
