@@ -54,7 +54,7 @@ struct ProbeTable {  // lives in LDS
 // wave 0 fills the probe table; cells whose start equals the previous probe's start are
 // skipped (ivfpq_topk.cu:864-866)
 __device__ __forceinline__ void build_probe_table(const ScanArgs& a, int q, int n_probe,
-                                                  ProbeTable t) {
+                                                  ProbeTable t, int tile_shift = 6) {
   const int lane = lane_id();
   int running = 0;
   for (int base = 0; base < n_probe; base += 64) {
@@ -66,7 +66,7 @@ __device__ __forceinline__ void build_probe_table(const ScanArgs& a, int q, int 
       if (p > 0 && a.cell_start[(int64_t)q * a.max_nprobe + p - 1] == (int64_t)st) sz = 0;
       if (sz < 0) sz = 0;
     }
-    int tiles = (sz + 63) >> 6;
+    int tiles = (sz + (1 << tile_shift) - 1) >> tile_shift;
     int incl = tiles;  // inclusive wave scan
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -502,6 +502,13 @@ __device__ __forceinline__ void finalize_and_write(const ScanArgs& a, int q, con
 // waves per workgroup: 8 while two workgroups share a CU (LUT <= 64 KiB); 16 when the LUT is so
 // large that only one workgroup fits (m > 64, e.g. GIST m=120: 120 KiB) -- same 16 waves per CU
 constexpr int packed_waves(int M) { return M <= 64 ? 8 : 16; }
+// Short codes are instruction-bound, not bandwidth-bound (~61 + 3.4 m cycles per 64-slot
+// tile per CU, the 61 being table walk, address arithmetic, exec-mask handling, threshold poll and
+// ballot): a lane therefore takes S slots (64 apart) per iteration and pays that part once.
+// (measured, 10 000 queries x 32 probes: m=4 +18 %, 8 +16 %, 12 +12 %, 16 +9 %, 20 +10 %, 24 +10 %;
+// neutral from m=28 on, where one slot per lane is kept)
+constexpr int packed_slots(int M) { return M <= 8 ? 4 : (M <= 24 ? 2 : 1); }
+constexpr int packed_tile_shift(int M) { return M <= 8 ? 8 : (M <= 24 ? 7 : 6); }
 
 // per-wave scratch of the end-of-query exact re-evaluation: un-permute rows of M/4+1 dwords,
 // 16 per pass (8 when the LUT leaves little LDS: m > 64)
@@ -556,7 +563,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
   if (threadIdx.x < M) jmax[threadIdx.x] = 0u;
   __syncthreads();
   if (wave == 0) {
-    build_probe_table(a, q, n_probe, tab);
+    build_probe_table(a, q, n_probe, tab, packed_tile_shift(M));
     if (lane == 0) {
       *tau_key = f2key(-INFINITY);
       *tile_ctr = 0;
@@ -638,83 +645,191 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
     }
   };
 
-  struct Tile {
-    int s;
-    bool valid;
-    float add;  // RES: base_p + slot_term[s]
-  };
-  int p = 0;
-  auto locate = [&](int T) -> Tile {
-    while (T >= tab.tile_begin[p + 1]) ++p;
-    const int off = ((T - tab.tile_begin[p]) << 6) + lane;
-    Tile t{tab.start[p] + off, off < tab.size[p], 0.f};
-    if constexpr (RES) {
-      if (t.valid) t.add = pbase[p] + ra.slot_term[t.s];
-    }
-    return t;
-  };
-  auto consume = [&](const typename L::chunk_t(&w)[L::kChunks], const Tile& t) {
-    float v = 0.f;
-    bool live = t.valid;
-    if (t.valid) {
-      if (a.is_empty) live = (a.is_empty[t.s] == 0);
-      v = L::accumulate(w, t.s, lut);
-      if constexpr (RES) v += t.add;
-    }
-    refresh_tau();
-    const float tau_before = sel.tau;
-    const int flushes_before = sel.n_flush;
-    sel.push(live && (v >= sel.tau - delta2), v, t.s);
-    if (sel.n_flush != flushes_before) publish(tau_before);
-  };
-
-  // software pipeline: the codes of tile T+NW are in flight while tile T is being consumed
-  // (m <= 64; larger m runs 16 waves per workgroup under a 128-VGPR cap and relies on them)
-  if constexpr (M <= 64) {
-    typename L::chunk_t w0[L::kChunks], w1[L::kChunks];
-    Tile m0{0, false, 0.f}, m1{0, false, 0.f};
-    int T = t_begin + wave;
-    if (T < t_end) {
-      m0 = locate(T);
-      if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
-    }
-    while (T < t_end) {
-      int Tn = T + NW;
-      if (Tn < t_end) {
-        m1 = locate(Tn);
-        if (m1.valid) L::load(a.packed, a.n_slots, m1.s, w1);
+  if constexpr (packed_slots(M) == 1) {
+    struct Tile {
+      int s;
+      bool valid;
+      float add;  // RES: base_p + slot_term[s]
+    };
+    int p = 0;
+    auto locate = [&](int T) -> Tile {
+      while (T >= tab.tile_begin[p + 1]) ++p;
+      const int off = ((T - tab.tile_begin[p]) << 6) + lane;
+      Tile t{tab.start[p] + off, off < tab.size[p], 0.f};
+      if constexpr (RES) {
+        if (t.valid) t.add = pbase[p] + ra.slot_term[t.s];
       }
-      consume(w0, m0);
-      T = Tn;
-      if (T >= t_end) break;
-      Tn = T + NW;
-      if (Tn < t_end) {
-        m0 = locate(Tn);
+      return t;
+    };
+    auto consume = [&](const typename L::chunk_t(&w)[L::kChunks], const Tile& t) {
+      float v = 0.f;
+      bool live = t.valid;
+      if (t.valid) {
+        if (a.is_empty) live = (a.is_empty[t.s] == 0);
+        v = L::accumulate(w, t.s, lut);
+        if constexpr (RES) v += t.add;
+      }
+      refresh_tau();
+      const float tau_before = sel.tau;
+      const int flushes_before = sel.n_flush;
+      sel.push(live && (v >= sel.tau - delta2), v, t.s);
+      if (sel.n_flush != flushes_before) publish(tau_before);
+    };
+
+    // software pipeline: the codes of tile T+NW are in flight while tile T is being consumed
+    // (m <= 64; larger m runs 16 waves per workgroup under a 128-VGPR cap and relies on them)
+    if constexpr (M <= 64) {
+      typename L::chunk_t w0[L::kChunks], w1[L::kChunks];
+      Tile m0{0, false, 0.f}, m1{0, false, 0.f};
+      int T = t_begin + wave;
+      if (T < t_end) {
+        m0 = locate(T);
         if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
       }
-      consume(w1, m1);
-      T = Tn;
+      while (T < t_end) {
+        int Tn = T + NW;
+        if (Tn < t_end) {
+          m1 = locate(Tn);
+          if (m1.valid) L::load(a.packed, a.n_slots, m1.s, w1);
+        }
+        consume(w0, m0);
+        T = Tn;
+        if (T >= t_end) break;
+        Tn = T + NW;
+        if (Tn < t_end) {
+          m0 = locate(Tn);
+          if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
+        }
+        consume(w1, m1);
+        T = Tn;
+      }
+    } else {
+      // One 16-wave workgroup per CU and one tile in flight per wave: with a static deal the waves
+      // drift apart (the oldest wave of a SIMD wins the issue arbitration), the early finishers
+      // idle at the end-of-query barrier and the stragglers run alone, latency-bound -- 37-41 % of
+      // the workgroup's life at m = 120.  Tiles are therefore handed out from an LDS counter (one
+      // integer atomic per tile, fetched while the previous tile is consumed); a wave's tile
+      // indices still increase, which is all locate() needs.
+      auto grab = [&]() -> int {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(tile_ctr, 1);
+        return t_begin + __builtin_amdgcn_readfirstlane(t);
+      };
+      typename L::chunk_t w0[L::kChunks];
+      int T = grab();
+      while (T < t_end) {
+        const Tile m0 = locate(T);
+        if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
+        const int Tn = grab();
+        consume(w0, m0);
+        T = Tn;
+      }
     }
   } else {
-    // One 16-wave workgroup per CU and one tile in flight per wave: with a static deal the waves
-    // drift apart (the oldest wave of a SIMD wins the issue arbitration), the early finishers
-    // idle at the end-of-query barrier and the stragglers run alone, latency-bound -- 37-41 % of
-    // the workgroup's life at m = 120.  Tiles are therefore handed out from an LDS counter (one
-    // integer atomic per tile, fetched while the previous tile is consumed); a wave's tile
-    // indices still increase, which is all locate() needs.
-    auto grab = [&]() -> int {
-      int t = 0;
-      if (lane == 0) t = atomicAdd(tile_ctr, 1);
-      return t_begin + __builtin_amdgcn_readfirstlane(t);
+    constexpr int S = packed_slots(M);          // slots per lane per tile, 64 apart
+    constexpr int TS = packed_tile_shift(M);    // log2(slots per tile)
+    struct Tile {
+      int s;      // the lane's first slot; its u-th slot is s + 64 u
+      int rem;    // slots of the cell from s on: the u-th slot exists iff 64 u < rem
+      float add;  // RES: base_p (slot_term is added per slot)
     };
-    typename L::chunk_t w0[L::kChunks];
-    int T = grab();
-    while (T < t_end) {
-      const Tile m0 = locate(T);
-      if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
-      const int Tn = grab();
-      consume(w0, m0);
-      T = Tn;
+    int p = 0;
+    auto locate = [&](int T) -> Tile {
+      while (T >= tab.tile_begin[p + 1]) ++p;
+      const int off = ((T - tab.tile_begin[p]) << TS) + lane;
+      Tile t{tab.start[p] + off, tab.size[p] - off, 0.f};
+      if constexpr (RES) t.add = pbase[p];
+      return t;
+    };
+    auto load_tile = [&](const Tile& t, typename L::chunk_t (&w)[S][L::kChunks], float (&term)[S]) {
+  #pragma unroll
+      for (int u = 0; u < S; ++u) {
+        if (64 * u < t.rem) {
+          L::load(a.packed, a.n_slots, t.s + 64 * u, w[u]);
+          if constexpr (RES) term[u] = ra.slot_term[t.s + 64 * u];
+        }
+      }
+    };
+    auto consume = [&](const typename L::chunk_t (&w)[S][L::kChunks], const float (&term)[S],
+                       const Tile& t) {
+      float v[S];
+      bool live[S];
+  #pragma unroll
+      for (int u = 0; u < S; ++u) {
+        v[u] = 0.f;
+        live[u] = 64 * u < t.rem;
+        if (live[u]) {
+          if (a.is_empty) live[u] = (a.is_empty[t.s + 64 * u] == 0);
+          v[u] = L::accumulate(w[u], t.s + 64 * u, lut);
+          if constexpr (RES) v[u] += t.add + term[u];
+        }
+      }
+      refresh_tau();
+      if constexpr (S > 1) {
+        bool any = false;
+  #pragma unroll
+        for (int u = 0; u < S; ++u) any = any || (live[u] && (v[u] >= sel.tau - delta2));
+        if (__ballot(any) == 0ull) return;  // the common case: one ballot for S x 64 slots
+      }
+  #pragma unroll
+      for (int u = 0; u < S; ++u) {
+        const float tau_before = sel.tau;
+        const int flushes_before = sel.n_flush;
+        sel.push(live[u] && (v[u] >= sel.tau - delta2), v[u], t.s + 64 * u);
+        if (sel.n_flush != flushes_before) publish(tau_before);
+      }
+    };
+
+    // software pipeline: the codes of tile T+NW are in flight while tile T is being consumed
+    // (m <= 64; larger m runs 16 waves per workgroup under a 128-VGPR cap and relies on them)
+    if constexpr (M <= 64) {
+      typename L::chunk_t w0[S][L::kChunks], w1[S][L::kChunks];
+      float r0[S] = {}, r1[S] = {};
+      Tile m0{0, 0, 0.f}, m1{0, 0, 0.f};
+      int T = t_begin + wave;
+      if (T < t_end) {
+        m0 = locate(T);
+        load_tile(m0, w0, r0);
+      }
+      while (T < t_end) {
+        int Tn = T + NW;
+        if (Tn < t_end) {
+          m1 = locate(Tn);
+          load_tile(m1, w1, r1);
+        }
+        consume(w0, r0, m0);
+        T = Tn;
+        if (T >= t_end) break;
+        Tn = T + NW;
+        if (Tn < t_end) {
+          m0 = locate(Tn);
+          load_tile(m0, w0, r0);
+        }
+        consume(w1, r1, m1);
+        T = Tn;
+      }
+    } else {
+      // One 16-wave workgroup per CU and one tile in flight per wave: with a static deal the waves
+      // drift apart (the oldest wave of a SIMD wins the issue arbitration), the early finishers
+      // idle at the end-of-query barrier and the stragglers run alone, latency-bound -- 37-41 % of
+      // the workgroup's life at m = 120.  Tiles are therefore handed out from an LDS counter (one
+      // integer atomic per tile, fetched while the previous tile is consumed); a wave's tile
+      // indices still increase, which is all locate() needs.
+      auto grab = [&]() -> int {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(tile_ctr, 1);
+        return t_begin + __builtin_amdgcn_readfirstlane(t);
+      };
+      typename L::chunk_t w0[S][L::kChunks];
+      float r0[S] = {};
+      int T = grab();
+      while (T < t_end) {
+        const Tile m0 = locate(T);
+        load_tile(m0, w0, r0);
+        const int Tn = grab();
+        consume(w0, r0, m0);
+        T = Tn;
+      }
     }
   }
   TPQ_PROF(a, blockIdx.x, 4);

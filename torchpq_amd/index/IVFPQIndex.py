@@ -16,10 +16,12 @@ from ..kernels import CoarseProbeHip, CoarseSelectHip, SmartProbingHip
 
 
 class IVFPQIndex(CellContainer):
-    # plain (non-residual) search: below this many sub-quantizers the two code layouts scan within
-    # +-7 % of each other (the per-tile selection work dominates, not the LDS look-ups), so the
-    # second copy of the codes is not kept; the residual scan uses the scan layout at every m
+    # plain (non-residual) search keeps the scan-layout copy of the codes where it pays: long codes
+    # (m >= 56: bank-conflict-free look-ups, 1.2-1.7x) and short ones (m <= 24: several slots per
+    # lane per iteration, 1.1-1.25x); in between the two layouts scan within +-2 % of each other and
+    # the copy is not kept.  The residual scan uses the scan layout at every m.
     packed_min_subvectors = 56
+    packed_max_short_subvectors = 24
 
     def __init__(self, d_vector, n_subvectors=8, n_cells=128, initial_size=None,
                  expand_step_size=128, expand_mode="double", distance="euclidean",
@@ -327,7 +329,9 @@ class IVFPQIndex(CellContainer):
         packed = None
         if self.use_packed_layout:
             from ..kernels import PACKED_M
-            if self.n_subvectors in PACKED_M and self.n_subvectors >= self.packed_min_subvectors:
+            if self.n_subvectors in PACKED_M and (
+                    self.n_subvectors >= self.packed_min_subvectors
+                    or self.n_subvectors <= self.packed_max_short_subvectors):
                 packed = self.packed_storage()
         # the fused path re-reads the codebook (m*ds KiB, L2-resident) per workgroup instead of a
         # 1-KiB-per-sub-quantizer LUT row from HBM: a win while the sub-vectors are short
