@@ -207,11 +207,12 @@ def main():
         "value": round(args.nq * args.steps * world / dt, 1), "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u8 codes / f32 LUT+distances",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (SIFT1M-shaped: non-negative integer-valued clustered fp32)",
         "config": {"workload": f"SIFT1M-like d={args.d} n={args.n_base} IVFPQ n_cells={args.n_cells} "
                                f"m={args.m} nprobe={args.n_probe} k={args.k} on 1xMI355X per rank",
                    "n_query_per_rank": args.nq, "code_layout": args.layout,
+                   "codes": "u8 (8-bit PQ)", "arithmetic": "f32 LUT entries, f32 sums, exact ids",
                    "use_smart_probing": False, "parallelism": f"query-sharded x{world}, replicated index"},
         "roofline": roofline,
     }
