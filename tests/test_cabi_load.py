@@ -59,7 +59,8 @@ def test_torchpq_import_alias():
     this package (CPU: names only)."""
     import sys
     import torchpq_amd.compat as compat
-    assert "torchpq" not in sys.modules
+    # (the live-pin test may have imported the real reference into this process: set it aside)
+    parked = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "torchpq" or k.startswith("torchpq.")}
     compat.install_as_torchpq()
     try:
         from torchpq.index import IVFPQIndex
@@ -79,3 +80,4 @@ def test_torchpq_import_alias():
     finally:
         compat.uninstall()
     assert "torchpq" not in sys.modules and "torchpq.index" not in sys.modules
+    sys.modules.update(parked)
