@@ -402,30 +402,25 @@ __global__ __launch_bounds__(kScanThreads) void scan_residual_kernel(ScanArgs a,
 // jmax[j] (zeroed by the caller) collects max_c |LUT[j][c]| as the IEEE bit pattern of a
 // non-negative float -- order-preserving as an unsigned, and LDS integer atomics are fast
 // (float ones are not: DESIGN 3.5)
+template <int M>
 __device__ __forceinline__ void stage_lut_blocked(const ScanArgs& a, int q, float* lut,
                                                   int n_threads, unsigned* jmax, const float* xq,
                                                   const float* part1 = nullptr) {
-  // thread handles (j, 4 consecutive c): 16-byte global load, 4 scalar LDS stores.
-  // Consecutive threads take consecutive j for the same c-group so that the LDS stores of a
-  // half-wave land in distinct banks.
+  // thread handles (j, 4 consecutive c): 16-byte global load, 4 scalar LDS stores
   const float4* __restrict__ src = reinterpret_cast<const float4*>(a.lut);
-  const int m = a.m;
-  constexpr int JS = 4, JB = 1 << JS, CB = 64 >> JS;  // 16 x 4 (8 x 8 and 32 x 2 measured slower)
-  const bool tiled = (m & (JB - 1)) == 0;
-  const int jblocks = m >> JS;
+  constexpr int m = M;
+  // a wave-instruction covers JB sub-quantizers x 64/JB consecutive float4: 16 x 4 when m allows
+  // (16 cache lines per load instead of one per lane, at the price of a 2-way bank conflict on the
+  // stores: 1.2 % of the kernel in a same-box A/B; 8 x 8 and 32 x 2 measured slower), 8 x 8 or
+  // 4 x 16 for m = 8 (mod 16) / 4 (mod 8)
+  constexpr int JS = (m & 15) == 0 ? 4 : ((m & 7) == 0 ? 3 : 2);
+  constexpr int JB = 1 << JS, CB = 64 >> JS;
+  constexpr int jblocks = m >> JS;
   for (int i = threadIdx.x; i < m * 64; i += n_threads) {
-    int c4, j;
-    if (tiled) {
-      // a wave-instruction covers 16 sub-quantizers x 4 consecutive float4: 16 cache lines per
-      // load instead of 64 (one per lane), at the price of a 2-way bank conflict on the stores
-      const int g = i >> 6, r = i & 63;
-      const int jb = g % jblocks, cb4 = g / jblocks;
-      j = jb * JB + (r & (JB - 1));
-      c4 = cb4 * CB + (r >> JS);
-    } else {
-      c4 = i / m;
-      j = i - c4 * m;
-    }
+    const int g = i >> 6, r = i & 63;
+    const int jb = g % jblocks, cb4 = g / jblocks;
+    const int j = jb * JB + (r & (JB - 1));
+    const int c4 = cb4 * CB + (r >> JS);
     const float4 x = part1 ? reinterpret_cast<const float4*>(part1)[((int64_t)q * m + j) * 64 + c4]
                      : a.lut ? src[((int64_t)j * a.nq + q) * 64 + c4]
                              : fused_lut4(a, j, c4, xq);
@@ -587,7 +582,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
   TPQ_PROF(a, blockIdx.x, 1);
   const float* part1 = RES ? ra.part1 : nullptr;
   if (!a.lut && !part1) stage_query(a, q, xq, NW * 64);
-  stage_lut_blocked(a, q, lut, NW * 64, jmax, xq, part1);
+  stage_lut_blocked<M>(a, q, lut, NW * 64, jmax, xq, part1);
   float probe_mx = 0.f;
   if constexpr (RES) {
     for (int pp = threadIdx.x; pp < n_probe; pp += NW * 64) {
