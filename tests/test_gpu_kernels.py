@@ -507,7 +507,10 @@ def test_coarse_select_equals_metric_then_select(K):
 
 @pytest.mark.parametrize("d,nq,n_cells,n_probe,smart", [(128, 777, 1024, 32, True), (32, 5, 16, 16, False),
                                                        (960, 70, 300, 64, True), (7, 1, 40, 1, True),
-                                                       (128, 130, 2000, 200, True)])
+                                                       (128, 130, 2000, 200, True),
+                                                       # big enough for the 128-centroid x 256-query GEMM blocks
+                                                       (32, 1100, 16500, 8, True), (24, 1300, 8200, 64, False),
+                                                       (16, 2100, 4100, 300, True)])
 def test_coarse_probe_fused(K, d, nq, n_cells, n_probe, smart):
     """tpq_ivfpq_coarse_probe: sims within fp32 tolerance of the oracle's (float64-accumulated)
     metric, the selection EXACT on the kernel's own sims, extents gathered, probe counts equal to
