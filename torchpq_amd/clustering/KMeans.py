@@ -1,6 +1,5 @@
 """Single k-means problem (mirrors torchpq/clustering/KMeans.py:13-479): the l = 1 case of
 MultiKMeans with 2-D tensors (data [d, n], centroids [d, n_clusters])."""
-import torch
 
 from ..CustomModule import CustomModule
 from .MultiKMeans import MultiKMeans

@@ -4,7 +4,6 @@ The coarse query x cell-centroid product is a plain library GEMM (rocBLAS/hipBLA
 torch.matmul), exactly as the reference uses cuBLAS; the epilogue follows the reference's
 order: ``y = a^T b; y *= 2; y -= |a|^2; y -= |b|^2``.
 """
-import torch
 
 
 def negative_squared_l2_distance(a, b, inplace=False, use_tensor_core=False, scale_mode="none"):
