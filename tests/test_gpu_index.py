@@ -74,6 +74,22 @@ def test_search_on_reference_trained_index(name, smart, packed, request):
         assert (N(i) == gi).mean() > 0.995  # LUT rounding may swap exact near-ties
 
 
+@pytest.mark.parametrize("name", ["fx_tiny", "fx_residual"])
+def test_state_dict_keys_shapes_dtypes_match_reference(name, request):
+    """state_dict interchange: after loading a reference-made state_dict the index
+    saves exactly the reference's keys with the same shapes and dtypes, and the values round-trip."""
+    fx = request.getfixturevalue(name)
+    kw = {"pq_use_residual": True} if name == "fx_residual" else {}
+    idx = _index_from_fixture(fx, **kw)
+    ref = {k[3:]: v for k, v in fx.items() if k.startswith("sd.")}
+    mine = {k: v for k, v in idx.state_dict().items() if v is not None}
+    assert set(mine) == set(ref), set(mine) ^ set(ref)
+    for k, v in ref.items():
+        got = N(mine[k])
+        assert got.shape == v.shape and got.dtype == v.dtype, (k, got.shape, v.shape, got.dtype, v.dtype)
+        assert np.array_equal(got, v), k
+
+
 def test_train_add_search_end_to_end_recall():
     from torchpq_amd.index import IVFPQIndex
     rng = np.random.default_rng(0)
