@@ -16,6 +16,16 @@ constexpr int kSelWaves = 4;
 // Optional coarse-probe epilogue (tpq_ivfpq_coarse_probe): the selected columns are cells, so the
 // same wave also gathers their list extents (IVFPQIndex.search_cells, index/IVFPQIndex.py:425-426)
 // and derives the per-query probe count (smart probing :499-512, or all of them).
+// Optional two-level select: gmax[row][g] = max of the row over columns [128 g, 128 g + 128) (written
+// by coarse_sims_kernel).  The k-th largest group maximum is a lower bound of the k-th largest
+// element (the k largest group maxima are k distinct elements), so only groups whose maximum
+// reaches it can hold a member of the top-k: with n_probe = 8 of 16 384 cells the row select reads
+// ~8 % of the row.  The result is the same total order (value desc, column asc) as the full scan.
+struct GroupFilter {
+  const float* gmax;  // [rows][n_groups]; nullptr = scan every column
+  int n_groups;
+};
+
 struct ProbeEpilogue {
   const int64_t* cell_start_tbl;  // [cols]; nullptr = no epilogue
   const int64_t* cell_size_tbl;
@@ -32,7 +42,7 @@ __global__ __launch_bounds__(kSelWaves * 64) void topk_select_kernel(const float
                                                                     float* __restrict__ vals,
                                                                     int64_t* __restrict__ idx,
                                                                     int rows, int cols, int k,
-                                                                    ProbeEpilogue pe) {
+                                                                    ProbeEpilogue pe, GroupFilter gf) {
   __shared__ float qv[kSelWaves * 64];
   __shared__ int qi[kSelWaves * 64];
   const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -42,32 +52,77 @@ __global__ __launch_bounds__(kSelWaves * 64) void topk_select_kernel(const float
   sel.init(qv + wave * 64, qi + wave * 64, k);
   const float* __restrict__ xr = x + (int64_t)row * cols;
   const float ra2 = a2 ? a2[row] : 0.f;
-  // kSelAhead 64-column groups are loaded before any of them is pushed: with one load per
-  // iteration a wave waits out a full memory latency per 256 bytes (1.9 TB/s on a
-  // [10 000 x 16 384] matrix); 16 waves x 4 KiB in flight per CU cover the latency
-  constexpr int kSelAhead = 16;
-  for (int base = 0; base < cols; base += 64 * kSelAhead) {
-    float va[kSelAhead];
-#pragma unroll
-    for (int u = 0; u < kSelAhead; ++u) {
-      const int c = base + 64 * u + lane;
-      va[u] = c < cols ? xr[c] : -INFINITY;
+  if (gf.gmax) {
+    // phase 1: the k-th largest group maximum
+    const float* __restrict__ gm = gf.gmax + (int64_t)row * gf.n_groups;
+    for (int base = 0; base < gf.n_groups; base += 64) {
+      const int g = base + lane;
+      const float v = g < gf.n_groups ? gm[g] + 0.0f : -INFINITY;
+      sel.push(g < gf.n_groups && (v >= sel.tau), v, g);
     }
+    sel.flush();
+    const float tau0 = sel.top.kth_value(k);  // -inf while there are fewer than k groups
+    sel.init(qv + wave * 64, qi + wave * 64, k);
+    // phase 2: only the groups that can hold a member of the top-k, four (eight loads) at a time
+    for (int base = 0; base < gf.n_groups; base += 64) {
+      const int g = base + lane;
+      const bool hot = g < gf.n_groups && (gm[g] >= tau0);
+      unsigned long long mask = __ballot(hot);
+      while (mask != 0ull) {
+        int gs[4];
 #pragma unroll
-    for (int u = 0; u < kSelAhead; ++u) {
-      const int c = base + 64 * u + lane;
-      if (base + 64 * u < cols) {  // wave-uniform
-        const bool valid = c < cols;
-        float v = va[u];
-        if (valid) {
-          if (a2) {
-            v = 2.f * v;
-            v = v - ra2;
-            v = v - b2[c];
+        for (int u = 0; u < 4; ++u) {
+          gs[u] = -1;
+          if (mask != 0ull) {
+            gs[u] = base + (int)__builtin_ctzll(mask);
+            mask &= mask - 1ull;
           }
-          v = v + 0.0f;  // -0.0 -> +0.0 (key order)
         }
-        sel.push(valid && (v >= sel.tau), v, c);
+        float va[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int c = gs[u >> 1] * 128 + 64 * (u & 1) + lane;
+          va[u] = (gs[u >> 1] >= 0 && c < cols) ? xr[c] : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (gs[u >> 1] >= 0) {  // wave-uniform
+            const int c = gs[u >> 1] * 128 + 64 * (u & 1) + lane;
+            const bool valid = c < cols;
+            const float v = va[u] + 0.0f;
+            sel.push(valid && (v >= sel.tau), v, c);
+          }
+        }
+      }
+    }
+  } else {
+    // kSelAhead 64-column groups are loaded before any of them is pushed: with one load per
+    // iteration a wave waits out a full memory latency per 256 bytes (1.9 TB/s on a
+    // [10 000 x 16 384] matrix); 16 waves x 4 KiB in flight per CU cover the latency
+    constexpr int kSelAhead = 16;
+    for (int base = 0; base < cols; base += 64 * kSelAhead) {
+      float va[kSelAhead];
+  #pragma unroll
+      for (int u = 0; u < kSelAhead; ++u) {
+        const int c = base + 64 * u + lane;
+        va[u] = c < cols ? xr[c] : -INFINITY;
+      }
+  #pragma unroll
+      for (int u = 0; u < kSelAhead; ++u) {
+        const int c = base + 64 * u + lane;
+        if (base + 64 * u < cols) {  // wave-uniform
+          const bool valid = c < cols;
+          float v = va[u];
+          if (valid) {
+            if (a2) {
+              v = 2.f * v;
+              v = v - ra2;
+              v = v - b2[c];
+            }
+            v = v + 0.0f;  // -0.0 -> +0.0 (key order)
+          }
+          sel.push(valid && (v >= sel.tau), v, c);
+        }
       }
     }
   }
@@ -167,89 +222,101 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Coarse similarities sims[q][c] = 2 x_q.C_c - |x_q|^2 - |C_c|^2 (metric.negative_squared_l2_distance,
 // torchpq/metric.py:31-98: library GEMM + three element-wise passes) as one fp32-MFMA kernel, built
-// like max_sim_kernel (kmeans.hip): a block owns 128 centroids (4 waves x 32 MFMA columns, operand
-// in registers, prefetched one k-slab ahead) and walks query chunks of 256 MFMA rows whose 16-row
-// k-slabs are double-buffered in LDS (global -> registers while the previous slab's 8 x 8 MFMAs
-// run -> the other buffer, one barrier per slab).  |x|^2 is accumulated from the values each
-// thread stages (its query, every slab, ascending k), |C|^2 by each lane for its own centroid;
-// epilogue in the reference's rounding order; the stores of a half-wave cover 128 contiguous bytes
-// of a sims row.  In the reference's own benchmark grid (IVF4096 / IVF16384, n_probe 1..128) this
-// step is 40-85 % of a search, not the scan.
-// x [d][nq], C [d][n_cells] -> sims [nq][n_cells];  grid (ceil(n_cells/128), query-chunk groups)
-constexpr int kCsRows = 256;  // queries per chunk (8 MFMA row tiles)
+// like max_sim_kernel (kmeans.hip): a block owns 128 QUERIES (4 waves x 32 MFMA columns, operand
+// in registers, prefetched one k-slab ahead) and walks centroid chunks of 256 MFMA rows whose
+// 16-row k-slabs are double-buffered in LDS (global -> registers while the previous slab's 8 x 8
+// MFMAs run -> the other buffer, one barrier per slab).  |C|^2 is accumulated from the values each
+// thread stages (its centroid, every slab, ascending k), |x|^2 by each lane for its own query.
+// With the queries on the lanes
+//   * the maximum of a query's sims over a 128-centroid group is an in-lane reduction over
+//     accumulator registers -> gmax[q][group], which lets the row select skip every group that
+//     cannot hold a member of the top-n_probe (GroupFilter above);
+//   * a tile's sims leave through a 32 x 33 LDS transpose per wave, so that a half-wave still
+//     stores 128 contiguous bytes of a sims row.
+// In the reference's own benchmark grid (IVF4096 / IVF16384, n_probe 1..128) this step is 40-85 %
+// of a search, not the scan.
+// x [d][nq], C [d][n_cells] -> sims [nq][n_cells], gmax [nq][ceil(n_cells/128)]
+// grid (ceil(nq/128), centroid-chunk groups)
+constexpr int kCsRows = 256;  // centroids per chunk (8 MFMA row tiles = 2 groups of 128)
 constexpr int kCsKC = 16;     // k rows per LDS slab
 constexpr int kCsSlab = kCsKC * kCsRows;
 
 __global__ __launch_bounds__(256, 2) void coarse_sims_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ C,
                                                             float* __restrict__ sims, int d, int nq,
-                                                            int n_cells, int chunks_per_block) {
-  __shared__ float qs[2 * kCsSlab];  // [2][kCsKC][kCsRows]
-  __shared__ float q2s[kCsRows];
+                                                            int n_cells, int chunks_per_block,
+                                                            float* __restrict__ gmax, int n_groups) {
+  __shared__ float cs[2 * kCsSlab];   // [2][kCsKC][kCsRows]
+  __shared__ float c2s[kCsRows];
+  __shared__ float tr[4 * 32 * 33];   // per wave: 32 queries x (32 + 1) centroids
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l31 = lane & 31, half = lane >> 5;
-  const int c = blockIdx.x * 128 + wave * 32 + l31;  // this lane's centroid
-  const bool cvalid = c < n_cells;
-  const float* __restrict__ Cc = C + (cvalid ? c : 0);
+  const int qw = blockIdx.x * 128 + wave * 32;   // first query of this wave
+  const int q = qw + l31;                        // this lane's query
+  const bool qvalid = q < nq;
+  const float* __restrict__ xq = x + (qvalid ? q : 0);
+  float* trw = tr + wave * 32 * 33;
 
-  float c2 = 0.f;  // |C_c|^2, one ascending-k chain, 16 loads in flight per step
+  float q2 = 0.f;  // |x_q|^2, one ascending-k chain, 16 loads in flight per step
   {
-    const float* __restrict__ p = Cc;
+    const float* __restrict__ p = xq;
     int k = 0;
     for (; k + 16 <= d; k += 16) {
       float y[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) y[u] = p[(int64_t)u * n_cells];
+      for (int u = 0; u < 16; ++u) y[u] = p[(int64_t)u * nq];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) c2 = fmaf(y[u], y[u], c2);
-      p += 16 * (int64_t)n_cells;
+      for (int u = 0; u < 16; ++u) q2 = fmaf(y[u], y[u], q2);
+      p += 16 * (int64_t)nq;
     }
     for (; k < d; ++k) {
-      c2 = fmaf(*p, *p, c2);
-      p += n_cells;
+      q2 = fmaf(*p, *p, q2);
+      p += nq;
     }
   }
 
   const int n_slabs = (d + kCsKC - 1) / kCsKC;
   const int chunk0 = blockIdx.y * chunks_per_block;
   for (int ch = chunk0; ch < chunk0 + chunks_per_block; ++ch) {
-    const int q0 = ch * kCsRows;
-    if (q0 >= nq) break;
-    const int nr = (nq - q0) < kCsRows ? (nq - q0) : kCsRows;
-    const bool qv = (int)threadIdx.x < nr;  // this thread's query row of the chunk exists
-    const float* __restrict__ xq = x + q0 + (qv ? (int)threadIdx.x : 0);
+    const int c0 = ch * kCsRows;
+    if (c0 >= n_cells) break;
+    const int nc = (n_cells - c0) < kCsRows ? (n_cells - c0) : kCsRows;
+    const bool cv = (int)threadIdx.x < nc;  // this thread's centroid row of the chunk exists
+    const float* __restrict__ Cc = C + c0 + (cv ? (int)threadIdx.x : 0);
     float rs[kCsKC], yc[kCsKC / 2], yn[kCsKC / 2];
-    float qsq = 0.f;
+    float csq = 0.f;
     auto load_slab = [&](int kb) {
-      const float* __restrict__ p = xq + (int64_t)kb * nq;
+      const float* __restrict__ p = Cc + (int64_t)kb * n_cells;
 #pragma unroll
       for (int u = 0; u < kCsKC; ++u) {
-        rs[u] = (qv && kb + u < d) ? *p : 0.f;
-        p += nq;
+        rs[u] = (cv && kb + u < d) ? *p : 0.f;
+        p += n_cells;
       }
     };
     auto square_slab = [&]() {
 #pragma unroll
-      for (int u = 0; u < kCsKC; ++u) qsq = fmaf(rs[u], rs[u], qsq);
+      for (int u = 0; u < kCsKC; ++u) csq = fmaf(rs[u], rs[u], csq);
     };
     auto store_slab = [&](float* dst) {
 #pragma unroll
       for (int u = 0; u < kCsKC; ++u) dst[u * kCsRows + threadIdx.x] = rs[u];
     };
     auto load_y = [&](int kb, float (&y)[kCsKC / 2]) {
-      const float* __restrict__ p = Cc + (int64_t)(kb + half) * n_cells;
+      const float* __restrict__ p = xq + (int64_t)(kb + half) * nq;
 #pragma unroll
       for (int j = 0; j < kCsKC / 2; ++j) {
-        y[j] = (cvalid && kb + 2 * j + half < d) ? *p : 0.f;
-        p += 2 * (int64_t)n_cells;
+        y[j] = (qvalid && kb + 2 * j + half < d) ? *p : 0.f;
+        p += 2 * (int64_t)nq;
       }
     };
     load_slab(0);
     load_y(0, yc);
-    __syncthreads();  // every wave finished the previous chunk (reads of qs and q2s)
+    __syncthreads();  // every wave finished the previous chunk (reads of cs and c2s)
     square_slab();
-    if (n_slabs == 1) q2s[threadIdx.x] = qsq;
-    store_slab(qs);
+    // (rows past the last centroid get |C|^2 = +inf: their sims come out as -inf and drop out of
+    // the group maxima without a per-element predicate)
+    if (n_slabs == 1) c2s[threadIdx.x] = cv ? csq : INFINITY;
+    store_slab(cs);
     f32x16 acc[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -257,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void coarse_sims_kernel(const float* __rest
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     __syncthreads();
     for (int sb = 0; sb < n_slabs; ++sb) {
-      const float* cur = qs + (sb & 1) * kCsSlab;
+      const float* cur = cs + (sb & 1) * kCsSlab;
       const bool more = sb + 1 < n_slabs;
       if (more) {
         load_slab((sb + 1) * kCsKC);
@@ -265,34 +332,56 @@ __global__ __launch_bounds__(256, 2) void coarse_sims_kernel(const float* __rest
       }
 #pragma unroll
       for (int j = 0; j < kCsKC / 2; ++j) {
-        const float* qrow = cur + (2 * j + half) * kCsRows + l31;  // A operand [row=query][k]
+        const float* crow = cur + (2 * j + half) * kCsRows + l31;  // A operand [row=centroid][k]
 #pragma unroll
         for (int t = 0; t < 8; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[t * 32], yc[j], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(crow[t * 32], yc[j], acc[t], 0, 0, 0);
       }
       if (more) {
         square_slab();
-        if (sb + 2 == n_slabs) q2s[threadIdx.x] = qsq;
-        store_slab(qs + ((sb + 1) & 1) * kCsSlab);
+        if (sb + 2 == n_slabs) c2s[threadIdx.x] = cv ? csq : INFINITY;
+        store_slab(cs + ((sb + 1) & 1) * kCsSlab);
 #pragma unroll
         for (int j = 0; j < kCsKC / 2; ++j) yc[j] = yn[j];
       }
       __syncthreads();
     }
-    if (cvalid) {
+    // epilogue: acc[t][r] = (centroid row cl(t, r, half), query column l31)
+    float gm[2] = {-INFINITY, -INFINITY};
+    const int nq_w = nq - qw;  // queries of this wave that exist (may be <= 0)
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < 8; ++t) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (row < nr) {
-            float v = 2.f * acc[t][r];
-            v = v - q2s[row];
-            v = v - c2;
-            sims[(int64_t)(q0 + row) * n_cells + c] = v;
-          }
+      for (int r = 0; r < 16; ++r) {
+        const int cl = (r & 3) + 8 * (r >> 2) + 4 * half;   // row inside the tile
+        float v = 2.f * acc[t][r];
+        v = v - q2;
+        v = v - c2s[t * 32 + cl];
+        gm[t >> 2] = fmaxf(gm[t >> 2], v);
+        trw[l31 * 33 + cl] = v;                              // [query][centroid]
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      // read back transposed: lane (l31, half) takes centroid l31 of queries 16 half + i
+      const int c = c0 + t * 32 + l31;
+      if (c < n_cells) {
+        float* __restrict__ out = sims + (int64_t)(qw + 16 * half) * n_cells + c;
+        const int n_here = nq_w - 16 * half;  // rows of this half-wave that exist
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float v = trw[(16 * half + i) * 33 + l31];
+          if (i < n_here) out[(int64_t)i * n_cells] = v;
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_sched_barrier(0);  // one tile at a time: keeps the live predicate masks few
+    }
+    // the two half-waves of a query hold disjoint centroid rows
+    gm[0] = fmaxf(gm[0], __shfl_xor(gm[0], 32, 64));
+    gm[1] = fmaxf(gm[1], __shfl_xor(gm[1], 32, 64));
+    if (half == 0 && qvalid) {
+      const int g0 = 2 * ch;
+      gmax[(int64_t)q * n_groups + g0] = gm[0];
+      if (g0 + 1 < n_groups) gmax[(int64_t)q * n_groups + g0 + 1] = gm[1];
     }
   }
 }
@@ -395,9 +484,10 @@ __global__ __launch_bounds__(256) void coarse_sims_small_kernel(const float* __r
 
 template <int R>
 static int launch_select(const float* x, const float* a2, const float* b2, float* v, int64_t* i,
-                         int rows, int cols, int k, hipStream_t st, const ProbeEpilogue& pe) {
+                         int rows, int cols, int k, hipStream_t st, const ProbeEpilogue& pe,
+                         const GroupFilter& gf) {
   hipLaunchKernelGGL(topk_select_kernel<R>, dim3((rows + kSelWaves - 1) / kSelWaves),
-                     dim3(kSelWaves * 64), 0, st, x, a2, b2, v, i, rows, cols, k, pe);
+                     dim3(kSelWaves * 64), 0, st, x, a2, b2, v, i, rows, cols, k, pe, gf);
   TPQ_LAUNCH_CHECK("topk_select_kernel");
   return TPQ_OK;
 }
@@ -408,7 +498,7 @@ using namespace tpq;
 
 static int select_impl(const float* x, const float* a2, const float* b2, float* vals, int64_t* idx,
                        int rows, int cols, int k, tpq_stream_t stream,
-                       const ProbeEpilogue& pe = ProbeEpilogue{});
+                       const ProbeEpilogue& pe = ProbeEpilogue{}, const GroupFilter& gf = GroupFilter{});
 
 extern "C" int tpq_topk_select(const float* x, float* vals, int64_t* idx, int rows, int cols, int k,
                                tpq_stream_t stream) {
@@ -422,23 +512,25 @@ extern "C" int tpq_coarse_select(const float* dots, const float* a2, const float
 }
 
 static int select_impl(const float* x, const float* a2, const float* b2, float* vals, int64_t* idx,
-                       int rows, int cols, int k, tpq_stream_t stream, const ProbeEpilogue& pe) {
+                       int rows, int cols, int k, tpq_stream_t stream, const ProbeEpilogue& pe,
+                       const GroupFilter& gf) {
   TPQ_REQUIRE(x && vals && idx, "topk_select: null pointer");
   TPQ_REQUIRE(rows >= 0 && cols >= 1, "topk_select: bad shape [%d, %d]", rows, cols);
   TPQ_REQUIRE(k >= 1 && k <= 1024 && k <= cols, "topk_select: k=%d out of range (cols=%d, max 1024)", k, cols);
   if (rows == 0) return TPQ_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int r = (k + 63) / 64;
-  if (r <= 1) return launch_select<1>(x, a2, b2, vals, idx, rows, cols, k, st, pe);
-  if (r <= 2) return launch_select<2>(x, a2, b2, vals, idx, rows, cols, k, st, pe);
-  if (r <= 4) return launch_select<4>(x, a2, b2, vals, idx, rows, cols, k, st, pe);
-  if (r <= 8) return launch_select<8>(x, a2, b2, vals, idx, rows, cols, k, st, pe);
-  return launch_select<16>(x, a2, b2, vals, idx, rows, cols, k, st, pe);
+  if (r <= 1) return launch_select<1>(x, a2, b2, vals, idx, rows, cols, k, st, pe, gf);
+  if (r <= 2) return launch_select<2>(x, a2, b2, vals, idx, rows, cols, k, st, pe, gf);
+  if (r <= 4) return launch_select<4>(x, a2, b2, vals, idx, rows, cols, k, st, pe, gf);
+  if (r <= 8) return launch_select<8>(x, a2, b2, vals, idx, rows, cols, k, st, pe, gf);
+  return launch_select<16>(x, a2, b2, vals, idx, rows, cols, k, st, pe, gf);
 }
 
 extern "C" size_t tpq_ivfpq_coarse_probe_workspace_bytes(int nq, int n_cells) {
   if (nq <= 0 || n_cells <= 0) return 0;
-  return (size_t)nq * (size_t)n_cells * sizeof(float);
+  // sims [nq][n_cells] + group maxima [nq][ceil(n_cells / 128)]
+  return ((size_t)nq * (size_t)n_cells + (size_t)nq * (size_t)((n_cells + 127) / 128)) * sizeof(float);
 }
 
 extern "C" int tpq_ivfpq_coarse_probe(const float* query, const float* centroids,
@@ -462,24 +554,29 @@ extern "C" int tpq_ivfpq_coarse_probe(const float* query, const float* centroids
     return TPQ_ERR_WORKSPACE;
   }
   float* sims = reinterpret_cast<float*>(workspace);
-  // blocks = centroid groups of 128 x query-chunk groups; a block walks several 256-query chunks
-  // once there are enough blocks to fill the chip a few times over
-  const int cgroups = (n_cells + 127) / 128, chunks = (nq + kCsRows - 1) / kCsRows;
-  if ((long long)cgroups * chunks < 512) {  // too few big blocks to fill 256 CUs twice over
+  // large problems: blocks = 128-query groups x centroid-chunk groups (a block walks several
+  // 256-centroid chunks once there are enough blocks to fill the chip a few times over) and the
+  // row select is restricted by the group maxima; small ones: 64 x 256 tiles, full row select
+  const int qgroups = (nq + 127) / 128, chunks = (n_cells + kCsRows - 1) / kCsRows;
+  const int n_groups = (n_cells + 127) / 128;
+  float* gmax = sims + (size_t)nq * n_cells;
+  GroupFilter gf{nullptr, 0};
+  if ((long long)qgroups * chunks < 512) {
     hipLaunchKernelGGL(coarse_sims_small_kernel, dim3((nq + 63) / 64, (n_cells + 255) / 256),
                        dim3(256), 0, reinterpret_cast<hipStream_t>(stream), query, centroids, sims,
                        d, nq, n_cells);
   } else {
-    int per_block = (int)(((long long)cgroups * chunks) / 1024);
+    int per_block = (int)(((long long)qgroups * chunks) / 1024);
     per_block = per_block < 1 ? 1 : (per_block > 8 ? 8 : per_block);
-    hipLaunchKernelGGL(coarse_sims_kernel, dim3(cgroups, (chunks + per_block - 1) / per_block),
+    hipLaunchKernelGGL(coarse_sims_kernel, dim3(qgroups, (chunks + per_block - 1) / per_block),
                        dim3(256), 0, reinterpret_cast<hipStream_t>(stream), query, centroids, sims,
-                       d, nq, n_cells, per_block);
+                       d, nq, n_cells, per_block, gmax, n_groups);
+    gf = GroupFilter{gmax, n_groups};
   }
   TPQ_LAUNCH_CHECK("coarse_sims_kernel");
   ProbeEpilogue pe{cell_start_tbl, cell_size_tbl, cell_start, cell_size, n_probe_list,
                    smart_temperature > 0.f ? 1.0f / smart_temperature : 0.f};
-  return select_impl(sims, nullptr, nullptr, topk_sims, cells, nq, n_cells, n_probe, stream, pe);
+  return select_impl(sims, nullptr, nullptr, topk_sims, cells, nq, n_cells, n_probe, stream, pe, gf);
 }
 
 extern "C" int tpq_smart_probing(const float* topk_sims, int64_t* n_probe_list, int rows,
