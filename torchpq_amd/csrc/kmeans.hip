@@ -431,99 +431,159 @@ __global__ __launch_bounds__(256) void centroid_accum_global_kernel(
     unsafeAtomicAdd(&sums[((int64_t)b * d + e0 + e) * k + lab], data[((int64_t)b * d + e0 + e) * n + i]);
 }
 
-// ---- update, codebook-sized problems (k <= 256) ---------------------------------------------
-// LDS float atomics are the trap here: ds_add_f32 retires ~0.38 lanes per clock per CU on gfx950
-// whatever the access pattern (tools/ubench/lds_atomic.hip: 168 cycles per wave instruction; int
-// atomics are 16x faster), which held the kernel above at 0.8 TB/s.  This kernel uses none:
-// each wave OWNS a 16-dimension slice of the block's 64-dimension tile and keeps private
-// accumulators acc[label][16] in LDS.  A 32-point half-tile is loaded coalesced (lane = point),
-// transposed through a small LDS stage, and then added 4 points per instruction with lanes =
-// (point group g, dimension e): plain ds_read / v_add / ds_write.  Two points of one instruction
-// that share a label are serialised by rank (rare: 4 points, 256 labels).
-constexpr int kCu2Dims = 16;    // dimensions per wave
-constexpr int kCu2Half = 32;    // points per staged half-tile
+// ---- update on the bf16 matrix cores (k <= 256) ---------------------------------------------
+// sums[cluster][dim] = sum_i onehot(label_i)[cluster] * x_i[dim] is a GEMM whose left operand is a
+// 0/1 matrix.  fp32 MFMA would waste 255/256 of its multiplies at 1/16 of the bf16 rate; instead x
+// is split EXACTLY into three bf16 pieces (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi -
+// mid): 3 x 8 significant bits), the one-hot tile is built in registers from the labels, and
+// v_mfma_f32_32x32x16_bf16 accumulates 1.0 * piece products in fp32 -- exact products, fp32 sums,
+// 16 points per instruction.  Operand layout (tools/ubench/mfma_bf16_layout.hip): A[row][k] in
+// lane row + 32 (k / 8), element k % 8; B[k][col] likewise; D as the f32 forms.
+// LDS float atomics are the trap on the scalar route: ds_add_f32 retires ~0.38 lanes per clock
+// per CU on gfx950 whatever the access pattern (tools/ubench/lds_atomic.hip; integer atomics are
+// 16x faster); an atomic-free LDS read-add-write version reached 9.2 ms at C5, this one 5.9 ms.
+// (A NaN / Inf coordinate reaches every cluster of its 16-point group through 0 * x; the scalar
+// kernels confine it to its own cluster.)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kUmP = 64;              // points per staged tile (4 MFMA k-steps of 16)
+constexpr int kUmStride = kUmP + 4;   // floats per dimension row in LDS (b128 reads stay conflict-free)
 
-__global__ __launch_bounds__(256, 2) void centroid_accum_codebook_kernel(
+// One WAVE per block owns all 256 clusters x 64 dimensions of its point range: 8 x 2 accumulator
+// tiles = 256 AGPRs, one wave per SIMD.  (A first version spread the clusters over the 4 waves of
+// a block: every wave then split the same tile into bf16 pieces again and the block met at a
+// barrier per 64 points -- 7.4 ms at C5; the LDS read-add-write kernel above: 9.2 ms.)
+// The B fragment wants 8 consecutive points of ONE dimension per lane; straight from global memory
+// that is one 32-byte request per lane (address-unit bound, 32 ms), so [64 dims][64 points] tiles
+// go through LDS with coalesced row loads (lane = point), the next tile in flight in registers
+// while the MFMAs of the current one run.
+__global__ __launch_bounds__(64) void centroid_accum_mfma_kernel(
     const float* __restrict__ data, const int64_t* __restrict__ labels, float* __restrict__ sums,
     float* __restrict__ counts, int d, int64_t n, int k, int64_t points) {
-  __shared__ float acc_all[4 * 256 * kCu2Dims];                    // 64 KiB: [wave][label][16]
-  __shared__ float stage_all[4 * kCu2Dims * (kCu2Half + 1)];       // [wave][16][33]
-  __shared__ int lab_all[4 * kCu2Half];
+  __shared__ __attribute__((aligned(16))) float xt[2][64 * kUmStride];
+  __shared__ __attribute__((aligned(16))) int lt[2][kUmP];
   __shared__ int cnt[256];
   const int b = blockIdx.z;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int e0 = blockIdx.y * 64 + wave * kCu2Dims;               // first dimension of this wave
-  float* acc = acc_all + wave * 256 * kCu2Dims;
-  float* stage = stage_all + wave * kCu2Dims * (kCu2Half + 1);
-  int* labs = lab_all + wave * kCu2Half;
-  for (int t = lane; t < 256 * kCu2Dims; t += 64) acc[t] = 0.f;
-  cnt[threadIdx.x] = 0;
-  __syncthreads();
-  const bool count_here = (blockIdx.y == 0) && (wave == 0);
+  const int lane = threadIdx.x;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int e0 = blockIdx.y * 64;
+  const int nd = (d - e0) < 64 ? (d - e0) : 64;  // dimensions of this block that exist
   const int64_t i0 = (int64_t)blockIdx.x * points;
   const int64_t i1 = (i0 + points) < n ? (i0 + points) : n;
-  const float* __restrict__ drow = data + ((int64_t)b * d + e0) * n;
   const int64_t* __restrict__ lrow = labels + (int64_t)b * n;
-  const int pl = lane & 31, hl = lane >> 5;   // load phase: point pl, dimension parity hl
-  const int g = lane >> 4, e = lane & 15;     // add phase: point group g, dimension e
-  const bool wave_active = e0 < d;
+  const float* __restrict__ dbase = data + ((int64_t)b * d + e0) * n;
+  f32x16 acc[8][2];  // [cluster row tile][dimension column tile]
+#pragma unroll
+  for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) cnt[lane + 64 * u] = 0;
+  const bool count_here = blockIdx.y == 0;
 
-  if (wave_active) {
-    for (int64_t base = i0; base < i1; base += kCu2Half) {
-      // coalesced loads: lanes 0-31 take even dimensions, lanes 32-63 odd ones (8 loads per lane)
-      const int64_t i = base + pl;
-      const bool pv = i < i1;
-      float x[kCu2Dims / 2];
+  // The next tile is fetched in four quarters (16 dimension rows each), one per MFMA k-step, so
+  // that the address arithmetic and load issue of the single wave hide behind its own MFMAs.
+  // Loads are unconditional on clamped addresses and masked afterwards: no exec-mask branches.
+  float rx[64];
+  int rl = -1;
+  auto load_quarter = [&](int64_t p0, int qt) {
+    const int64_t pt = p0 + lane;
+    const bool pv = pt < i1;
+    const float* __restrict__ p = dbase + (pv ? pt : i0);
 #pragma unroll
-      for (int u = 0; u < kCu2Dims / 2; ++u) {
-        const int ee = 2 * u + hl;
-        x[u] = (pv && e0 + ee < d) ? drow[(int64_t)ee * n + i] : 0.f;
-      }
-      int lab = -1;
-      if (lane < kCu2Half && pv) {
-        const int64_t l64 = lrow[i];
-        lab = (l64 >= 0 && l64 < k) ? (int)l64 : -1;
-      }
+    // (no masking of the values: a select right behind each load makes the compiler wait for
+    // every load on the spot.  Out-of-range points carry label -1 -- their one-hot column is zero
+    // -- and out-of-range dimension rows land in accumulator columns that are never written
+    // out; both read clamped, finite, addresses)
+    for (int u = 16 * qt; u < 16 * qt + 16; ++u) rx[u] = p[(int64_t)(u < nd ? u : 0) * n];
+    if (qt == 0) {
+      const int64_t l64 = lrow[pv ? pt : i0];
+      rl = (pv && l64 >= 0 && l64 < k) ? (int)l64 : -1;
+    }
+  };
+  auto load_tile = [&](int64_t p0) {
 #pragma unroll
-      for (int u = 0; u < kCu2Dims / 2; ++u) stage[(2 * u + hl) * (kCu2Half + 1) + pl] = x[u];
-      if (lane < kCu2Half) {
-        labs[lane] = lab;
-        if (count_here && lab >= 0) atomicAdd(&cnt[lab], 1);  // integer LDS atomic: fast
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-#pragma unroll 2
-      for (int t = 0; t < kCu2Half / 4; ++t) {
-        const int p = 4 * t + g;
-        const float v = stage[e * (kCu2Half + 1) + p];
-        const int l0 = labs[4 * t + 0], l1 = labs[4 * t + 1], l2 = labs[4 * t + 2], l3 = labs[4 * t + 3];
-        const int mine = g == 0 ? l0 : g == 1 ? l1 : g == 2 ? l2 : l3;
-        // rank = earlier groups of this instruction with the same label
-        const int rank = (g > 0 && l0 == mine) + (g > 1 && l1 == mine) + (g > 2 && l2 == mine);
-        const int maxdup = (l0 == l1) + (l0 == l2) + (l0 == l3) + (l1 == l2) + (l1 == l3) + (l2 == l3);
-        if (maxdup == 0) {  // wave-uniform (labels are the same values in every lane)
-          if (mine >= 0) acc[mine * kCu2Dims + e] += v;
-        } else {
-          for (int r = 0; r < 4; ++r) {
-            if (mine >= 0 && rank == r) acc[mine * kCu2Dims + e] += v;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-          }
+    for (int qt = 0; qt < 4; ++qt) load_quarter(p0, qt);
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 64; ++u) xt[buf][u * kUmStride + lane] = rx[u];
+    lt[buf][lane] = rl;
+  };
+  load_tile(i0);
+  store_tile(0);
+  __syncthreads();
+  int it = 0;
+  for (int64_t p0 = i0; p0 < i1; p0 += kUmP, ++it) {
+    const int buf = it & 1;
+    const bool more = p0 + kUmP < i1;
+    if (count_here) {
+      const int l = lt[buf][lane];
+      if (l >= 0) atomicAdd(&cnt[l], 1);  // integer LDS atomic: fast
+    }
+#pragma unroll
+    for (int ks = 0; ks < kUmP / 16; ++ks) {
+      if (more) load_quarter(p0 + kUmP, ks);
+      const int pts = 16 * ks + 8 * half;  // this lane's 8 points (its k-group)
+      const int4 la = *reinterpret_cast<const int4*>(&lt[buf][pts]);
+      const int4 lb = *reinterpret_cast<const int4*>(&lt[buf][pts + 4]);
+      const int lab[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
+      bf16x8 piece[3][2];  // [hi, mid, lo][column tile]
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const float* xrow = &xt[buf][(32 * ct + l31) * kUmStride + pts];
+        const float4 xa = *reinterpret_cast<const float4*>(xrow);
+        const float4 xb = *reinterpret_cast<const float4*>(xrow + 4);
+        const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const __bf16 h = (__bf16)xv[i];
+          const float r1 = xv[i] - (float)h;
+          const __bf16 m = (__bf16)r1;
+          const float r2 = r1 - (float)m;
+          piece[0][ct][i] = h;
+          piece[1][ct][i] = m;
+          piece[2][ct][i] = (__bf16)r2;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      // the 16 accumulator tiles take turns: an MFMA never waits for the one issued before it
+#pragma unroll
+      for (int rt = 0; rt < 8; ++rt) {
+        bf16x8 a;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = (__bf16)((lab[i] == 32 * rt + l31) ? 1.0f : 0.0f);
+        // (both column tiles always: a wave-uniform branch around the second one when d <= 32
+        // broke the MFMA interleaving and cost more than the multiplies it saved)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, piece[pc][ct], acc[rt][ct], 0, 0, 0);
+      }
     }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
   }
-  __syncthreads();
-  if (wave_active) {
-    for (int t = lane; t < 256 * kCu2Dims; t += 64) {
-      const int lab = t >> 4, ee = t & 15;
-      const float v = acc[t];
-      if (lab < k && e0 + ee < d && v != 0.f)
-        unsafeAtomicAdd(&sums[((int64_t)b * d + e0 + ee) * k + lab], v);
+#pragma unroll
+  for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int dim = e0 + 32 * ct + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cluster = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float v = acc[rt][ct][r];
+        if (dim < d && cluster < k && v != 0.f)
+          unsafeAtomicAdd(&sums[((int64_t)b * d + dim) * k + cluster], v);
+      }
     }
-  }
-  if (blockIdx.y == 0 && threadIdx.x < k) {
-    const int c = cnt[threadIdx.x];
-    if (c) unsafeAtomicAdd(&counts[(int64_t)b * k + threadIdx.x], (float)c);
+  if (count_here) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = lane + 64 * u;
+      if (c < k && cnt[c]) unsafeAtomicAdd(&counts[(int64_t)b * k + c], (float)cnt[c]);
+    }
   }
 }
 
@@ -604,18 +664,17 @@ extern "C" int tpq_compute_centroids(const float* data, const int64_t* labels, f
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                    "centroid_accum_kernel attr");
     if (rc) return rc;
-    if (k <= 256 && d >= 32) {  // wide PQ-codebook shape: atomic-free LDS accumulation
-      // (below 32 dimensions most of a wave's 16-dimension slice would idle: use the kernel below)
+    if (k <= 256 && d >= 32) {  // wide PQ-codebook shape: bf16 matrix cores
       const int dt64 = (d + 63) / 64;
-      int64_t chunks = 2048 / ((int64_t)l * dt64);
+      int64_t chunks = 1024 / ((int64_t)l * dt64);
       if (chunks < 1) chunks = 1;
       int64_t points = (n + chunks - 1) / chunks;
-      if (points < 2048) points = 2048;
-      points = (points + kCu2Half - 1) / kCu2Half * kCu2Half;
-      hipLaunchKernelGGL(centroid_accum_codebook_kernel,
-                         dim3((unsigned)((n + points - 1) / points), dt64, l), dim3(256), 0, st, data,
+      if (points < 4096) points = 4096;
+      points = (points + kUmP - 1) / kUmP * kUmP;
+      hipLaunchKernelGGL(centroid_accum_mfma_kernel,
+                         dim3((unsigned)((n + points - 1) / points), dt64, l), dim3(64), 0, st, data,
                          labels, sums, counts, d, n, k, points);
-      TPQ_LAUNCH_CHECK("centroid_accum_codebook_kernel");
+      TPQ_LAUNCH_CHECK("centroid_accum_mfma_kernel");
       const int64_t total = (int64_t)l * d * k;
       hipLaunchKernelGGL(centroid_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
                          0, st, sums, counts, centroids, d, k, total);
