@@ -1,24 +1,37 @@
 #!/usr/bin/env python
 """bench.py -- queries/sec + recall@100 of IVFPQIndex.search on a SIFT1M-shaped index.
 
-Workload (BASELINE.json configs[1]; SIFT1M files are not available offline, so the data is
-synthetic of the same shape -- SURVEY.md 8d "SIFT1M-like"): d=128 non-negative integer-valued
-clustered fp32, 1 M base vectors, 100 k training vectors, 10 000 queries, IVFPQ n_cells=1024,
-m=64 (8-bit), n_probe=32, k=100, use_smart_probing=False (deterministic scanned bytes).
+Headline workload (BASELINE.json configs[1]): d=128, 1 M base vectors, 100 k training vectors,
+10 000 queries, IVFPQ n_cells=1024, m=64 (8-bit), n_probe=32, k=100, use_smart_probing=False
+(deterministic scanned bytes).  With `--data-dir DIR` holding the TEXMEX files
+(sift_base/learn/query.fvecs, sift_groundtruth.ivecs) the real SIFT1M is used; they are not
+available offline, so the default is synthetic data of the same shape.
 
-A "step" is one search() call over the whole resident query batch (coarse GEMM + select + LUT +
-list scan + id map).  `value` = queries/s over all ranks; each rank owns a replica of the index
-(built on rank 0, broadcast once over RCCL) and its own 10 000 queries -> weak scaling, no
-per-query collective.
+A "step" is one search() call over the whole resident query batch (coarse probe + LUT + list
+scan + id map).  `value` = queries/s over all ranks; each rank owns a replica of the index (built
+on rank 0, broadcast once over RCCL) and its own 10 000 queries -> weak scaling, no per-query
+collective.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--nq 10000] [--n-base 1000000]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4] [--no-secondary]
+
+`--gpus N` with N > 1 launches its own N ranks (torch.distributed.run, one per GPU, RCCL) when
+not already running under a launcher; under the driver's torchrun command it is one of the ranks.
+
+At N=1 a time-boxed secondary pass (<= ~60 s) puts the other BASELINE.json configs on the record
+under the key "secondary" of the same JSON line, each with its own roofline:
+  stream_peak  measured HBM streaming-read rate of this box (tpq_ubench_stream_read, 8 GiB)
+  c3           GIST1M-shaped search() (d=960, m=120, n_probe=64, 1000 queries)
+  c4           100 M-slot scan (n_cells=16384, m=64, n_probe=64; 6.4 GB of codes: the DRAM test)
+  c5           MultiKMeans assign / update per Lloyd iteration (64 x 64 x 1 M, k=256)
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,46 +41,239 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix-core peak (MI355X_MICROARCH.md)
+PROFILE_TAG = "r02"
 
 
-def sift_like(gen, d, n, centers, device, noise=30.0):
-    """clamp(round(|center + noise|)) in [0, 218]: non-negative, integer-valued, clustered."""
-    out = torch.empty(d, n, device=device, dtype=torch.float32)
-    step = 1 << 18
-    for b in range(0, n, step):
-        e = min(n, b + step)
-        a = torch.randint(0, centers.shape[1], (e - b,), generator=gen, device=device)
-        x = centers[:, a] + torch.randn(d, e - b, generator=gen, device=device) * noise
-        out[:, b:e] = x.abs().round().clamp_(0, 218)
-    return out
+# ---------------------------------------------------------------------------------------------
+# data
+# ---------------------------------------------------------------------------------------------
+class SiftLike:
+    """Synthetic stand-in for SIFT: non-negative, integer-valued fp32 in [0, 218].
+    A vector = |blob centre + low-dimensional within-blob variation + isotropic noise|: the
+    latent part gives the data a low intrinsic dimension (as real descriptors have), which is
+    what makes an IVF probe of 32 / 1024 cells miss a few true neighbours -- recall@100 lands
+    near the reference's 0.95 instead of a non-diagnostic 1.0."""
+
+    def __init__(self, d, device, seed=1234, n_centers=256, latent_dim=12, latent_scale=55.0,
+                 noise=12.0):
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        self.d, self.device = d, device
+        self.noise, self.latent_scale = noise, latent_scale
+        self.centers = torch.randn(d, n_centers, generator=g, device=device).abs() * 40.0
+        self.basis = torch.randn(d, latent_dim, generator=g, device=device) / latent_dim ** 0.5
+
+    def sample(self, n, seed):
+        g = torch.Generator(device=self.device)
+        g.manual_seed(seed)
+        out = torch.empty(self.d, n, device=self.device, dtype=torch.float32)
+        step = 1 << 18
+        for b in range(0, n, step):
+            e = min(n, b + step)
+            a = torch.randint(0, self.centers.shape[1], (e - b,), generator=g, device=self.device)
+            z = torch.randn(self.basis.shape[1], e - b, generator=g, device=self.device)
+            x = self.centers[:, a] + (self.basis @ z) * self.latent_scale \
+                + torch.randn(self.d, e - b, generator=g, device=self.device) * self.noise
+            out[:, b:e] = x.abs().round().clamp_(0, 218)
+        return out
 
 
-def make_centers(gen, d, device):
-    # broad, overlapping mixture: k-means cells come out mildly unbalanced, as on real SIFT
-    return torch.randn(d, 256, generator=gen, device=device).abs() * 40.0
+def load_texmex(data_dir, name, device, n_base, nq):
+    """(base, train, queries, groundtruth NN ids or None) as [d, n] device tensors"""
+    from torchpq_amd import datasets
+    paths = datasets.find_texmex(data_dir, name)
+    if paths is None:
+        return None
+    base = torch.from_numpy(datasets.read_fvecs(paths["base"], n_base)).to(device).T.contiguous()
+    learn = paths["learn"] and torch.from_numpy(datasets.read_fvecs(paths["learn"])).to(device).T.contiguous()
+    query = torch.from_numpy(datasets.read_fvecs(paths["query"], nq)).to(device).T.contiguous()
+    gt = None
+    if paths["groundtruth"] and base.shape[1] == 1_000_000:
+        gt = torch.from_numpy(datasets.read_ivecs(paths["groundtruth"], nq)[:, 0].astype(np.int64)).to(device)
+    return base, learn, query, gt
 
 
-def build_index(args, device):
+def exact_nn(queries, base):
+    """true nearest neighbour (L2) of every query column: GEMM + argmin, chunked"""
+    b2 = (base * base).sum(0)
+    out = []
+    for q0 in range(0, queries.shape[1], 2048):
+        d2 = b2[None, :] - 2.0 * (queries[:, q0:q0 + 2048].T @ base)
+        out.append(d2.argmin(dim=1))
+    return torch.cat(out)
+
+
+# ---------------------------------------------------------------------------------------------
+# index construction
+# ---------------------------------------------------------------------------------------------
+def build_index(args, device, base, train):
     from torchpq_amd.index import IVFPQIndex
-    gen = torch.Generator(device=device)
-    gen.manual_seed(1234)
-    centers = make_centers(gen, args.d, device)
-    base = sift_like(gen, args.d, args.n_base, centers, device)
     np.random.seed(1234)
-    idx = IVFPQIndex(d_vector=args.d, n_subvectors=args.m, n_cells=args.n_cells,
-                     initial_size=max(64, 2 * args.n_base // args.n_cells), device=str(device))
+    n_base = base.shape[1]
+    idx = IVFPQIndex(d_vector=base.shape[0], n_subvectors=args.m, n_cells=args.n_cells,
+                     initial_size=max(64, 2 * n_base // args.n_cells), device=str(device))
+    torch.cuda.synchronize()
     t0 = time.time()
-    train = base[:, torch.randperm(args.n_base, generator=gen, device=device)[:args.n_train]].contiguous()
     idx.train(train)
     torch.cuda.synchronize()
     t_train = time.time() - t0
     t0 = time.time()
-    for b in range(0, args.n_base, 1 << 18):
+    for b in range(0, n_base, 1 << 18):
         idx.add(base[:, b:b + (1 << 18)].contiguous())
     torch.cuda.synchronize()
-    t_add = time.time() - t0
-    return idx, base, centers, gen, t_train, t_add
+    return idx, t_train, time.time() - t0
+
+
+def fabricate_index(device, d, m, n_cells, n_items, seed, slack=9):
+    """configs[3] (SURVEY 8d "C4"): the codes are generated directly (no train/add): multinomial
+    cell sizes, uniform random codes, random fp32 codebooks and coarse centroids; loaded through
+    load_state_dict like any foreign index."""
+    from torchpq_amd.index import IVFPQIndex
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    idx = IVFPQIndex(d_vector=d, n_subvectors=m, n_cells=n_cells, initial_size=1, device=str(device))
+    probs = torch.full((n_cells,), 1.0 / n_cells, device=device)
+    sizes = torch.zeros(n_cells, device=device, dtype=torch.long)
+    for b in range(0, n_items, 1 << 24):  # multinomial(n_items, uniform) in draws of 16 M
+        draw = torch.multinomial(probs, min(1 << 24, n_items - b), replacement=True, generator=g)
+        sizes += torch.bincount(draw, minlength=n_cells)
+    cap = sizes + slack
+    start = torch.cumsum(cap, 0) - cap
+    n_slots = int(cap.sum().item())
+    storage = torch.empty(m // 4, n_slots, 4, device=device, dtype=torch.uint8)
+    for gi in range(m // 4):  # in slices: randint draws int64 internally
+        for s0 in range(0, n_slots, 1 << 26):
+            e = min(n_slots, s0 + (1 << 26))
+            storage[gi, s0:e] = torch.randint(0, 256, (e - s0, 4), generator=g, device=device,
+                                              dtype=torch.uint8)
+    pos = torch.arange(n_slots, device=device)
+    cell_of = torch.repeat_interleave(torch.arange(n_cells, device=device), cap)
+    occupied = (pos - start[cell_of]) < sizes[cell_of]
+    a2i = torch.where(occupied, torch.cumsum(occupied.long(), 0) - 1, torch.full_like(pos, -1))
+    del pos, cell_of
+    sd = idx.state_dict()
+    new = {
+        "_storage": storage, "_cell_start": start, "_cell_size": sizes, "_cell_capacity": cap,
+        "_is_empty": (~occupied).to(torch.uint8), "_address2id": a2i,
+        "vq_codec._is_trained": torch.tensor(True, device=device),
+        "pq_codec._is_trained": torch.tensor(True, device=device),
+        "vq_codec.kmeans.centroids": torch.randn(d, n_cells, generator=g, device=device),
+        "pq_codec.kmeans.centroids": torch.randn(m, d // m, 256, generator=g, device=device),
+    }
+    missing = set(sd) - set(new)
+    for k in missing:
+        new[k] = sd[k]
+    idx.load_state_dict(new)
+    return idx
+
+
+# ---------------------------------------------------------------------------------------------
+# measurement helpers
+# ---------------------------------------------------------------------------------------------
+def scanned_bytes(idx, queries, m):
+    """sum over queries and probed cells of cell_size x m (uint8 codes only)"""
+    tot = 0
+    for q0 in range(0, queries.shape[1], 16384):
+        _, cells, npl = idx.probe(queries[:, q0:q0 + 16384].contiguous())
+        sizes = idx._cell_size[cells]
+        live = torch.arange(cells.shape[1], device=cells.device)[None, :] < npl[:, None]
+        tot += int((sizes * live).sum().item())
+    return tot * m
+
+
+def time_search(idx, queries, k, steps, warmup, dist=None):
+    """W untimed + K timed search() calls, barrier + synchronize on both sides; (wall seconds,
+    mean scan-kernel ms from HIP events on the launch stream, last result)"""
+    scan = idx._ivfpq_topk._scan
+    for _ in range(warmup):
+        idx.search(queries, k=k)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    scan.record_events = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        vals, ids = idx.search(queries, k=k)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    events = scan.record_events
+    scan.record_events = None
+    nb = max(1, len(events) // max(steps, 1))  # query batches per search() call
+    scan_ms = float(np.sum([a.elapsed_time(b) for a, b in events])) / max(steps, 1) if events else float("nan")
+    return dt, scan_ms, nb, vals, ids
+
+
+def hbm_roofline(algo_bytes, kernel_ms, kernel, stream_peak=None, **extra):
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": kernel,
+         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes)}
+    if stream_peak:
+        r["stream_peak"] = round(stream_peak, 1)
+        r["frac_of_stream_peak"] = round(achieved / stream_peak, 4)
+    r.update(extra)
+    return r
+
+
+def source_fingerprint():
+    """sha1 over the kernel sources: a committed PMC summary is attached to the bench line only
+    when it was taken from exactly this code"""
+    h = hashlib.sha1()
+    src = os.path.join(ROOT, "torchpq_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".h", ".hip", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(src, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def attach_traffic(roofline, name):
+    """HBM-side bytes per launch come from a separate rocprofv3 --pmc pass over the same command
+    (FETCH_SIZE, corrected as MI355X_MICROARCH.md prescribes; tools/profile_bench.sh); the
+    committed summary is read back only if its source fingerprint and byte count match"""
+    prof = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{name}.json")
+    if not os.path.exists(prof):
+        return
+    try:
+        pj = json.load(open(prof))
+        algo = roofline["algorithmic_bytes_per_launch"]
+        if pj.get("source_fingerprint") != source_fingerprint():
+            roofline["traffic_note"] = f"profiles/{PROFILE_TAG}_{name}.json is from other kernel sources: not attached"
+            return
+        if abs(pj["algorithmic_bytes_per_launch"] - algo) <= 0.02 * algo:
+            roofline["traffic"] = round(pj["hbm_side_read_bytes_corrected"])
+            roofline["traffic_source"] = (f"profiles/{PROFILE_TAG}_{name}.json (rocprofv3 --pmc "
+                                          "FETCH_SIZE x2 x1KiB, same command, same sources)")
+    except Exception as e:  # a malformed summary must not break the bench line
+        roofline["traffic_note"] = f"unreadable profile: {e}"
+
+
+def stream_peak_gbps(device, gib=8, iters=5):
+    """sustained HBM read rate: tpq_ubench_stream_read over a buffer far beyond the 256 MiB
+    Infinity Cache, best of `iters` (HIP events on the launch stream)"""
+    from torchpq_amd import _lib
+    lib = _lib.load()
+    buf = torch.empty(gib << 30, device=device, dtype=torch.uint8)
+    buf.view(torch.int64).fill_(0x0123456789abcdef)
+    sink = torch.zeros(1, device=device, dtype=torch.int32)
+    st = _lib.stream_ptr(device)
+    best = 0.0
+    with torch.cuda.device(device):
+        for it in range(iters + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(lib.tpq_ubench_stream_read(_lib.ptr(buf), buf.numel(), _lib.ptr(sink), 0, st),
+                       "tpq_ubench_stream_read")
+            e1.record()
+            torch.cuda.synchronize()
+            if it:  # first launch = warm-up
+                best = max(best, buf.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    return best
 
 
 def cpu_baseline(idx, queries, k, n_sample):
@@ -88,28 +294,214 @@ def cpu_baseline(idx, queries, k, n_sample):
         use_smart_probing=idx.use_smart_probing,
         scan_fn=lambda *a: c_oracle.scan_topk(*a, n_threads=cores))
     dt = time.time() - t0
-    return {"value": n_sample / dt, "unit": "queries/s", "cores": cores, "kind": "port",
+    return {"value": round(n_sample / dt, 1), "unit": "queries/s", "cores": cores, "kind": "port",
             "sample": f"{n_sample} of the {queries.shape[1]} queries, full pipeline "
                       f"(numpy coarse+LUT, C/OpenMP list scan), {dt:.1f} s"}, ids
 
 
-def main():
+# ---------------------------------------------------------------------------------------------
+# secondary pass: BASELINE.json configs[2..4] + the box's stream peak (N=1, rank 0, time-boxed)
+# ---------------------------------------------------------------------------------------------
+def secondary_c3(device, stream_peak, steps=10):
+    """configs[2]: GIST1M-shaped index built through train/add on synthetic d=960 data in [0,1]"""
+    from torchpq_amd.index import IVFPQIndex
+    d, m, n_cells, n, nq, n_probe, k = 960, 120, 1024, 1_000_000, 1000, 64, 100
+    g = torch.Generator(device=device)
+    g.manual_seed(1235)
+    centers = torch.rand(d, 512, generator=g, device=device)
+    basis = torch.randn(d, 24, generator=g, device=device) / 24 ** 0.5
+
+    def sample(count):
+        a = torch.randint(0, 512, (count,), generator=g, device=device)
+        z = torch.randn(24, count, generator=g, device=device)
+        x = centers[:, a] * 0.6 + (basis @ z) * 0.12 + torch.randn(d, count, generator=g, device=device) * 0.04
+        return x.clamp_(0, 1)
+
+    np.random.seed(1235)
+    idx = IVFPQIndex(d_vector=d, n_subvectors=m, n_cells=n_cells, initial_size=2 * n // n_cells,
+                     device=str(device))
+    t0 = time.time()
+    idx.train(sample(100_000))
+    torch.cuda.synchronize()
+    t_train = time.time() - t0
+    t0 = time.time()
+    for b in range(0, n, 1 << 17):
+        idx.add(sample(min(1 << 17, n - b)))
+    torch.cuda.synchronize()
+    t_add = time.time() - t0
+    idx.n_probe, idx.use_smart_probing = n_probe, False
+    queries = sample(nq)
+    dt, scan_ms, _, vals, ids = time_search(idx, queries, k, steps, 2)
+    algo = scanned_bytes(idx, queries, m)
+    return {"workload": f"GIST1M-like d={d} n={n} IVFPQ n_cells={n_cells} m={m} nprobe={n_probe} k={k}, "
+                        f"{nq} queries, search() end to end",
+            "value": round(nq * steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / steps * 1e3, 4),
+            "train_s": round(t_train, 2), "add_s": round(t_add, 2),
+            "roofline": hbm_roofline(algo, scan_ms, "scan_packed_kernel<.,120,.> + merge", stream_peak,
+                                     bytes_per_query=round(algo / nq, 1))}
+
+
+def secondary_c4(device, stream_peak, steps=5):
+    """configs[3] on one GPU: 100 M slots, 6.4 GB of codes -- beyond the Infinity Cache"""
+    d, m, n_cells, n, nq, n_probe, k = 128, 64, 16384, 100_000_000, 10000, 64, 100
+    idx = fabricate_index(device, d, m, n_cells, n, seed=1236)
+    idx.n_probe, idx.use_smart_probing = n_probe, False
+    g = torch.Generator(device=device)
+    g.manual_seed(4236)
+    queries = torch.randn(d, nq, generator=g, device=device)
+    dt, scan_ms, _, vals, ids = time_search(idx, queries, k, steps, 1)
+    algo = scanned_bytes(idx, queries, m)
+    return {"workload": f"synthetic codes d={d} n={n} IVFPQ n_cells={n_cells} m={m} nprobe={n_probe} k={k}, "
+                        f"{nq} queries per GPU, search() end to end (coarse probe + fused LUT + scan)",
+            "value": round(nq * steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / steps * 1e3, 4),
+            "code_bytes_resident": int(idx._storage.numel()),
+            "roofline": hbm_roofline(algo, scan_ms, "scan_packed_kernel<2,64,false> + merge", stream_peak,
+                                     bytes_per_query=round(algo / nq, 1))}
+
+
+def secondary_c5(device, stream_peak, iters=3):
+    """configs[4]: MultiKMeans n_kmeans=64 d=64 n=1M k=256: the two kernels of one Lloyd iteration"""
+    from torchpq_amd import kernels as K
+    l, d, n, k = 64, 64, 1_000_000, 256
+    g = torch.Generator(device=device)
+    g.manual_seed(1237)
+    data = torch.randn(l, d, n, generator=g, device=device)
+    cent = data[:, :, torch.randperm(n, generator=g, device=device)[:k]].contiguous()
+    assign, update = K.MaxSimHip(distance="euclidean"), K.ComputeCentroidsHip()
+    _, lab = assign(data, cent, dim=2, mode="tn")
+    update(data, lab, k=k)
+    torch.cuda.synchronize()
+
+    def timeit(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    t_assign = timeit(lambda: assign(data, cent, dim=2, mode="tn"))
+    t_update = timeit(lambda: update(data, lab, k=k))
+    out = {"workload": f"MultiKMeans n_kmeans={l} d={d} n={n} k={k}, one Lloyd iteration = assign + update"}
+    fused = getattr(K, "KMeansStepHip", None)
+    if fused is not None:
+        step = fused(distance="euclidean")
+        step(data, cent)
+        torch.cuda.synchronize()
+        t_fused = timeit(lambda: step(data, cent))
+        out["fused_step_ms"] = round(t_fused, 3)
+    flop = 2.0 * l * n * k * d
+    byt = 4.0 * l * d * n
+    tf = flop / t_assign / 1e9
+    out.update({
+        "assign_ms": round(t_assign, 3), "update_ms": round(t_update, 3),
+        "iter_ms": round(out.get("fused_step_ms", t_assign + t_update), 3),
+        "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                     "kernel": "max_sim_codebook_kernel (fp32 MFMA)", "kernel_ms": round(t_assign, 3),
+                     "algorithmic_flops_per_launch": flop},
+        "update_roofline": hbm_roofline(byt + 8.0 * l * n, t_update, "centroid_accum_mfma_kernel + finalize",
+                                        stream_peak)})
+    if "fused_step_ms" in out:
+        tf2 = flop / out["fused_step_ms"] / 1e9
+        out["fused_roofline"] = {"bound": "mfma", "achieved": round(tf2, 1), "peak": MFMA_F32_PEAK_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": round(tf2 / MFMA_F32_PEAK_TFLOPS, 4),
+                                 "kernel": "kmeans_step_kernel (assign + update, data read once)"}
+    return out
+
+
+def secondary_pass(device, budget_s, only=None):
+    out = {}
+    t_start = time.time()
+    try:
+        sp = stream_peak_gbps(device)
+        out["stream_peak"] = {"value": round(sp, 1), "unit": "GB/s", "frac_of_spec": round(sp / HBM_PEAK_GBPS, 4),
+                              "what": "tpq_ubench_stream_read, 8 GiB buffer, dwordx4 loads, best of 5"}
+    except Exception as e:
+        sp = None
+        out["stream_peak"] = {"error": repr(e)[:300]}
+    for name, fn in (("c4", secondary_c4), ("c3", secondary_c3), ("c5", secondary_c5)):
+        if only and name not in only:
+            continue
+        if time.time() - t_start > budget_s:
+            out[name] = {"skipped": f"secondary budget of {budget_s:.0f} s spent"}
+            continue
+        t0 = time.time()
+        try:
+            free, _ = torch.cuda.mem_get_info()
+            if free < 48 * 2 ** 30:
+                out[name] = {"skipped": f"needs ~40 GB of HBM, {free >> 30} GiB free"}
+                continue
+            out[name] = fn(device, sp)
+            attach_traffic(out[name]["roofline"], name)
+        except Exception as e:
+            out[name] = {"error": repr(e)[:300]}
+        out[name]["wall_s"] = round(time.time() - t0, 1)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return out, sp
+
+
+# ---------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_command(n, argv, port=None):
+    """the one-rank-per-GPU launch of this script (what the driver runs for N > 1)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.call(launch_command(args.gpus, sys.argv[1:]), env=env)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=["c2", "c4"], default="c2",
+                    help="c2 = SIFT1M shape (BASELINE.json configs[1], the headline); "
+                         "c4 = 100 M vectors, n_cells=16384, n_probe=64 (configs[3])")
     ap.add_argument("--nq", type=int, default=10000)
-    ap.add_argument("--n-base", type=int, default=1000000)
+    ap.add_argument("--n-base", type=int, default=None)
     ap.add_argument("--n-train", type=int, default=100000)
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--m", type=int, default=64)
-    ap.add_argument("--n-cells", type=int, default=1024)
-    ap.add_argument("--n-probe", type=int, default=32)
+    ap.add_argument("--n-cells", type=int, default=None)
+    ap.add_argument("--n-probe", type=int, default=None)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--layout", choices=["packed", "ref"], default="packed")
+    ap.add_argument("--data-dir", default=os.environ.get("TPQ_DATA_DIR"),
+                    help="directory with sift_base/learn/query.fvecs (+ sift_groundtruth.ivecs)")
     ap.add_argument("--cpu-sample", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--secondary-only", default=None, help="comma list of c3,c4,c5 (profiling)")
+    ap.add_argument("--secondary-budget", type=float, default=60.0)
+    args = ap.parse_args(argv)
+    c4 = args.workload == "c4"
+    args.n_base = args.n_base or (100_000_000 if c4 else 1_000_000)
+    args.n_cells = args.n_cells or (16384 if c4 else 1024)
+    args.n_probe = args.n_probe or (64 if c4 else 32)
+    return args
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,8 +515,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if one_device else "nccl"
         if one_device:
             dist.init_process_group("gloo")
         else:
@@ -133,104 +527,116 @@ def main():
     from torchpq_amd import distributed as tpd
     from torchpq_amd.index import IVFPQIndex
 
+    # ---- secondary pass first (N=1 only): it needs the HBM the headline index does not -------
+    secondary, stream_peak = None, None
+    if world == 1 and args.secondary_only:
+        secondary, stream_peak = secondary_pass(device, 1e9, set(args.secondary_only.split(",")))
+        print(json.dumps({"secondary": secondary}))
+        return
+    if world == 1 and not args.no_secondary and args.workload == "c2":
+        secondary, stream_peak = secondary_pass(device, args.secondary_budget)
+
+    # ---- the index: built on rank 0, replicated with one broadcast per buffer ------------------
     t_train = t_add = 0.0
-    if rank == 0:
-        idx, base, centers, gen, t_train, t_add = build_index(args, device)
-    else:
-        idx = IVFPQIndex(d_vector=args.d, n_subvectors=args.m, n_cells=args.n_cells, device=str(device))
-        base = None
+    base = gt_nn = None
+    data_label = "synthetic (SIFT1M-shaped: non-negative integer-valued clustered fp32, low intrinsic dimension)"
+    real = load_texmex(args.data_dir, "sift", device, args.n_base, args.nq) if args.workload == "c2" else None
+    synth = SiftLike(args.d, device)
+    if args.workload == "c4":
+        data_label = "synthetic (uniform random codes, multinomial cell sizes, random codebooks)"
+        if rank == 0:
+            idx = fabricate_index(device, args.d, args.m, args.n_cells, args.n_base, seed=1236)
+    elif rank == 0:
+        if real is not None:
+            base, train, _, _ = real
+            data_label = f"SIFT1M from {args.data_dir}"
+            if train is None:
+                train = base[:, :args.n_train].contiguous()
+        else:
+            base = synth.sample(args.n_base, seed=1)
+            gsel = torch.Generator(device=device)
+            gsel.manual_seed(2)
+            train = base[:, torch.randperm(args.n_base, generator=gsel, device=device)[:args.n_train]].contiguous()
+        idx, t_train, t_add = build_index(args, device, base, train)
+        del train
+    if rank != 0:
+        idx = IVFPQIndex(d_vector=args.d, n_subvectors=args.m, n_cells=args.n_cells, initial_size=1,
+                         device=str(device))
+    t_bcast = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.time()
+        tpd.replicate_index(idx, src=0)  # the one collective: RCCL broadcast at load
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_bcast = time.time() - t0
     idx.n_probe = args.n_probe
     idx.use_smart_probing = False
     idx.use_packed_layout = args.layout == "packed"
-    if world > 1:
-        tpd.replicate_index(idx, src=0)  # the one collective: RCCL broadcast at load
-    # every rank searches its own query set (weak scaling), same distribution, rank-specific seed
-    qgen = torch.Generator(device=device)
-    qgen.manual_seed(4321 + rank)
-    cgen = torch.Generator(device=device)
-    cgen.manual_seed(1234)
-    centers = make_centers(cgen, args.d, device)
-    queries = sift_like(qgen, args.d, args.nq, centers, device)
 
-    scan = idx._ivfpq_topk._scan
-    for _ in range(args.warmup):
-        idx.search(queries, k=args.k)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    scan.record_events = []
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        vals, ids = idx.search(queries, k=args.k)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    events = scan.record_events
-    scan.record_events = None
+    # every rank searches its own query set (weak scaling): same distribution, rank-specific seed
+    if args.workload == "c4":
+        qg = torch.Generator(device=device)
+        qg.manual_seed(4321 + rank)
+        queries = torch.randn(args.d, args.nq, generator=qg, device=device)
+    elif real is not None:
+        queries, gt_nn = real[2], real[3]
+    else:
+        queries = synth.sample(args.nq, seed=4321 + rank)
+
+    dt, scan_ms, n_batches, vals, ids = time_search(idx, queries, args.k, args.steps, args.warmup,
+                                                    dist if world > 1 else None)
     if world > 1:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     # ---- roofline of the dominant kernel (the list scan) --------------------------------------
-    scan_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
-    _, cells, npl = idx.probe(queries)
-    sizes = idx._cell_size[cells]
-    live = torch.arange(cells.shape[1], device=device)[None, :] < npl[:, None]
-    scanned_slots = int((sizes * live).sum().item())
-    algo_bytes = scanned_slots * args.m  # uint8 codes only: the irreducible read
-    achieved = algo_bytes / (scan_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                "kernel": "scan_packed_kernel" if (args.layout == "packed") else "scan_ref_kernel",
-                "kernel_ms": round(scan_ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
-                "bytes_per_query": round(algo_bytes / args.nq, 1),
-                "cell_imbalance": round(float((idx._cell_size.double() ** 2).sum().item()) * args.n_cells
-                                        / float(idx._cell_size.sum().item()) ** 2, 3)}
+    algo_bytes = scanned_bytes(idx, queries, args.m)  # uint8 codes only: the irreducible read
+    kernel = "scan_packed_kernel" if args.layout == "packed" else "scan_ref_kernel"
+    roofline = hbm_roofline(
+        algo_bytes, scan_ms, kernel, stream_peak, bytes_per_query=round(algo_bytes / args.nq, 1),
+        cell_imbalance=round(float((idx._cell_size.double() ** 2).sum().item()) * args.n_cells
+                             / float(idx._cell_size.sum().item()) ** 2, 3))
+    if args.layout == "packed" and args.workload == "c2":
+        attach_traffic(roofline, "bench_scan_packed")
 
-    # HBM-side bytes per launch come from a separate rocprofv3 --pmc pass over this same command
-    # (FETCH_SIZE, corrected as MI355X_MICROARCH.md prescribes); the committed summary is read back
-    prof = os.path.join(ROOT, "profiles", "r01_bench_scan_packed.json")
-    if args.layout == "packed" and os.path.exists(prof):
-        try:
-            pj = json.load(open(prof))
-            if abs(pj["algorithmic_bytes_per_launch"] - algo_bytes) <= 0.02 * algo_bytes:
-                roofline["traffic"] = round(pj["hbm_side_read_bytes_corrected"])
-                roofline["traffic_source"] = "profiles/r01_bench_scan_packed.json (rocprofv3 --pmc FETCH_SIZE x2)"
-        except Exception:
-            pass
-
+    shape = "SIFT1M" if real is not None else ("SIFT1M-like" if args.workload == "c2" else "synthetic")
     out = {
         "metric": "queries/sec + recall@100, SIFT1M IVFPQ d=128 m=64 nprobe=32",
         "value": round(args.nq * args.steps * world / dt, 1), "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic (SIFT1M-shaped: non-negative integer-valued clustered fp32)",
-        "config": {"workload": f"SIFT1M-like d={args.d} n={args.n_base} IVFPQ n_cells={args.n_cells} "
+        "data": data_label,
+        "config": {"workload": f"{shape} d={args.d} n={args.n_base} IVFPQ n_cells={args.n_cells} "
                                f"m={args.m} nprobe={args.n_probe} k={args.k} on 1xMI355X per rank",
                    "n_query_per_rank": args.nq, "code_layout": args.layout,
                    "codes": "u8 (8-bit PQ)", "arithmetic": "f32 LUT entries, f32 sums, exact ids",
-                   "use_smart_probing": False, "parallelism": f"query-sharded x{world}, replicated index"},
+                   "use_smart_probing": False, "parallelism": f"query-sharded x{world}, replicated index",
+                   "collective_backend": backend, "world_size_seen": world,
+                   "index_broadcast_s": round(t_bcast, 3)},
         "roofline": roofline,
     }
     if rank == 0:
         out["train_s"] = round(t_train, 2)
         out["add_s"] = round(t_add, 2)
-        # recall@100 against exact search on the raw vectors (true nearest neighbour in the top-k,
-        # the reference benchmark's definition -- BASELINE.md) on a 1000-query sample
-        ns = min(1000, args.nq)
-        d2 = (-2.0 * queries[:, :ns].T @ base) + (base * base).sum(0)[None, :]
-        nn = d2.argmin(dim=1)
-        out["recall_gt@%d" % args.k] = round(float((ids[:ns] == nn[:, None]).any(dim=1).float().mean().item()), 4)
-        if not args.no_cpu_baseline and world == 1:  # CPU baseline: rank 0 at N=1 only
+        if base is not None:
+            # recall@k = the true nearest neighbour (exact L2 on the raw vectors) is in the top-k:
+            # the reference benchmark's definition, on a 1000-query sample
+            ns = min(1000, args.nq)
+            nn = gt_nn[:ns] if gt_nn is not None else exact_nn(queries[:, :ns], base)
+            out["recall_gt@%d" % args.k] = round(float((ids[:ns] == nn[:, None]).any(dim=1).float().mean().item()), 4)
+            out["recall_gt@1"] = round(float((ids[:ns, 0] == nn).float().mean().item()), 4)
+        if not args.no_cpu_baseline and world == 1 and args.workload == "c2":  # rank 0 at N=1 only
             cb, cpu_ids = cpu_baseline(idx, queries, args.k, min(args.cpu_sample, args.nq))
             out["cpu_baseline"] = cb
             gpu_ids = ids[:cpu_ids.shape[0]].cpu().numpy()
             inter = [len(np.intersect1d(gpu_ids[q], cpu_ids[q])) for q in range(cpu_ids.shape[0])]
             out["recall_vs_ref@%d" % args.k] = round(float(np.mean(inter)) / args.k, 4)
+        if secondary is not None:
+            out["secondary"] = secondary
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -267,6 +267,14 @@ int tpq_pq_decode(const float* codebook, const uint8_t* codes, float* out, int m
 int tpq_scatter_codes(const uint8_t* codes, const int64_t* address, uint8_t* storage,
                       uint8_t* packed, int m, int64_t n, int64_t n_slots, tpq_stream_t stream);
 
+/* Measurement utility (no reference counterpart): streams `bytes` of `src` through 16-byte
+ * loads from `n_blocks` workgroups of 256 threads (0 = 8 per CU) and discards them.  bench.py
+ * times it on a buffer larger than the 256 MiB Infinity Cache to obtain the box's sustained HBM
+ * read rate, the "measured stream peak" that SURVEY 8d asks roofline fractions to be quoted
+ * against next to the 8 TB/s spec figure.  `sink_or_null`: optional u32 the kernel may bump. */
+int tpq_ubench_stream_read(const void* src, size_t bytes, void* sink_or_null, int n_blocks,
+                           tpq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

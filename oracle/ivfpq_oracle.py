@@ -400,6 +400,42 @@ def kmeans_fit(data, centroids, max_iter, tol, distance="euclidean", numerics="d
     return centroids, labels, it
 
 
+def kmeans_fit_redo(data, centroids, n_redo, max_iter, tol, n_clusters, distance="euclidean",
+                    numerics="direct", assign=None):
+    """The whole of MultiKMeans.fit (clustering/MultiKMeans.py:415-453) including the redo loop:
+    redo 0 starts from ``centroids`` when given, every later redo from
+    ``initialize_centroids`` (:277-283: ONE ``np.random.choice(n, [k], replace=False)`` index
+    set shared by all sub-problems -- the caller seeds np.random); the redo with the smallest
+    inertia ``mean(-maxsims)`` of its LAST assign wins (:440-445, strict ``<``); the labels
+    returned are those of that last assign (taken BEFORE the final update).
+    ``assign`` overrides the arg-max routine (e.g. the C oracle's).
+    Returns (centroids, labels, inertia per redo, steps per redo)."""
+    assign = assign or (lambda a, b: max_sim(a, b, distance, numerics))
+    data = np.asarray(data, dtype=F32)
+    n = data.shape[2]
+    best = None
+    inertias, steps = [], []
+    for _ in range(n_redo):
+        if centroids is None:
+            index = np.random.choice(n, size=[n_clusters], replace=False)
+            centroids = data[:, :, index].copy()
+        it = 0
+        for it in range(1, max_iter + 1):
+            maxsims, labels = assign(data, centroids)
+            new_c = compute_centroids(data, labels, n_clusters)
+            err = ((centroids.astype(F32) - new_c) ** 2).sum(dtype=F32)
+            centroids = new_c
+            if err <= tol:
+                break
+        inertia = float((-maxsims).astype(F32).mean(dtype=np.float64))
+        inertias.append(inertia)
+        steps.append(it)
+        if best is None or inertia < best[0]:
+            best = (inertia, centroids, labels)
+        centroids = None
+    return best[1], best[2], inertias, steps
+
+
 def pq_decode(codebook, codes):
     """codes u8 [m, n] -> reconstruction f32 [m*ds, n].
     Restates pq_decode.cu:8-53 / PQCodec._decode_cpu (codec/PQCodec.py:95-111)."""

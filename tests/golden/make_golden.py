@@ -20,6 +20,7 @@ What is reference-generated (key prefix ``ref_``):
   ref_nprobe_list  the smart-probing expression of IVFPQIndex.py:499-512 evaluated with torch
   fx_container     CellContainer.add sequences incl. expand()      (CellContainer.py:249-367)
   fx_kmeans        MultiKMeans.get_labels / compute_centroids CPU   (MultiKMeans.py:334-380)
+  fx_kmeans_fit    MultiKMeans.fit driver: 1/3 steps, tol exit, n_redo=2 (MultiKMeans.py:415-453)
 What is oracle-generated (key prefix ``orc_``): scan top-k (values, addresses, ids) --
 the reference has no CPU scan; those are regression vectors for the restatement,
 cross-checked in tests against ref_adc_exact.
@@ -192,6 +193,81 @@ def fx_kmeans(torch, tq):
     print("fx_kmeans ok")
 
 
+def fx_kmeans_fit(torch, tq):
+    """The reference's own Lloyd DRIVER (MultiKMeans.fit, MultiKMeans.py:415-453) run on CPU from
+    fixed initial centroids: 1 step, 3 steps, a tolerance early exit, and n_redo=2 (best-inertia
+    selection, second redo initialised by np.random.choice as in :277-283).
+
+    The CPU branch of get_labels never labels the last point and abs()-es its inputs
+    (MultiKMeans.py:352-358); `fit` is therefore run with get_labels bound to the reference's
+    own in-memory branch (:311-313, disabled upstream by `if False`): sim(inplace=False) + max.
+    Everything else -- compute_centroids_loop, calculate_error, calculate_inertia, the tol test,
+    the redo bookkeeping, initialize_centroids -- is the unmodified reference code."""
+    import types
+    rng = np.random.default_rng(21)
+    l, d, n, k = 3, 8, 3000, 24
+    data = np.stack([sift_like(rng, d, n, 10) for _ in range(l)])  # [l, d, n] >= 0
+    init = data[:, :, rng.choice(n, k, replace=False)].copy()
+    out = {"data": data, "init": init}
+
+    def in_memory_get_labels(self, data, centroids):
+        sims = self.sim(data, centroids, inplace=False)
+        return sims.max(dim=-1)
+
+    def run(max_iter, tol, n_redo=1, seed=None, verbose_log=None, init=init):
+        mk = tq.clustering.MultiKMeans(n_clusters=k, distance="euclidean", max_iter=max_iter,
+                                       tol=tol, n_redo=n_redo)
+        mk.get_labels = types.MethodType(in_memory_get_labels, mk)
+        if verbose_log is not None:  # record (error, inertia) per iteration through the
+            mk.verbose = 3           # reference's own progress messages (:433)
+            mk.print_message = lambda msg, level=1: verbose_log.append(msg)
+        if seed is not None:
+            np.random.seed(seed)
+        labels = mk.fit(torch.from_numpy(data.copy()), torch.from_numpy(init.copy()))
+        return mk.centroids.numpy().copy(), labels.numpy().copy()
+
+    for steps in (1, 3):
+        c, lab = run(steps, 0.0)
+        out[f"ref_centroids_{steps}"] = c
+        out[f"ref_labels_{steps}"] = lab
+    # tolerance exit: errors of a 12-step run, then tol halfway between the errors of steps 3 and 4
+    log = []
+    run(12, 0.0, verbose_log=log)
+    errs = [float(m.split("error=")[1].split(",")[0]) for m in log if "iteration" in m]
+    assert len(errs) == 12 and errs[2] > errs[3] > 0, errs
+    tol = 0.5 * (errs[2] + errs[3])
+    c, lab = run(12, tol)
+    c4, lab4 = run(4, 0.0)
+    assert np.array_equal(c, c4) and np.array_equal(lab, lab4), "tol exit must stop after step 4"
+    out["errors_12"] = np.array(errs, dtype=np.float64)
+    out["tol_exit"] = np.float64(tol)
+    out["tol_exit_steps"] = np.int64(4)
+    out["ref_centroids_tol"] = c
+    out["ref_labels_tol"] = lab
+    # n_redo = 2: redo 0 from `init`, redo 1 from np.random.choice under seed 77
+    log = []
+    c, lab = run(3, 0.0, n_redo=2, seed=77, verbose_log=log)
+    inert = [float(m.split("inertia: ")[1].split("time")[0]) for m in log if "redo finished" in m]
+    assert len(inert) == 2
+    out["redo_seed"] = np.int64(77)
+    out["redo_inertia"] = np.array(inert, dtype=np.float64)
+    out["ref_centroids_redo"] = c
+    out["ref_labels_redo"] = lab
+    # ... and from a poor start (all initial centroids within +-1 of one point) so that redo 1 wins
+    bad = (data[:, :, :1] + rng.integers(0, 2, (l, d, k))).astype(np.float32)
+    log = []
+    c, lab = run(3, 0.0, n_redo=2, seed=78, verbose_log=log, init=bad)
+    inert = [float(m.split("inertia: ")[1].split("time")[0]) for m in log if "redo finished" in m]
+    assert len(inert) == 2 and inert[1] < inert[0], inert
+    out["bad_init"] = bad
+    out["redo_b_seed"] = np.int64(78)
+    out["redo_b_inertia"] = np.array(inert, dtype=np.float64)
+    out["ref_centroids_redo_b"] = c
+    out["ref_labels_redo_b"] = lab
+    np.savez_compressed(os.path.join(OUT, "fx_kmeans_fit.npz"), **out)
+    print("fx_kmeans_fit ok: errors", [round(e, 3) for e in errs[:5]], "redo inertia", inert)
+
+
 def fx_residual(torch, tq):
     """pq_use_residual=True: reference train/add on CPU, reference part1/part2/full tables
     (IVFPQIndex.py:160-170, 366-405); scan results from the oracle (no CPU scan in the reference)."""
@@ -325,6 +401,7 @@ def main():
                                   initial_size=128, seed=3, n_probe=8, ks=[10], slim=True),
         "fx_container": lambda: fx_container(torch, tq),
         "fx_kmeans": lambda: fx_kmeans(torch, tq),
+        "fx_kmeans_fit": lambda: fx_kmeans_fit(torch, tq),
         "fx_residual": lambda: fx_residual(torch, tq),
         "fx_ties_tomb": lambda: fx_ties_and_tomb(torch, tq),
         "fx_layout": lambda: fx_layout(torch, tq),

@@ -1,0 +1,92 @@
+"""GPU: the replica path of SURVEY 8e on one device -- two ranks share cuda:0 and rendezvous over
+gloo (RCCL refuses two ranks on one GPU): rank 0 builds an index, replicate_index() broadcasts
+it, the non-source rank load_state_dict()s it and its search() must equal rank 0's bit for bit.
+Also: bench.py --gpus 2 launches its own ranks (TPQ_BENCH_ONE_DEVICE validation hook)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torchpq_amd import distributed as tpd
+    from torchpq_amd.index import IVFPQIndex
+    dev = "cuda:0"
+    d, m, n_cells, n, nq, k = 64, 16, 32, 20000, 300, 20
+    rng = np.random.default_rng(3)
+    base = np.abs(rng.standard_normal((d, n)) * 25).astype(np.float32)
+    queries = torch.from_numpy(np.abs(rng.standard_normal((d, nq)) * 25).astype(np.float32)).to(dev)
+    idx = IVFPQIndex(d_vector=d, n_subvectors=m, n_cells=n_cells, initial_size=8, device=dev)
+    if rank == 0:
+        np.random.seed(3)
+        xb = torch.from_numpy(base).to(dev)
+        idx.train(xb)
+        idx.add(xb[:, :12000].contiguous(), ids=torch.arange(12000, device=dev) * 2 + 5)
+        idx.add(xb[:, 12000:].contiguous(), ids=torch.arange(12000, n, device=dev) * 2 + 5)
+        idx.remove(ids=torch.arange(100, device=dev) * 2 + 5)
+        idx.n_probe = 6
+        idx.use_smart_probing = True
+        idx.smart_probing_temperature = 20.0
+    else:
+        assert not idx.vq_codec.is_trained
+    tpd.replicate_index(idx, src=0)
+    assert idx.vq_codec.is_trained and idx.pq_codec.is_trained
+    assert idx.n_probe == 6 and idx.use_smart_probing and idx.smart_probing_temperature == 20.0
+    assert idx.n_items == n - 100 and idx.max_id == (n - 1) * 2 + 5
+    # every rank searches the FULL batch here (so results are comparable) and its own shard
+    v, i = idx.search(queries, k=k)
+    vs, is_ = tpd.sharded_search(lambda x, kk: idx.search(x, k=kk), queries, k, gather=True)
+    torch.cuda.synchronize()
+    pair = [None, None]
+    dist.all_gather_object(pair, (v.cpu(), i.cpu(), vs.cpu(), is_.cpu()))
+    if rank == 0:
+        (v0, i0, g0, gi0), (v1, i1, g1, gi1) = pair
+        ret["replica_equal"] = bool(torch.equal(v0, v1) and torch.equal(i0, i1))
+        ret["gather_equal"] = bool(torch.equal(g0, v0) and torch.equal(gi0, i0)
+                                   and torch.equal(g1, v0) and torch.equal(gi1, i0))
+        ret["finite"] = bool(torch.isfinite(v0[:, 0]).all()) and int(i0.min()) >= 5
+    dist.destroy_process_group()
+
+
+def test_replicate_index_two_ranks_one_gpu():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29600 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret.get("replica_equal") is True
+    assert ret.get("gather_equal") is True
+    assert ret.get("finite") is True
+
+
+def test_bench_gpus2_self_launches_under_the_one_device_hook():
+    """python bench.py --gpus 2 with no launcher around it: spawns 2 ranks itself and rank 0 prints
+    one JSON line with n_gpus=2 (reduced sizes; the hook puts both ranks on cuda:0 over gloo)"""
+    env = dict(os.environ, TPQ_BENCH_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+         "--nq", "512", "--n-base", "60000", "--n-train", "20000", "--n-cells", "64", "--n-probe", "8"],
+        env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["world_size_seen"] == 2
+    assert rec["config"]["collective_backend"] == "gloo"
+    assert rec["value"] > 0 and rec["scaling"] == "weak" and rec["steps"] == 2
+    assert "cpu_baseline" not in rec and "secondary" not in rec

@@ -366,8 +366,34 @@ def test_graphed_search_replays_search(residual):
         v, i = g(q)
         ev, ei = idx.search(q, k=k)
         assert torch.equal(v, ev) and torch.equal(i, ei)
+    # a stale graph refuses to replay: knob change, re-train (new codebook buffers), residual
+    # table rebuild, add -- each detected (only _codes_version used to be checked)
+    idx.n_probe = 3
+    with pytest.raises(RuntimeError, match="n_probe"):
+        g(q)
+    idx.n_probe = 5
+    assert g.stale_reason() is None
+    g(q)
+    idx.use_smart_probing = False
+    with pytest.raises(RuntimeError, match="use_smart_probing"):
+        g(q)
+    idx.use_smart_probing = True
+    if residual:
+        idx.use_precomputed = True   # rebuilds the part2 table: new buffer
+        with pytest.raises(RuntimeError, match="part2|slot_term|cell_bound"):
+            g(q)
+        g = idx.graphed_search(nq, k=k)
+        v, i = g(q)
+        ev, ei = idx.search(q, k=k)
+        assert torch.equal(v, ev) and torch.equal(i, ei)
+    np.random.seed(13)
+    idx.train(T(base), force_retrain=True)  # registers new codebooks; codes are now meaningless
+    with pytest.raises(RuntimeError, match="codebook|part2"):
+        g(q)
+    g = idx.graphed_search(nq, k=k)
+    g(q)
     idx.add(T(base[:, :10] + 1), ids=torch.arange(n, n + 10, device=DEV))
-    with pytest.raises(AssertionError):
+    with pytest.raises(RuntimeError, match="_codes_version"):
         g(q)
 
 
@@ -437,3 +463,51 @@ def test_search_edge_cases_many_probes_batches_empty():
     ev, ei, _, npl = _expected_search(idx, queries, 10)
     assert np.array_equal(N(v_s), ev) and np.array_equal(N(i_s), ei)
     assert npl.min() >= 1 and npl.max() <= 12
+
+
+def test_remove_on_a_state_dict_with_holes(fx_tomb):
+    """remove() on a foreign index whose cells hold tombstones INSIDE [start, start+size)
+    used to trip a bare assert; now the cells are compacted first.  Result = oracle search on the
+    surviving items; codes and ids of survivors are untouched."""
+    fx = fx_tomb
+    idx = _index_from_fixture(fx)
+    assert idx._has_holes
+    idx.n_probe = int(fx["n_probe"])
+    idx.use_smart_probing = False
+    live_before = N(idx._address2id)
+    live_ids = np.sort(live_before[live_before >= 0])
+    codes_before = {int(i): N(idx.get_data_by_address(idx.get_address_by_id(torch.tensor([i], device=DEV))))[:, 0]
+                    for i in live_ids[:40]}
+    victims = live_ids[::7]
+    idx.remove(ids=T(victims))
+    assert not idx._has_holes
+    st, sz, cap = N(idx._cell_start), N(idx._cell_size), N(idx._cell_capacity)
+    ie, a2i = N(idx._is_empty), N(idx._address2id)
+    for c in range(idx.n_cells):  # dense cells again
+        assert np.all(ie[st[c]:st[c] + sz[c]] == 0) and np.all(ie[st[c] + sz[c]:st[c] + cap[c]] == 1)
+        assert np.all(a2i[st[c]:st[c] + sz[c]] >= 0) and np.all(a2i[st[c] + sz[c]:st[c] + cap[c]] == -1)
+    left = np.sort(a2i[a2i >= 0])
+    assert np.array_equal(left, np.setdiff1d(live_ids, victims))
+    assert idx.n_items == left.shape[0]
+    for i, code in codes_before.items():
+        if i in set(victims.tolist()):
+            continue
+        adr = idx.get_address_by_id(torch.tensor([i], device=DEV))
+        assert np.array_equal(N(idx.get_data_by_address(adr))[:, 0], code)
+    v, i = idx.search(T(fx["queries"]), k=10)
+    ev, ei, _, _ = _expected_search(idx, fx["queries"], 10)
+    assert np.array_equal(N(v), ev) and np.array_equal(N(i), ei)
+    assert not np.isin(N(i), victims).any() and not np.isin(N(i), fx["dead_ids"]).any()
+
+
+def test_is_trained_sees_in_place_writes():
+    """the cached trained flag follows in-place updates of the buffer"""
+    from torchpq_amd.codec import VQCodec
+    c = VQCodec(n_clusters=4).to(DEV)
+    assert c.is_trained is False
+    c._is_trained.fill_(True)
+    assert c.is_trained is True
+    c._is_trained.data = torch.tensor(False, device=DEV)
+    assert c.is_trained is False
+    c._is_trained.copy_(torch.tensor(True))
+    assert c.is_trained is True

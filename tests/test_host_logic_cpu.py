@@ -53,3 +53,49 @@ def test_cpu_devices_are_refused():
                  lambda: FlatIndex(d_vector=32, device="cpu")):
         with pytest.raises((RuntimeError, AssertionError)):
             ctor()
+
+
+def test_texmex_readers_round_trip(tmp_path):
+    """fvecs / ivecs (the SIFT1M / GIST1M file format bench.py --data-dir reads)"""
+    import numpy as np
+    from torchpq_amd import datasets
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((37, 128)).astype(np.float32)
+    gt = rng.integers(0, 1000, (37, 100)).astype(np.int32)
+    d = tmp_path / "sift"
+    d.mkdir()
+    datasets.write_fvecs(d / "sift_base.fvecs", x)
+    datasets.write_fvecs(d / "sift_query.fvecs", x[:5])
+    datasets.write_ivecs(d / "sift_groundtruth.ivecs", gt)
+    assert np.array_equal(datasets.read_fvecs(d / "sift_base.fvecs"), x)
+    assert np.array_equal(datasets.read_fvecs(d / "sift_base.fvecs", 10), x[:10])
+    assert np.array_equal(datasets.read_ivecs(d / "sift_groundtruth.ivecs"), gt)
+    raw = np.fromfile(d / "sift_base.fvecs", dtype="<i4")
+    assert raw[0] == 128 and raw[129] == 128          # int32 dimension in front of every vector
+    p = datasets.find_texmex(str(tmp_path), "sift")
+    assert p["base"].endswith("sift_base.fvecs") and p["learn"] is None and p["groundtruth"]
+    assert datasets.find_texmex(str(tmp_path), "gist") is None
+    with open(d / "bad.fvecs", "wb") as f:
+        f.write(b"\\x80\\x00\\x00\\x00" + b"\\x00" * 7)
+    import pytest
+    with pytest.raises(ValueError):
+        datasets.read_fvecs(d / "bad.fvecs")
+
+
+def test_bench_launch_command_and_defaults():
+    """bench.py --gpus N (N > 1, no launcher) re-executes itself as one rank per GPU"""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "5"], port=29512)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd and "29512" in cmd
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "5"] and cmd[-5].endswith("bench.py")
+    a = bench.parse_args([])
+    assert (a.gpus, a.workload, a.n_base, a.n_cells, a.n_probe, a.m, a.k) == (1, "c2", 1_000_000, 1024, 32, 64, 100)
+    a = bench.parse_args(["--workload", "c4", "--gpus", "8"])
+    assert (a.n_base, a.n_cells, a.n_probe) == (100_000_000, 16384, 64)
+    assert len(bench.source_fingerprint()) == 16

@@ -280,3 +280,37 @@ def test_oracle_pinned_against_live_reference():
         warnings.simplefilter("ignore")
         done = pin_against_reference.run(verbose=False)
     assert len(done) == 7
+
+
+def _fit_case(fx, case):
+    """(init, n_redo, max_iter, tol, seed) of each reference-run fit case in fx_kmeans_fit"""
+    return {
+        "1": (fx["init"], 1, 1, 0.0, None),
+        "3": (fx["init"], 1, 3, 0.0, None),
+        "tol": (fx["init"], 1, 12, float(fx["tol_exit"]), None),
+        "redo": (fx["init"], 2, 3, 0.0, int(fx["redo_seed"])),
+        "redo_b": (fx["bad_init"], 2, 3, 0.0, int(fx["redo_b_seed"])),
+    }[case]
+
+
+@pytest.mark.parametrize("case", ["1", "3", "tol", "redo", "redo_b"])
+@pytest.mark.parametrize("numerics", ["direct", "expanded"])
+def test_kmeans_fit_driver_matches_reference(fx_kmeans_fit, case, numerics):
+    """oracle.kmeans_fit_redo vs the reference's own MultiKMeans.fit run on CPU (fixture made by
+    tests/golden/make_golden.py::fx_kmeans_fit): steps, tolerance exit, best-of-n_redo."""
+    fx = fx_kmeans_fit
+    init, n_redo, max_iter, tol, seed = _fit_case(fx, case)
+    if seed is not None:
+        np.random.seed(seed)
+    cen, labels, inertias, steps = orc.kmeans_fit_redo(
+        fx["data"], init.copy(), n_redo, max_iter, tol, init.shape[2],
+        assign=lambda a, b: c_oracle.max_sim(a, b, "euclidean", numerics))
+    assert (labels == fx[f"ref_labels_{case}"]).mean() >= 0.999
+    np.testing.assert_allclose(cen, fx[f"ref_centroids_{case}"], rtol=1e-4, atol=2e-2)
+    assert np.mean(np.abs(cen - fx[f"ref_centroids_{case}"]) > 1e-3) < 0.01
+    if case == "tol":
+        assert steps == [int(fx["tol_exit_steps"])]
+    if case in ("redo", "redo_b"):
+        ref_in = fx["redo_inertia" if case == "redo" else "redo_b_inertia"]
+        np.testing.assert_allclose(inertias, ref_in, rtol=1e-4)
+        assert int(np.argmin(inertias)) == int(np.argmin(ref_in)) == (0 if case == "redo" else 1)

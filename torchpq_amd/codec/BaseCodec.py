@@ -16,14 +16,18 @@ class BaseCodec(CustomModule):
 
     @property
     def is_trained(self):
-        # bool() of a device tensor is a host sync: read the flag once per buffer object (train(),
+        # bool() of a device tensor is a host sync: read the flag once per buffer state (train(),
         # load_state_dict() and .to() all install a NEW tensor), so search() stays sync-free and
         # can be captured in a HIP graph
+        # (in-place writes -- `_is_trained.fill_()`, `.data = ...`, a stock load_state_dict
+        # copying into the buffer -- bump the tensor's version counter or replace its storage)
+        t = self._is_trained
+        key = (t._version, t.data_ptr())
         cached = self.__dict__.get("_trained_seen")
-        if cached is None or cached[0] is not self._is_trained:
-            cached = (self._is_trained, bool(self._is_trained))
+        if cached is None or cached[0] is not t or cached[1] != key:
+            cached = (t, key, bool(t))
             self.__dict__["_trained_seen"] = cached
-        return cached[1]
+        return cached[2]
 
     def _trained(self, value):
         if not isinstance(value, bool):

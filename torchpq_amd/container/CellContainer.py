@@ -221,6 +221,51 @@ class CellContainer(BaseContainer):
         self.print_message(f"{n_data} new items added", 1)
         return (ids, write_address) if return_address else ids
 
+    def _compact(self):
+        """Pack the live slots of every cell to the front of its range (stable), so that
+        [start, start+size) holds no tombstone.  Capacities and starts are unchanged."""
+        dev = self._storage.device
+        cap = self.capacity
+        pos = torch.arange(cap, device=dev)
+        cell = torch.repeat_interleave(torch.arange(self.n_cells, device=dev), self._cell_capacity)
+        if cell.numel() != cap:
+            raise RuntimeError("CellContainer: cell capacities do not tile the storage")
+        live = self._is_empty == 0
+        # rank of each live slot among the live slots of its cell
+        csum = torch.cumsum(live.long(), 0)
+        before_cell = torch.cat([csum.new_zeros(1), csum])[self._cell_start]
+        rank = csum - 1 - before_cell[cell]
+        src = pos[live]
+        dst = (self._cell_start[cell] + rank)[live]
+        n_live = torch.zeros(self.n_cells, device=dev, dtype=torch.long).scatter_add_(
+            0, cell[live], torch.ones_like(src))
+        storage = torch.zeros_like(self._storage)
+        storage[:, dst] = self._storage[:, src]
+        a2i = torch.full_like(self._address2id, -1)
+        a2i[dst] = self._address2id[src]
+        is_empty = torch.ones_like(self._is_empty)
+        is_empty[dst] = 0
+        self._storage.copy_(storage)
+        self._address2id.copy_(a2i)
+        self._is_empty.copy_(is_empty)
+        self._cell_size.copy_(n_live)
+        self._has_holes = False
+        self._packed_valid = False
+        self._codes_version += 1
+        self._drop_inverse_id_mapping()
+
+    def _apply(self, fn, *args, **kwargs):
+        """.to() / .cuda(): the derived scan-layout copy is not a registered buffer -- drop it
+        (rebuilt lazily on the new device) and follow the buffers' device"""
+        out = super()._apply(fn, *args, **kwargs)
+        new_dev = str(self._storage.device)
+        if new_dev != str(torch.device(self.device)) or (
+                self._packed is not None and self._packed.device != self._storage.device):
+            self._packed = None
+            self._packed_valid = False
+            self.device = new_dev
+        return out
+
     def remove(self, ids=None, address=None):
         """Remove by id or by address.  The reference's guard `if n_removed <= self.n_items: return`
         (:381-383) is inverted, so its remove() never removes anything; this one does what the code
@@ -240,6 +285,12 @@ class CellContainer(BaseContainer):
         n_removed = address.shape[0]
         if n_removed == 0:
             return
+        if self._has_holes:
+            # a foreign state_dict left tombstones inside some [start, start+size): the dense
+            # bookkeeping below needs every cell packed first (addresses change; ids do not)
+            ids_to_remove = self._address2id[address]
+            self._compact()
+            address = self.get_address_by_id(ids_to_remove)
         cells = self.get_cell_by_address(address)
         ucells, counts = cells.unique(return_counts=True)
         old_end = (self._cell_start + self._cell_size)[ucells]
@@ -253,7 +304,9 @@ class CellContainer(BaseContainer):
         movers = tail[~removed_flag[tail]]                      # survivors sitting in a tail
         cell_of_adr = torch.searchsorted(ucells, cells)
         holes = address[address < new_end[cell_of_adr]]         # removed slots below the new end
-        assert movers.shape[0] == holes.shape[0]
+        if movers.shape[0] != holes.shape[0]:
+            raise RuntimeError("CellContainer.remove: cell bookkeeping is inconsistent "
+                               f"({movers.shape[0]} survivors to move, {holes.shape[0]} holes)")
         if holes.shape[0]:
             self._storage[:, holes] = self._storage[:, movers]
             self._address2id[holes] = self._address2id[movers]

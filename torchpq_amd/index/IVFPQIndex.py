@@ -146,9 +146,13 @@ class IVFPQIndex(CellContainer):
         """[m, n_cells, 256]: -2 c_j . r_jc - |r_jc|^2 (reference :160-170; one-off library bmm)"""
         pq_codebook = self.pq_codec.codebook
         vq_codebook = self.vq_codec.codebook.reshape(self.n_subvectors, self.d_subvector, self.n_cells)
-        self._precomputed_part2 = (torch.bmm(vq_codebook.transpose(-1, -2), pq_codebook) * -2
-                                   - pq_codebook.norm(dim=1).pow(2)[:, None])
-        self._part2_by_cell = self._precomputed_part2.transpose(0, 1).contiguous()
+        part2 = (torch.bmm(vq_codebook.transpose(-1, -2), pq_codebook) * -2
+                 - pq_codebook.norm(dim=1).pow(2)[:, None])
+        # one resident copy, in the [n_cells, m, 256] order the scan kernels read;
+        # `_precomputed_part2` keeps the reference's [m, n_cells, 256] shape as a view of it
+        self._part2_by_cell = part2.transpose(0, 1).contiguous()
+        del part2
+        self._precomputed_part2 = self._part2_by_cell.transpose(0, 1)
         self._slot_terms = None
 
     def _residual_slot_terms(self):

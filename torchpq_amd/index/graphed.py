@@ -12,9 +12,39 @@ import torch
 class GraphedSearch:
     """``g = index.graphed_search(n_query, k); values, ids = g(x)``.
 
-    The graph holds the index buffers' addresses: re-create it after add / remove / train /
-    load_state_dict or a knob change (n_probe, use_smart_probing, ...).  The returned tensors are
-    the graph's static outputs -- clone them if they must survive the next call."""
+    The graph holds the index buffers' addresses and has the knobs baked in as kernel arguments:
+    re-create it after add / remove / train / load_state_dict or a knob change (n_probe,
+    use_smart_probing, ...).  __call__ checks exactly that -- it compares a snapshot of every
+    knob and of the identity (object, address, version counter) of every buffer search() reads
+    with the live index and refuses to replay a stale graph; the captured buffers are kept alive
+    by the snapshot, so a replay can never read freed memory.  The returned tensors are the
+    graph's static outputs -- clone them if they must survive the next call."""
+
+    KNOBS = ("n_probe", "use_smart_probing", "_smart_probing_temperature", "use_packed_layout",
+             "use_fused_lut", "use_fused_probe", "use_cublas", "_use_precomputed", "pq_use_residual",
+             "distance", "max_query_batch", "_has_holes", "_codes_version")
+
+    @staticmethod
+    def _buffers(index):
+        """the device buffers a search() reads (None where the index does not have one)"""
+        slot = index._slot_terms
+        return {
+            "vq_codebook": index.vq_codec.codebook, "pq_codebook": index.pq_codec.codebook,
+            "_storage": index._storage, "_packed": index._packed if index._packed_valid else None,
+            "_is_empty": index._is_empty, "_address2id": index._address2id,
+            "_cell_start": index._cell_start, "_cell_size": index._cell_size,
+            "_part2_by_cell": index._part2_by_cell,
+            "slot_term": None if slot is None else slot[1],
+            "cell_bound": None if slot is None else slot[2],
+        }
+
+    @classmethod
+    def _snapshot(cls, index):
+        knobs = tuple(getattr(index, name) for name in cls.KNOBS)
+        bufs = cls._buffers(index)
+        ident = tuple((name, None if t is None else (t.data_ptr(), tuple(t.shape), t._version))
+                      for name, t in bufs.items())
+        return knobs, ident, bufs
 
     def __init__(self, index, n_query, k, warmup=2):
         assert n_query >= 1
@@ -22,7 +52,6 @@ class GraphedSearch:
         self.n_query = n_query
         self.k = k
         device = torch.device(index.device)
-        self._codes_version = index._codes_version
         self.x = torch.zeros(index.d_vector, n_query, device=device, dtype=torch.float32)
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
@@ -33,11 +62,26 @@ class GraphedSearch:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.values, self.ids = index.search(self.x, k=k)
+        # taken AFTER the capture: lazily built state is in place; `_held` pins the tensors
+        self._knobs, self._ident, self._held = self._snapshot(index)
+
+    def stale_reason(self):
+        """None while the captured graph still describes the index, else what changed"""
+        knobs, ident, _ = self._snapshot(self.index)
+        for name, old, new in zip(self.KNOBS, self._knobs, knobs):
+            if old != new:
+                return f"{name} changed ({old!r} -> {new!r})"
+        for (name, old), (_, new) in zip(self._ident, ident):
+            if old != new:
+                return f"buffer {name} was replaced or written"
+        return None
 
     def __call__(self, x):
         assert x.shape == self.x.shape, f"graph was captured for queries of shape {tuple(self.x.shape)}"
-        assert self._codes_version == self.index._codes_version, \
-            "the index changed since the graph was captured: call index.graphed_search() again"
+        why = self.stale_reason()
+        if why is not None:
+            raise RuntimeError(f"the index changed since the graph was captured ({why}): "
+                               "call index.graphed_search() again")
         self.x.copy_(x, non_blocking=True)
         self.graph.replay()
         return self.values, self.ids
