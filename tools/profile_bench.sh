@@ -1,31 +1,50 @@
 #!/bin/bash
 # Round profile of bench.py on the GPU box (run through gpurun from the repo root):
-#   bash tools/profile_bench.sh r01
-# 1. plain bench line                         -> gpurun_out/<tag>/bench.json
-# 2. rocprofv3 --kernel-trace --stats         -> gpurun_out/<tag>/stats/
-# 3. three separate --pmc passes (HBM-side fetch, TCC, SQ/LDS) -> gpurun_out/<tag>/pmc_*/
-# 4. tools/summarize_rocprof.py               -> gpurun_out/<tag>/scan_packed.json
-# Copy bench.json, the kernel stats CSV and scan_packed.json into profiles/ afterwards.
+#   bash tools/profile_bench.sh r02 [c2 c3 c4 c5]
+# per workload W (c2 = the headline bench line; c3/c4/c5 = `bench.py --secondary-only W`):
+#   1. plain run                                 -> gpurun_out/<tag>/<W>/bench.json
+#   2. rocprofv3 --kernel-trace --stats          -> gpurun_out/<tag>/<W>/stats/
+#   3. separate --pmc passes (HBM-side fetch, TCC, SQ/LDS) -> gpurun_out/<tag>/<W>/pmc_*/
+#   4. tools/summarize_rocprof.py                -> gpurun_out/<tag>/<W>/summary.json
+# Copy bench.json, the kernel-stats CSV and summary.json into profiles/ afterwards
+# (tools/collect_profiles.py <tag> does it).
 set -uo pipefail
-TAG="${1:-r01}"
+TAG="${1:-r02}"
+shift || true
+WORKLOADS="${*:-c2 c3 c4 c5}"
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
-OUT="${ROOT}/gpurun_out/${TAG}"
-mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python ${ROOT}/bench.py --steps 20 --warmup 3"
-$BENCH > "$OUT/bench.json" 2> "$OUT/bench.err"
-tail -1 "$OUT/bench.json"
-ALGO=$(python -c "import json;print(json.load(open('$OUT/bench.json'))['roofline']['algorithmic_bytes_per_launch'])")
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $BENCH --no-cpu-baseline > "$OUT/run_stats.log" 2>&1
-i=0
-for ctrs in "FETCH_SIZE TCC_EA0_RDREQ_sum" "TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
-  i=$((i + 1))
-  rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/pmc_$i" -o run -- $BENCH --steps 5 --no-cpu-baseline > "$OUT/run_pmc$i.log" 2>&1
+for W in $WORKLOADS; do
+  OUT="${ROOT}/gpurun_out/${TAG}/${W}"
+  mkdir -p "$OUT"
+  case "$W" in
+    c2) BENCH="python ${ROOT}/bench.py --steps 20 --warmup 3 --no-secondary"; KERNEL="scan_packed_kernel";;
+    c3) BENCH="python ${ROOT}/bench.py --secondary-only c3"; KERNEL="scan_packed_kernel";;
+    c4) BENCH="python ${ROOT}/bench.py --secondary-only c4"; KERNEL="scan_packed_kernel";;
+    c5) BENCH="python ${ROOT}/bench.py --secondary-only c5"; KERNEL="max_sim_codebook_kernel";;
+  esac
+  $BENCH > "$OUT/bench.json" 2> "$OUT/bench.err"
+  tail -c 600 "$OUT/bench.json"; echo
+  ALGO=$(python - "$OUT/bench.json" "$W" <<'PY'
+import json, sys
+j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+r = j["roofline"] if sys.argv[2] == "c2" else j["secondary"][sys.argv[2]]["roofline"]
+print(r.get("algorithmic_bytes_per_launch", r.get("algorithmic_flops_per_launch", 0)))
+PY
+)
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $BENCH --no-cpu-baseline > "$OUT/run_stats.log" 2>&1
+  i=0
+  PASSES=("FETCH_SIZE TCC_EA0_RDREQ_sum")   # c3/c4/c5: HBM-side bytes only (each pass re-builds the workload)
+  [[ "$W" == "c2" ]] && PASSES+=("TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE")
+  for ctrs in "${PASSES[@]}"; do
+    i=$((i + 1))
+    STEPS=""; [[ "$W" == "c2" ]] && STEPS="--steps 5"
+    rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/pmc_$i" -o run -- $BENCH $STEPS --no-cpu-baseline > "$OUT/run_pmc$i.log" 2>&1
+  done
+  # flatten rocprofv3's <dir>/<host>/ level
+  for d in "$OUT"/stats "$OUT"/pmc_*; do
+    find "$d" -mindepth 2 -name "*.csv" -exec mv {} "$d"/ \; 2>/dev/null
+  done
+  python "${ROOT}/tools/summarize_rocprof.py" "$OUT" "$KERNEL" "$ALGO" > "$OUT/summary.json"
+  head -c 1200 "$OUT/summary.json"; echo
 done
-# flatten rocprofv3's <dir>/<host>/ level
-for d in "$OUT"/stats "$OUT"/pmc_*; do
-  find "$d" -mindepth 2 -name "*.csv" -exec mv {} "$d"/ \; 2>/dev/null
-done
-python "${ROOT}/tools/summarize_rocprof.py" "$OUT" scan_packed "$ALGO" > "$OUT/scan_packed.json"
-head -c 1500 "$OUT/scan_packed.json"
-ls "$OUT" "$OUT/stats" | head -30

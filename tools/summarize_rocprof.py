@@ -14,6 +14,16 @@ import sys
 def main():
     root, kernel, algo = sys.argv[1], sys.argv[2], float(sys.argv[3])
     out = {"kernel_filter": kernel, "algorithmic_bytes_per_launch": algo, "kernels": [], "pmc": {}}
+    try:  # the kernel sources this profile was taken from (bench.py attaches it only on a match)
+        import importlib.util
+        here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(here, "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        out["source_fingerprint"] = bench.source_fingerprint()
+    except Exception as e:
+        out["source_fingerprint"] = None
+        out["source_fingerprint_error"] = repr(e)
     for f in glob.glob(os.path.join(root, "stats", "*kernel_stats.csv")):
         for r in list(csv.DictReader(open(f)))[:12]:
             out["kernels"].append({"name": r["Name"][:110], "calls": int(r["Calls"]),
