@@ -56,7 +56,7 @@ class SiftLike:
     what makes an IVF probe of 32 / 1024 cells miss a few true neighbours -- recall@100 lands
     near the reference's 0.95 instead of a non-diagnostic 1.0."""
 
-    def __init__(self, d, device, seed=1234, n_centers=256, latent_dim=12, latent_scale=55.0,
+    def __init__(self, d, device, seed=1234, n_centers=256, latent_dim=10, latent_scale=55.0,
                  noise=12.0):
         g = torch.Generator(device=device)
         g.manual_seed(seed)

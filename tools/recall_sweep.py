@@ -38,6 +38,8 @@ def main():
         dict(n_centers=256, latent_dim=1, latent_scale=0.0, noise=30.0),   # round-1 generator
         dict(n_centers=256, latent_dim=1, latent_scale=0.0, noise=45.0),
     ]
+    if a.grid != "default":
+        grid = json.loads(a.grid)
     args = bench.parse_args(["--no-secondary"])
     for g in grid:
         t0 = time.time()

@@ -11,7 +11,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtorchpq_amd.so")
+# TPQ_AMD_LIB: load an experimental build of the SAME library instead (tools/build_variant.sh;
+# kernel A/B measurements only -- there is still no fallback of any kind)
+LIB_PATH = os.environ.get("TPQ_AMD_LIB") or os.path.join(_HERE, "libtorchpq_amd.so")
 
 METRIC_NEG_SQ_L2 = 0
 METRIC_INNER = 1

@@ -11,11 +11,40 @@
 // tpq_compute_centroids replaces compute_centroids (torchpq/kernels/cuda/compute_centroids.cu:10-86):
 // the reference launches l*d blocks that each re-read all labels; here data and labels are read
 // exactly once (LDS atomics per block, one global atomic flush, tiny finalize kernel).
+#include <type_traits>
+
 #include "common.h"
 
 namespace tpq {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// compile-time loop: f(integral_constant<int, I>) for I in [I0, I1)
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I0 < I1) {
+    f(std::integral_constant<int, I0>{});
+    static_for<I0 + 1, I1>(f);
+  }
+}
+
+// (best, besti) <- (val, CL) if val > best: compare + two selects.  CL must be an inline constant
+// (0..64): a 32-bit literal next to vcc violates the one-constant-bus-operand rule of VOP2, which is
+// why the compiler spends a v_mov per candidate index; the callers therefore track the index
+// within the 32-centroid unit (0..27) here and the unit number once per unit.
+// volatile: pins the selects next to the compare (left alone, the optimiser sinks the besti chain
+// to its use at the end of the tile and parks 128 compare masks in spilled SGPRs)
+template <int CL>
+__device__ __forceinline__ void ms_take(float& best, int& besti, float val) {
+  static_assert(CL >= 0 && CL <= 64, "inline constant");
+  asm volatile(
+      "v_cmp_ngt_f32 vcc, %2, %0\n\ts_nop 1\n\tv_cndmask_b32 %0, %2, %0, vcc\n\tv_cndmask_b32 %1, %3, %1, vcc"
+      : "+v"(best), "+v"(besti)
+      : "v"(val), "n"(CL)
+      : "vcc");
+}
 
 constexpr int kMsCent = 256;  // centroids per pass (8 MFMA row tiles)
 constexpr int kMsKC = 16;     // k rows staged in LDS per step (per buffer)
@@ -182,7 +211,10 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
 // the block then walks kMsTiles point tiles.  Per tile a wave pre-loads its whole data fragment
 // (DH = d/2 registers, loads issued back to back) before the MFMA loop, so the matrix pipe is fed
 // from registers + LDS only: 8 independent 32x32 accumulators, 8 ds_read_b32 per 8 MFMAs.
-constexpr int kMsTiles = 8;  // 128-point tiles per block
+#ifndef TPQ_MS_TILES
+#define TPQ_MS_TILES 32
+#endif
+constexpr int kMsTiles = TPQ_MS_TILES;  // 128-point tiles per block
 
 template <int DH, bool euclidean>
 __global__ __launch_bounds__(256, (DH <= 32 ? 2 : 1)) void max_sim_codebook_kernel(
@@ -226,106 +258,185 @@ __global__ __launch_bounds__(256, (DH <= 32 ? 2 : 1)) void max_sim_codebook_kern
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(Ab), 0, (int)(((int64_t)d * m * 4 > 0x7fffffffLL) ? 0x7fffffff : (int64_t)d * m * 4),
       0x00020000);
-  auto load_frag = [&](int t, float (&xf)[DH], bool& iv, int& i) {
+  auto frag_offset = [&](int t, bool& iv, int& i) -> int {
     const int tile = blockIdx.x * kMsTiles + t;
     i = tile * 128 + wave * 32 + l31;
     iv = (t < kMsTiles) && (i < m);
-    const int voff = iv ? (half * m + i) * 4 : 0x7ffffff0;  // out of range -> the load returns 0
-#pragma unroll
-    for (int kk = 0; kk < DH; ++kk)
-      xf[kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, kk * 2 * m * 4, 0));
+    return iv ? (half * m + i) * 4 : 0x7ffffff0;  // out of range -> the loads return 0
   };
-  constexpr bool kPrefetch = DH <= 32;  // DH = 64 runs one wave per SIMD already
-  float xn[kPrefetch ? DH : 1];
-  bool ivn = false;
-  int in_ = 0;
-  if constexpr (kPrefetch) load_frag(0, xn, ivn, in_);
-#pragma unroll 1
-  for (int t = 0; t < kMsTiles; ++t) {
-    if ((blockIdx.x * kMsTiles + t) * 128 >= m) break;
-    float xf[DH];
-    bool iv;
-    int i;
-    if constexpr (kPrefetch) {
+  auto load_k = [&](int voff, int kk) -> float {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, kk * 2 * m * 4, 0));
+  };
+  float xf[DH], xn[DH];  // this tile's data fragment (B operand), and the next tile's in flight
+  bool iv, ivn = false;
+  int i, in_ = 0;
+  {
+    const int voff = frag_offset(0, iv, i);
 #pragma unroll
-      for (int kk = 0; kk < DH; ++kk) xf[kk] = xn[kk];
-      iv = ivn;
-      i = in_;
-      load_frag(t + 1, xn, ivn, in_);
-    } else {
-      load_frag(t, xf, iv, i);
-    }
-    // |a|^2 as the ascending-k fma chain: this lane holds k = 2kk+half, its partner (lane ^ 32)
-    // the other parity
-    float a2 = 0.f;
+    for (int kk = 0; kk < DH; ++kk) xf[kk] = load_k(voff, kk);
+  }
+
+  // A tile = 8 UNITS of 32 centroids; a unit is one chain of DH MFMAs into a single 32x32
+  // accumulator (back-to-back accumulation into the same registers is forwarded by the matrix
+  // pipe).  Units alternate between two accumulators: while unit u runs, the 16 values per lane
+  // of unit u-1 go through the arg-max epilogue (2 acc - |a|^2 - |b|^2, compare, select) in
+  // slices BETWEEN the MFMAs, as do the |a|^2 chain of the tile (under unit 0) and the loads of
+  // the next tile's fragment (spread over all 8 units), so the matrix pipe never waits for them.
+  // (The previous form -- 4 independent accumulators per pass, epilogue on its own after each
+  // pass -- spent 3.5 of 19.9 ms at C5 in the epilogue and 1.3 in |a|^2, measured by knocking
+  // them out; a phase-pipelined version of THAT form needed two 64-register accumulator sets and
+  // spilled.)  The A operands (centroid rows from LDS) are fetched two k-steps ahead.
+  // Within a lane the centroid index grows with (unit, r), so "first maximum" == smallest index.
+  f32x16 accA, accB;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accB[r] = 0.f;
+  float best = -INFINITY;
+  int besti = 0, bestu = 0;  // index within the unit (0..27, without the lane's 4*half), unit
+  float a2_prev = 0.f;
+  bool iv_prev = false;
+  int i_prev = 0;
+
+  // value r (0..15) of finished unit fu -> running (best, besti).  besti is tracked WITHOUT the
+  // lane's 4*half offset: the candidate index is then an instruction literal (with the offset in
+  // it the compiler hoists loop-invariant index registers out of the tile loop and spills)
+  const float* b2h = b2s + 4 * half;
+  // The fp32 MFMA shares the SIMD's fp32 ALUs with the VALU (knock-out measurements: VALU work
+  // placed between the MFMAs is NOT hidden, it adds), so the epilogue is counted in instructions:
+  // values go in PAIRS (r, r+1: consecutive centroids) through v_pk_fma_f32 (2 acc - |a|^2: the
+  // doubling is exact, so this is the two-step 2*acc, then -|a|^2) and v_pk_add_f32 (-|b|^2 pair,
+  // one ds_read_b64), then compare + two selects each with the centroid index as an instruction
+  // literal: 4 VALU instructions per value instead of 7.
+  auto cl_of = [](int fu, int r) { return fu * 32 + (r & 3) + 8 * (r >> 2); };
+  auto epi_pair = [&](const f32x16& fin, auto fu_c, auto r_c, float a2, f32x2 b2) {
+    constexpr int r = decltype(r_c)::value;
+    f32x2 v = {fin[r], fin[r + 1]};
     if (euclidean) {
-#pragma unroll
-      for (int kk = 0; kk < DH; ++kk) {
-        const float xo = __shfl_xor(xf[kk], 32, 64);
-        const float x0 = half ? xo : xf[kk], x1 = half ? xf[kk] : xo;
-        a2 = fmaf(x0, x0, a2);
-        if (2 * kk + 1 < d) a2 = fmaf(x1, x1, a2);
-      }
+      const f32x2 two = {2.f, 2.f}, na2 = {-a2, -a2};
+      v = __builtin_elementwise_fma(v, two, na2);
+      v = v - b2;
+    } else {
+      v = v + b2;
     }
-    // two passes of 4 centroid tiles: 64 accumulator registers instead of 128; the data fragment
-    // is re-used from registers, the LDS traffic is unchanged.  Within a lane the centroid index
-    // grows with (pass, tt, r), so "first maximum" == smallest index.
-    float best = -INFINITY;
-    int besti = 0;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      f32x16 acc[4];
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < DH; ++kk) {
-        const float* crow = cs + (2 * kk + half) * 256 + pass * 128 + l31;
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-          acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(crow[tt * 32], xf[kk], acc[tt], 0, 0, 0);
-        // keep the scheduler from hoisting every k-step's LDS reads to the top (register blow-up)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int c = pass * 128 + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          float v;
-          if (euclidean) {
-            v = 2.f * acc[tt][r];
-            v = v - a2;
-            v = v - b2s[c];
-          } else {
-            v = acc[tt][r] + b2s[c];
-          }
-          const bool w = v > best;
-          best = w ? v : best;
-          besti = w ? c : besti;
-        }
-        __builtin_amdgcn_sched_barrier(0);  // do not hoist all b2s reads above the compares
-      }
-    }
+    ms_take<(r & 3) + 8 * (r >> 2)>(best, besti, v[0]);
+    ms_take<((r + 1) & 3) + 8 * ((r + 1) >> 2)>(best, besti, v[1]);
+  };
+  auto finish_tile = [&](bool fiv, int fi) {
+    besti += 32 * bestu + 4 * half;
     const float ov = __shfl_xor(best, 32, 64);
     const int oi = __shfl_xor(besti, 32, 64);
     if (ov > best || (ov == best && oi < besti)) {
       best = ov;
       besti = oi;
     }
-    if (half == 0 && iv) {
+    if (half == 0 && fiv) {
       besti += c0;
       if (!first) {
-        const float pv = vals[(int64_t)b * m + i];
+        const float pv = vals[(int64_t)b * m + fi];
         if (!(best > pv)) {
           best = pv;
-          besti = (int)inds[(int64_t)b * m + i];
+          besti = (int)inds[(int64_t)b * m + fi];
         }
       }
-      vals[(int64_t)b * m + i] = best;
-      inds[(int64_t)b * m + i] = besti;
+      vals[(int64_t)b * m + fi] = best;
+      inds[(int64_t)b * m + fi] = besti;
     }
+  };
+  constexpr int PF = DH >= 2 ? 2 : 1;  // A-operand prefetch distance (k-steps)
+  const int row2 = 2 * m * 4;  // bytes between the k-rows a lane owns
+  // unit U of the current tile into `acc`; `fin` = the accumulator of the unit before it
+  auto unit = [&](auto u_c, f32x16& acc, const f32x16& fin, float a2_fin, float& a2_out, int& voff_next) {
+    constexpr int U = decltype(u_c)::value, FU = (U + 7) & 7;
+    const float* crow = cs + half * 256 + U * 32 + l31;
+    float ring[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) ring[p] = crow[p * 512];
+    float a2 = 0.f;
+    // |b|^2 pairs are read one slice ahead: no LDS latency inside a slice
+    f32x2 b2n = *reinterpret_cast<const f32x2*>(b2h + cl_of(FU, 0));
+    const float best_before = best;  // the epilogue of unit FU starts here
+    static_for<0, DH>([&](auto kk_c) {
+      constexpr int kk = decltype(kk_c)::value;
+      const float a_cur = ring[kk % PF];
+      if (kk + PF < DH) ring[kk % PF] = crow[(kk + PF) * 512];
+      if (kk == 0) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, xf[kk], zero, 0, 0, 0);
+      } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, xf[kk], acc, 0, 0, 0);
+      }
+      if constexpr (U == 0 && euclidean) {
+        // |a|^2 as the ascending-k fma chain: this lane holds k = 2kk+half, its partner
+        // (lane ^ 32) the other parity; one half-swap hands every lane both (a k beyond d reads 0).
+        // (inline asm, hazard wait states inside the string: with the builtin hipcc 7.2 used
+        // result[0] for both results once float math followed -- tools/ubench/permlane_swap.hip)
+        float x0 = xf[kk], x1 = xf[kk];
+        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x0), "+v"(x1));
+        a2 = fmaf(x0, x0, a2);
+        a2 = fmaf(x1, x1, a2);
+      }
+      // next tile's fragment: DH loads spread evenly over the 8 DH k-steps of the tile
+      // (running per-lane offset, no soffset: DH distinct row offsets would be hoisted out of
+      // the tile loop as DH SGPRs and spilled to VGPR lanes)
+      if constexpr ((U * DH + kk) % 8 == 0) {
+        xn[(U * DH + kk) / 8] =
+            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_next, 0, 0));
+        voff_next += row2;
+      }
+      // epilogue slice of the previous unit: its 8 value pairs spread over the DH k-steps
+      static_for<(kk * 8) / DH, ((kk + 1) * 8) / DH>([&](auto pr_c) {
+        constexpr int r = 2 * decltype(pr_c)::value;
+        const f32x2 b2c = b2n;
+        if constexpr (r + 2 < 16) b2n = *reinterpret_cast<const f32x2*>(b2h + cl_of(FU, r + 2));
+        epi_pair(fin, std::integral_constant<int, FU>{}, std::integral_constant<int, r>{}, a2_fin, b2c);
+      });
+      // keep the scheduler from hoisting every k-step's LDS reads to the top
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    bestu = best > best_before ? FU : bestu;  // unit FU's epilogue is complete
+    a2_out = a2;
+  };
+  using std::integral_constant;
+
+  bool have_prev = false;
+#pragma unroll 1
+  for (int t = 0; t < kMsTiles; ++t) {
+    if ((blockIdx.x * kMsTiles + t) * 128 >= m) break;
+    int voff_next = frag_offset(t + 1, ivn, in_);
+    // (lanes without a point start at 0x7ffffff0; wherever their DH steps of row2 land, buffer
+    // loads are range-checked and the lane's result is never written)
+    // unit 0: under it, the epilogue of the LAST unit of tile t-1 (a zero accumulator and a
+    // discarded result for the first tile) and |a|^2 of tile t
+    float a2_t = 0.f, dummy = 0.f;
+    unit(integral_constant<int, 0>{}, accA, accB, a2_prev, a2_t, voff_next);
+    if (have_prev) finish_tile(iv_prev, i_prev);
+    best = -INFINITY;
+    besti = 0;
+    bestu = 0;
+    unit(integral_constant<int, 1>{}, accB, accA, a2_t, dummy, voff_next);
+    unit(integral_constant<int, 2>{}, accA, accB, a2_t, dummy, voff_next);
+    unit(integral_constant<int, 3>{}, accB, accA, a2_t, dummy, voff_next);
+    unit(integral_constant<int, 4>{}, accA, accB, a2_t, dummy, voff_next);
+    unit(integral_constant<int, 5>{}, accB, accA, a2_t, dummy, voff_next);
+    unit(integral_constant<int, 6>{}, accA, accB, a2_t, dummy, voff_next);
+    unit(integral_constant<int, 7>{}, accB, accA, a2_t, dummy, voff_next);
+    a2_prev = a2_t;
+    iv_prev = iv;
+    i_prev = i;
+    have_prev = true;
+#pragma unroll
+    for (int kk = 0; kk < DH; ++kk) xf[kk] = xn[kk];
+    iv = ivn;
+    i = in_;
+  }
+  if (have_prev) {  // epilogue of the last unit of the last tile: nothing left to hide it under
+    const float best_before = best;
+    static_for<0, 8>([&](auto pr_c) {
+      constexpr int r = 2 * decltype(pr_c)::value;
+      epi_pair(accB, std::integral_constant<int, 7>{}, std::integral_constant<int, r>{}, a2_prev,
+               *reinterpret_cast<const f32x2*>(b2h + cl_of(7, r)));
+    });
+    bestu = best > best_before ? 7 : bestu;
+    finish_tile(iv_prev, i_prev);
   }
 }
 
@@ -448,90 +559,138 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kUmP = 64;              // points per staged tile (4 MFMA k-steps of 16)
 constexpr int kUmStride = kUmP + 4;   // floats per dimension row in LDS (b128 reads stay conflict-free)
 
-// One WAVE per block owns all 256 clusters x 64 dimensions of its point range: 8 x 2 accumulator
-// tiles = 256 AGPRs, one wave per SIMD.  (A first version spread the clusters over the 4 waves of
-// a block: every wave then split the same tile into bf16 pieces again and the block met at a
-// barrier per 64 points -- 7.4 ms at C5; the LDS read-add-write kernel above: 9.2 ms.)
+// One WAVE per block owns all 256 clusters x 32*CT dimensions of its point range: 8 x CT
+// accumulator tiles.  CT = 2 (64 dimensions, 256 AGPRs) leaves one wave per SIMD: its one-hot /
+// bf16-splitting VALU work and its tile staging run in series with its own MFMAs (5.9 ms at C5
+// against 2.5 ms of matrix-pipe time).  CT = 1 (32 dimensions, 128 AGPRs) puts two independent
+// waves on every SIMD -- no barrier between them, each splits only its own dimensions -- so one
+// wave's VALU / LDS / load phases sit under the other's MFMAs; the price is that the one-hot
+// operand is built twice.  (A first version spread the CLUSTERS over the 4 waves of a block:
+// every wave then split the same tile into bf16 pieces again and the block met at a barrier per
+// 64 points -- 7.4 ms at C5; the LDS read-add-write kernel above: 9.2 ms.)
 // The B fragment wants 8 consecutive points of ONE dimension per lane; straight from global memory
-// that is one 32-byte request per lane (address-unit bound, 32 ms), so [64 dims][64 points] tiles
+// that is one 32-byte request per lane (address-unit bound, 32 ms), so [dims][64 points] tiles
 // go through LDS with coalesced row loads (lane = point), the next tile in flight in registers
 // while the MFMAs of the current one run.
-__global__ __launch_bounds__(64) void centroid_accum_mfma_kernel(
+//
+// One-hot operand: the labels of a tile sit in LDS as u16 (0xFFFF = none), so a lane's 8 points
+// arrive as four packed pairs with one ds_read_b128; per pair D = pair - (l31, l31) once per
+// k-step, and for every 32-cluster row tile rt three packed-u16 instructions make the two bf16
+// entries: t = D ^ (32 rt, 32 rt); u = sat(1 - t) [v_pk_sub_u16 clamp: 1 where t == 0];
+// w = u * 0x3F80 [bf16 1.0] -- 1.5 VALU instructions per entry instead of compare + select + pack.
+#ifndef TPQ_UM_CT
+#define TPQ_UM_CT 1
+#endif
+#ifndef TPQ_UM_EXP
+#define TPQ_UM_EXP 0  // experiments (tools/build_variant.sh): 1 = no MFMAs, 2 = no tile reloads, 4 = no one-hot
+#endif
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+
+// (plain vector code, no inline asm: the compiler selects v_pk_sub_i16 / v_pk_sub_u16 clamp /
+// v_pk_mul_lo_u16 from it AND knows the instructions -- an asm version of the same three
+// instructions produced scheduling-dependent wrong sums: the hazard recogniser cannot see a VALU
+// write inside an asm block that an MFMA reads as its A operand a few cycles later)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b));
+}
+__device__ __forceinline__ uint32_t onehot_pair_bf16(uint32_t t) {
+  const u16x2 one = {1, 1}, bf16_one = {0x3F80, 0x3F80};
+  const u16x2 u = __builtin_elementwise_sub_sat(one, __builtin_bit_cast(u16x2, t));  // 1 where t == 0
+  return __builtin_bit_cast(uint32_t, u * bf16_one);
+}
+
+template <int CT, bool VEC>
+__global__ __launch_bounds__(64, (CT == 1 ? 2 : 1)) void centroid_accum_mfma_kernel(
     const float* __restrict__ data, const int64_t* __restrict__ labels, float* __restrict__ sums,
     float* __restrict__ counts, int d, int64_t n, int k, int64_t points) {
-  __shared__ __attribute__((aligned(16))) float xt[2][64 * kUmStride];
-  __shared__ __attribute__((aligned(16))) int lt[2][kUmP];
+  constexpr int ND = 32 * CT;  // dimensions per wave
+  __shared__ __attribute__((aligned(16))) float xt[2][ND * kUmStride];
+  __shared__ __attribute__((aligned(16))) uint16_t lt[2][kUmP];
   __shared__ int cnt[256];
   const int b = blockIdx.z;
   const int lane = threadIdx.x;
   const int l31 = lane & 31, half = lane >> 5;
-  const int e0 = blockIdx.y * 64;
-  const int nd = (d - e0) < 64 ? (d - e0) : 64;  // dimensions of this block that exist
+  const int e0 = blockIdx.y * ND;
+  const int nd = (d - e0) < ND ? (d - e0) : ND;  // dimensions of this block that exist
   const int64_t i0 = (int64_t)blockIdx.x * points;
   const int64_t i1 = (i0 + points) < n ? (i0 + points) : n;
   const int64_t* __restrict__ lrow = labels + (int64_t)b * n;
   const float* __restrict__ dbase = data + ((int64_t)b * d + e0) * n;
-  f32x16 acc[8][2];  // [cluster row tile][dimension column tile]
+  f32x16 acc[8][CT];  // [cluster row tile][dimension column tile]
 #pragma unroll
   for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
 #pragma unroll
   for (int u = 0; u < 4; ++u) cnt[lane + 64 * u] = 0;
   const bool count_here = blockIdx.y == 0;
+  const uint32_t l31_pk = (uint32_t)l31 * 0x00010001u;
 
-  // The next tile is fetched in four quarters (16 dimension rows each), one per MFMA k-step, so
-  // that the address arithmetic and load issue of the single wave hide behind its own MFMAs.
-  // Loads are unconditional on clamped addresses and masked afterwards: no exec-mask branches.
-  float rx[64];
-  int rl = -1;
-  auto load_quarter = [&](int64_t p0, int qt) {
-    const int64_t pt = p0 + lane;
+  // Tiles travel global -> registers -> LDS, TWO tiles ahead of the MFMAs: the loads of tile t+2
+  // are issued in four quarters, one per MFMA k-step of tile t (so the wave's load issue hides
+  // behind its MFMAs), and reach LDS at the end of tile t+1 -- more than two tile times in flight
+  // (with one tile ahead the wave waited out part of every memory latency: 5.65 ms at C5 against
+  // 3.7 ms with the reloads knocked out).  VEC (n % 4 == 0): a lane loads 4 consecutive points of
+  // one dimension row (16 B), a wave-instruction 4 rows x 256 B; otherwise one point per lane.
+  // Loads are unconditional on clamped addresses: out-of-range points carry label 0xFFFF (their
+  // one-hot column is zero) and out-of-range dimension rows land in accumulator columns that are
+  // never written out; no exec-mask branches, no selects behind the loads.
+  constexpr int NV = VEC ? ND / 4 : ND;  // load instructions (registers: NV float4 / NV floats)
+  typedef typename std::conditional<VEC, f32x4, float>::type xreg_t;
+  struct Staged {
+    xreg_t x[NV];
+    int64_t label;
+    bool label_valid;
+  };
+  const int vrow = VEC ? (lane >> 4) : 0, vpt = VEC ? (lane & 15) * 4 : lane;
+  auto load_quarter = [&](Staged& st, int64_t p0, int qt) {
+    const int64_t pt = p0 + vpt;
     const bool pv = pt < i1;
     const float* __restrict__ p = dbase + (pv ? pt : i0);
 #pragma unroll
-    // (no masking of the values: a select right behind each load makes the compiler wait for
-    // every load on the spot.  Out-of-range points carry label -1 -- their one-hot column is zero
-    // -- and out-of-range dimension rows land in accumulator columns that are never written
-    // out; both read clamped, finite, addresses)
-    for (int u = 16 * qt; u < 16 * qt + 16; ++u) rx[u] = p[(int64_t)(u < nd ? u : 0) * n];
-    if (qt == 0) {
-      const int64_t l64 = lrow[pv ? pt : i0];
-      rl = (pv && l64 >= 0 && l64 < k) ? (int)l64 : -1;
+    for (int j = (NV / 4) * qt; j < (NV / 4) * (qt + 1); ++j) {
+      const int row = VEC ? 4 * j + vrow : j;
+      st.x[j] = *reinterpret_cast<const xreg_t*>(p + (int64_t)(row < nd ? row : 0) * n);
+    }
+    if (qt == 0) {  // the raw label: any arithmetic on it here would wait for the load on the spot
+      const int64_t lp = p0 + lane;
+      st.label_valid = lp < i1;
+      st.label = lrow[st.label_valid ? lp : i0];
     }
   };
-  auto load_tile = [&](int64_t p0) {
+  auto store_tile = [&](const Staged& st, int buf) {
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) load_quarter(p0, qt);
+    for (int j = 0; j < NV; ++j) {
+      const int row = VEC ? 4 * j + vrow : j;
+      *reinterpret_cast<xreg_t*>(&xt[buf][row * kUmStride + vpt]) = st.x[j];
+    }
+    lt[buf][lane] = (st.label_valid && st.label >= 0 && st.label < k) ? (uint16_t)st.label : (uint16_t)0xFFFF;
   };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int u = 0; u < 64; ++u) xt[buf][u * kUmStride + lane] = rx[u];
-    lt[buf][lane] = rl;
-  };
-  load_tile(i0);
-  store_tile(0);
-  __syncthreads();
-  int it = 0;
-  for (int64_t p0 = i0; p0 < i1; p0 += kUmP, ++it) {
-    const int buf = it & 1;
-    const bool more = p0 + kUmP < i1;
+  // one tile: MFMAs from LDS buffer `buf`; `fill` receives tile it+2; `drain` (tile it+1) goes to
+  // the other LDS buffer afterwards
+  auto run_tile = [&](int64_t p0, int buf, Staged& fill, const Staged& drain) {
+    // (no "is there a tile t+1 / t+2" branches: beyond the range the loads read clamped addresses
+    // and the stores fill a buffer nobody reads.  With conditional loads the compiler's waitcnt
+    // bookkeeping merges the two paths and falls back to vmcnt(0) before the LDS stores, i.e. it
+    // waits for the loads of tile t+2 that were only just issued)
     if (count_here) {
       const int l = lt[buf][lane];
-      if (l >= 0) atomicAdd(&cnt[l], 1);  // integer LDS atomic: fast
+      if (l != 0xFFFF) atomicAdd(&cnt[l], 1);  // integer LDS atomic: fast
     }
 #pragma unroll
     for (int ks = 0; ks < kUmP / 16; ++ks) {
-      if (more) load_quarter(p0 + kUmP, ks);
+      if (!(TPQ_UM_EXP & 2)) load_quarter(fill, p0 + 2 * kUmP, ks);
       const int pts = 16 * ks + 8 * half;  // this lane's 8 points (its k-group)
-      const int4 la = *reinterpret_cast<const int4*>(&lt[buf][pts]);
-      const int4 lb = *reinterpret_cast<const int4*>(&lt[buf][pts + 4]);
-      const int lab[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
-      bf16x8 piece[3][2];  // [hi, mid, lo][column tile]
+      const u32x4v lp = *reinterpret_cast<const u32x4v*>(&lt[buf][pts]);  // 4 packed label pairs
+      uint32_t dl[4];
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
+      for (int pr = 0; pr < 4; ++pr) dl[pr] = pk_sub_u16(lp[pr], l31_pk);
+      bf16x8 piece[3][CT];  // [hi, mid, lo][column tile]
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
         const float* xrow = &xt[buf][(32 * ct + l31) * kUmStride + pts];
         const float4 xa = *reinterpret_cast<const float4*>(xrow);
         const float4 xb = *reinterpret_cast<const float4*>(xrow + 4);
@@ -547,28 +706,55 @@ __global__ __launch_bounds__(64) void centroid_accum_mfma_kernel(
           piece[2][ct][i] = (__bf16)r2;
         }
       }
-      // the 16 accumulator tiles take turns: an MFMA never waits for the one issued before it
+      // the accumulator tiles take turns: an MFMA never waits for the one issued before it
 #pragma unroll
       for (int rt = 0; rt < 8; ++rt) {
-        bf16x8 a;
+        u32x4v aw;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = (__bf16)((lab[i] == 32 * rt + l31) ? 1.0f : 0.0f);
-        // (both column tiles always: a wave-uniform branch around the second one when d <= 32
+        for (int pr = 0; pr < 4; ++pr)
+          aw[pr] = (TPQ_UM_EXP & 4) ? (dl[pr] + rt)
+                                    : onehot_pair_bf16(rt == 0 ? dl[pr] : (dl[pr] ^ (uint32_t)(32 * rt * 0x00010001)));
+        const bf16x8 a = __builtin_bit_cast(bf16x8, aw);
+        // (all column tiles always: a wave-uniform branch around the second one when d <= 32
         // broke the MFMA interleaving and cost more than the multiplies it saved)
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct)
+          for (int ct = 0; ct < CT; ++ct) {
+            if (TPQ_UM_EXP & 1) {
+              acc[rt][ct][pc] += (float)a[pc] + (float)piece[pc][ct][rt];
+              continue;
+            }
             acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, piece[pc][ct], acc[rt][ct], 0, 0, 0);
+          }
       }
     }
-    if (more) store_tile(buf ^ 1);
-    __syncthreads();
+    store_tile(drain, buf ^ 1);
+    // one wave per block: its DS operations execute in order, so the next tile's reads see these
+    // stores without a barrier -- and a __syncthreads() would bring an s_waitcnt vmcnt(0) with it,
+    // i.e. wait for the loads of tile t+2 that were only just issued
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  Staged sa, sb;
+  sa.label = sb.label = -1;
+  sa.label_valid = sb.label_valid = false;
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) load_quarter(sa, i0, qt);
+  store_tile(sa, 0);
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) load_quarter(sa, i0 + kUmP, qt);  // clamped when out of range
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+  for (int64_t p0 = i0; p0 < i1; p0 += 2 * kUmP) {
+    run_tile(p0, 0, sb, sa);                             // tile 2j: fill sb (2j+2), drain sa (2j+1)
+    if (p0 + kUmP < i1) run_tile(p0 + kUmP, 1, sa, sb);  // tile 2j+1: fill sa (2j+3), drain sb (2j+2)
   }
 #pragma unroll
   for (int rt = 0; rt < 8; ++rt)
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < CT; ++ct) {
       const int dim = e0 + 32 * ct + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -665,15 +851,24 @@ extern "C" int tpq_compute_centroids(const float* data, const int64_t* labels, f
                    "centroid_accum_kernel attr");
     if (rc) return rc;
     if (k <= 256 && d >= 32) {  // wide PQ-codebook shape: bf16 matrix cores
-      const int dt64 = (d + 63) / 64;
-      int64_t chunks = 1024 / ((int64_t)l * dt64);
+      constexpr int CT = TPQ_UM_CT;
+      const int dtiles = (d + 32 * CT - 1) / (32 * CT);
+      // one wave per block; 2 / CT waves per SIMD resident -> aim for a few rounds of 2048 / CT blocks
+      int64_t chunks = (4096 / CT) / ((int64_t)l * dtiles);
       if (chunks < 1) chunks = 1;
       int64_t points = (n + chunks - 1) / chunks;
       if (points < 4096) points = 4096;
+#ifdef TPQ_UM_POINTS
+      points = TPQ_UM_POINTS;
+#endif
       points = (points + kUmP - 1) / kUmP * kUmP;
-      hipLaunchKernelGGL(centroid_accum_mfma_kernel,
-                         dim3((unsigned)((n + points - 1) / points), dt64, l), dim3(64), 0, st, data,
-                         labels, sums, counts, d, n, k, points);
+      const dim3 grid((unsigned)((n + points - 1) / points), dtiles, l);
+      if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(data) & 15) == 0)
+        hipLaunchKernelGGL((centroid_accum_mfma_kernel<CT, true>), grid, dim3(64), 0, st, data, labels,
+                           sums, counts, d, n, k, points);
+      else
+        hipLaunchKernelGGL((centroid_accum_mfma_kernel<CT, false>), grid, dim3(64), 0, st, data, labels,
+                           sums, counts, d, n, k, points);
       TPQ_LAUNCH_CHECK("centroid_accum_mfma_kernel");
       const int64_t total = (int64_t)l * d * k;
       hipLaunchKernelGGL(centroid_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
