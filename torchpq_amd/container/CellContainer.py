@@ -211,7 +211,14 @@ class CellContainer(BaseContainer):
         if added:
             self.print_message(f"Total storage capacity is expanded by {added}", 2)
 
-        write_address = self.get_write_address(cells=cells, ioa=ioa)
+        if self._has_holes:
+            write_address = self.get_write_address(cells=cells, ioa=ioa)
+        else:
+            # every cell is dense in [start, start+size) (add / remove / _grow keep it so; only a
+            # foreign state_dict can carry holes): the ioa-th free slot of a cell is simply
+            # start + size + ioa -- O(n) instead of a walk over the cell per vector
+            # (get_write_address_v2.cu:9-41 scans from the cell start), same addresses
+            write_address = self._cell_start[cells] + self._cell_size[cells] + ioa
         self.set_data_by_address(data, write_address)
         self._address2id[write_address] = ids
         self._max_id = max(self._max_id, ids.max().item())
