@@ -516,8 +516,19 @@ constexpr int packed_waves(int M) { return M <= 64 ? 8 : 16; }
 // ballot): a lane therefore takes S slots (64 apart) per iteration and pays that part once.
 // (measured, 10 000 queries x 32 probes: m=4 +18 %, 8 +16 %, 12 +12 %, 16 +9 %, 20 +10 %, 24 +10 %;
 // neutral from m=28 on, where one slot per lane is kept)
-constexpr int packed_slots(int M) { return M <= 8 ? 4 : (M <= 24 ? 2 : 1); }
-constexpr int packed_tile_shift(int M) { return M <= 8 ? 8 : (M <= 24 ? 7 : 6); }
+#ifdef TPQ_SLOTS_LOG2  // experiments (tools/build_variant.sh): slots per lane = 1 << TPQ_SLOTS_LOG2
+constexpr int packed_slots(int M) { return 1 << TPQ_SLOTS_LOG2; }
+constexpr int packed_tile_shift(int M) { return 6 + TPQ_SLOTS_LOG2; }
+#else
+// (r02 sweep, 10 000 queries x 32 probes, ms for S = 1 / 2 / 4: m=28 1.97 / 2.06 / 2.04,
+// m=32 2.25 / 2.05 / 1.98, m=40 2.37 / 2.44 / 2.47, m=48 2.84 / 2.65 / 4.82, m=56 3.35 / 3.21 / -,
+// m=64 3.09 / 5.84 / -: the 16-byte-chunk layouts (m % 16 == 0) gain until the second tile's
+// registers spill)
+constexpr int packed_slots(int M) {
+  return M <= 8 ? 4 : (M <= 24 ? 2 : (M == 32 ? 4 : ((M == 48 || M == 56) ? 2 : 1)));
+}
+constexpr int packed_tile_shift(int M) { return packed_slots(M) == 4 ? 8 : (packed_slots(M) == 2 ? 7 : 6); }
+#endif
 
 // per-wave scratch of the end-of-query exact re-evaluation: un-permute rows of M/4+1 dwords,
 // 16 per pass (8 when the LUT leaves little LDS: m > 64)

@@ -11,7 +11,10 @@ namespace tpq {
 
 template <int R, int M, bool RES>
 static int launch_packed(ScanArgs a, ResidualArgs ra, hipStream_t st) {
-  const size_t lds = scan_lds_bytes_packed(M, R, a.max_nprobe, fused_floats_of(a), RES);
+  size_t lds = scan_lds_bytes_packed(M, R, a.max_nprobe, fused_floats_of(a), RES);
+#ifdef TPQ_EXTRA_LDS  // experiment: force fewer workgroups per CU
+  lds += TPQ_EXTRA_LDS;
+#endif
   int rc = set_lds(scan_packed_kernel<R, M, RES>, lds, "scan_packed_kernel");
   if (rc) return rc;
   // delta = 1.05 * 2 (M-1) u * sum_j max|LUT_j|,  u = 2^-24   (residual: M+1 roundings, see kernel)

@@ -16,12 +16,16 @@ from ..kernels import CoarseProbeHip, CoarseSelectHip, SmartProbingHip
 
 
 class IVFPQIndex(CellContainer):
-    # plain (non-residual) search keeps the scan-layout copy of the codes where it pays: long codes
-    # (m >= 56: bank-conflict-free look-ups, 1.2-1.7x) and short ones (m <= 24: several slots per
-    # lane per iteration, 1.1-1.25x); in between the two layouts scan within +-2 % of each other and
-    # the copy is not kept.  The residual scan uses the scan layout at every m.
-    packed_min_subvectors = 56
+    # search keeps the scan-layout copy of the codes at every m that has a kernel instantiation:
+    # long codes gain from bank-conflict-free look-ups (m >= 56: 1.2-1.7x), short and medium ones
+    # from several slots per lane per iteration (r02 sweep, scan layout vs reference layout:
+    # m=28 1.97 vs 2.25 ms, 32 1.98 vs 2.19, 40 2.37 vs 2.67, 48 2.65 vs 2.94 per 10 000 queries).
+    # (m with packed_max_short_subvectors < m < packed_min_subvectors would use the reference layout)
+    packed_min_subvectors = 0
     packed_max_short_subvectors = 24
+    # the LUT is built inside the scan workgroups (no [m, nq, 256] table in HBM) up to this
+    # sub-vector length; the workgroup then reads m * ds KiB of L2-resident codebook per query
+    fused_lut_max_subvector = 4
 
     def __init__(self, d_vector, n_subvectors=8, n_cells=128, initial_size=None,
                  expand_step_size=128, expand_mode="double", distance="euclidean",
@@ -305,7 +309,7 @@ class IVFPQIndex(CellContainer):
                 if self._precomputed_part2 is None:
                     self.precompute_part2()
                 slot_term, cell_bound = self._residual_slot_terms()
-                fused = self.use_fused_lut and self.d_subvector <= 4
+                fused = self.use_fused_lut and self.d_subvector <= self.fused_lut_max_subvector
                 part1 = None if fused else self.precomputed_adc_residual_precomputed(x)[0]
                 topk_val, topk_address, topk_ids = self._ivfpq_topk._scan.topk_residual_packed(
                     data=self._storage, packed=self.packed_storage(), part2=self._part2_by_cell,
@@ -339,7 +343,7 @@ class IVFPQIndex(CellContainer):
                 packed = self.packed_storage()
         # the fused path re-reads the codebook (m*ds KiB, L2-resident) per workgroup instead of a
         # 1-KiB-per-sub-quantizer LUT row from HBM: a win while the sub-vectors are short
-        if self.use_fused_lut and self.d_subvector <= 4:
+        if self.use_fused_lut and self.d_subvector <= self.fused_lut_max_subvector:
             topk_val, topk_address, topk_ids = self._ivfpq_topk.topk_fused(
                 data=self._storage, query=x, codebook=self.pq_codec.codebook, cell_start=cell_start,
                 cell_size=cell_size, is_empty=self._is_empty if self._has_holes else None,
