@@ -22,7 +22,9 @@ def test_scan_split_heuristic():
 def test_scan_layout_policy_and_instantiated_m():
     from torchpq_amd.index import IVFPQIndex
     from torchpq_amd.kernels import PACKED_M, packed_chunk_width
-    assert IVFPQIndex.packed_min_subvectors == 56 and IVFPQIndex.packed_max_short_subvectors == 24
+    # r02: the scan layout is kept at every instantiated m (it wins at 28..48 too since the
+    # slots-per-lane policy was extended)
+    assert IVFPQIndex.packed_min_subvectors == 0 and IVFPQIndex.packed_max_short_subvectors == 24
     assert all(m % 4 == 0 for m in PACKED_M) and 64 in PACKED_M and 120 in PACKED_M
     assert [packed_chunk_width(m) for m in (4, 8, 12, 16, 24, 120, 128)] == [4, 8, 4, 16, 8, 8, 16]
     # the list in the Python layer is the one compiled into the library (scan_device.h)
