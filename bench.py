@@ -384,30 +384,19 @@ def secondary_c5(device, stream_peak, iters=3):
     t_assign = timeit(lambda: assign(data, cent, dim=2, mode="tn"))
     t_update = timeit(lambda: update(data, lab, k=k))
     out = {"workload": f"MultiKMeans n_kmeans={l} d={d} n={n} k={k}, one Lloyd iteration = assign + update"}
-    fused = getattr(K, "KMeansStepHip", None)
-    if fused is not None:
-        step = fused(distance="euclidean")
-        step(data, cent)
-        torch.cuda.synchronize()
-        t_fused = timeit(lambda: step(data, cent))
-        out["fused_step_ms"] = round(t_fused, 3)
     flop = 2.0 * l * n * k * d
     byt = 4.0 * l * d * n
     tf = flop / t_assign / 1e9
     out.update({
         "assign_ms": round(t_assign, 3), "update_ms": round(t_update, 3),
-        "iter_ms": round(out.get("fused_step_ms", t_assign + t_update), 3),
+        "iter_ms": round(t_assign + t_update, 3),
+        "iter_TFLOPs_end_to_end": round(flop / (t_assign + t_update) / 1e9, 1),
         "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                      "kernel": "max_sim_codebook_kernel (fp32 MFMA)", "kernel_ms": round(t_assign, 3),
                      "algorithmic_flops_per_launch": flop},
         "update_roofline": hbm_roofline(byt + 8.0 * l * n, t_update, "centroid_accum_mfma_kernel + finalize",
                                         stream_peak)})
-    if "fused_step_ms" in out:
-        tf2 = flop / out["fused_step_ms"] / 1e9
-        out["fused_roofline"] = {"bound": "mfma", "achieved": round(tf2, 1), "peak": MFMA_F32_PEAK_TFLOPS,
-                                 "unit": "TFLOP/s", "frac": round(tf2 / MFMA_F32_PEAK_TFLOPS, 4),
-                                 "kernel": "kmeans_step_kernel (assign + update, data read once)"}
     return out
 
 

@@ -274,6 +274,12 @@ int tpq_scatter_codes(const uint8_t* codes, const int64_t* address, uint8_t* sto
  * against next to the 8 TB/s spec figure.  `sink_or_null`: optional u32 the kernel may bump. */
 int tpq_ubench_stream_read(const void* src, size_t bytes, void* sink_or_null, int n_blocks,
                            tpq_stream_t stream);
+/* Measurement utility: the k-means update's read pattern without its compute -- data f32
+ * [l][d][n] read by one-wave blocks, 32 rows x 256 bytes per 64-point tile, `chunks` blocks per
+ * (sub-problem, 32-row group) taking tiles round-robin.  Tells a pattern-bound kernel from a
+ * compute-bound one (tools/kmeans_microbench.py --rows-read). */
+int tpq_ubench_rows_read(const float* src, int l, int d, int64_t n, int chunks, void* sink_or_null,
+                         tpq_stream_t stream);
 
 #ifdef __cplusplus
 }

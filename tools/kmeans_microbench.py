@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--n", type=int, default=1000000)
     ap.add_argument("--k", type=int, default=256)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--rows-read", action="store_true", help="also time the update's bare read pattern")
     args = ap.parse_args()
     from torchpq_amd import kernels as K
     dev = "cuda:0"
@@ -43,8 +44,16 @@ def main():
     t_update = timeit(lambda: cc_k(data, lab, k=args.k))
     flop = 2.0 * args.l * args.n * args.k * args.d
     byt = 4.0 * args.l * args.d * args.n
+    extra = {}
+    if args.rows_read:
+        from torchpq_amd import _lib
+        lib = _lib.load()
+        for chunks in (8, 32, 128):
+            t = timeit(lambda: _lib.check(lib.tpq_ubench_rows_read(
+                _lib.ptr(data), args.l, args.d, args.n, chunks, None, _lib.stream_ptr(dev)), "rows_read"))
+            extra[f"rows_read_chunks{chunks}_GBps"] = round(byt / t / 1e6, 1)
     print(json.dumps({
-        "config": vars(args),
+        "config": vars(args), **extra,
         "assign_ms": round(t_assign, 3), "assign_TFLOPs": round(flop / t_assign / 1e9, 2),
         "assign_GBps": round(byt / t_assign / 1e6, 1),
         "update_ms": round(t_update, 3),

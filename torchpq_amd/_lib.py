@@ -57,6 +57,7 @@ SIGNATURES = {
     "tpq_pq_decode": (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp]),
     "tpq_scatter_codes": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _vp]),
     "tpq_ubench_stream_read": (_i, [_vp, _sz, _vp, _i, _vp]),
+    "tpq_ubench_rows_read": (_i, [_vp, _i, _i, _i64, _i, _vp, _vp]),
 }
 
 _lib = None

@@ -552,69 +552,67 @@ __global__ __launch_bounds__(256) void centroid_accum_global_kernel(
 // lane row + 32 (k / 8), element k % 8; B[k][col] likewise; D as the f32 forms.
 // LDS float atomics are the trap on the scalar route: ds_add_f32 retires ~0.38 lanes per clock
 // per CU on gfx950 whatever the access pattern (tools/ubench/lds_atomic.hip; integer atomics are
-// 16x faster); an atomic-free LDS read-add-write version reached 9.2 ms at C5, this one 5.9 ms.
+// 16x faster); an atomic-free LDS read-add-write version reached 9.2 ms at C5, this one 4.8 ms.
 // (A NaN / Inf coordinate reaches every cluster of its 16-point group through 0 * x; the scalar
 // kernels confine it to its own cluster.)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kUmP = 64;              // points per staged tile (4 MFMA k-steps of 16)
 constexpr int kUmStride = kUmP + 4;   // floats per dimension row in LDS (b128 reads stay conflict-free)
 
-// One WAVE per block owns all 256 clusters x 32*CT dimensions of its point range: 8 x CT
-// accumulator tiles.  CT = 2 (64 dimensions, 256 AGPRs) leaves one wave per SIMD: its one-hot /
-// bf16-splitting VALU work and its tile staging run in series with its own MFMAs (5.9 ms at C5
-// against 2.5 ms of matrix-pipe time).  CT = 1 (32 dimensions, 128 AGPRs) puts two independent
-// waves on every SIMD -- no barrier between them, each splits only its own dimensions -- so one
-// wave's VALU / LDS / load phases sit under the other's MFMAs; the price is that the one-hot
-// operand is built twice.  (A first version spread the CLUSTERS over the 4 waves of a block:
-// every wave then split the same tile into bf16 pieces again and the block met at a barrier per
-// 64 points -- 7.4 ms at C5; the LDS read-add-write kernel above: 9.2 ms.)
+// One WAVE per block owns all 256 clusters x 32*CT dimensions of its tiles: 8 x CT accumulator
+// tiles.  CT = 2 (64 dimensions, 256 accumulator registers) leaves one wave per SIMD: its VALU
+// work and its tile staging then run in series with its own MFMAs (5.9 ms at C5 against 2.5 ms of
+// matrix-pipe time).  CT = 1 (32 dimensions, 128 registers) puts two independent waves on every
+// SIMD -- no barrier between them, each splits only its own dimensions -- so one wave's VALU / LDS
+// / load phases sit under the other's MFMAs.  (A first version spread the CLUSTERS over the 4
+// waves of a block: every wave then split the same tile into bf16 pieces again and the block met
+// at a barrier per 64 points -- 7.4 ms at C5; the LDS read-add-write kernel above: 9.2 ms.)
 // The B fragment wants 8 consecutive points of ONE dimension per lane; straight from global memory
 // that is one 32-byte request per lane (address-unit bound, 32 ms), so [dims][64 points] tiles
-// go through LDS with coalesced row loads (lane = point), the next tile in flight in registers
-// while the MFMAs of the current one run.
-//
-// One-hot operand: the labels of a tile sit in LDS as u16 (0xFFFF = none), so a lane's 8 points
-// arrive as four packed pairs with one ds_read_b128; per pair D = pair - (l31, l31) once per
-// k-step, and for every 32-cluster row tile rt three packed-u16 instructions make the two bf16
-// entries: t = D ^ (32 rt, 32 rt); u = sat(1 - t) [v_pk_sub_u16 clamp: 1 where t == 0];
-// w = u * 0x3F80 [bf16 1.0] -- 1.5 VALU instructions per entry instead of compare + select + pack.
+// go through LDS, loaded two tiles ahead (below).
+// r02 at C5: 5.9 -> 4.8 ms (3.5 TB/s; the bare read pattern streams at 6.2 TB/s --
+// tpq_ubench_rows_read -- and the MFMAs need 2.5 ms; what is left is a wave waiting, 59 % of its
+// cycles by SQ_WAIT_INST_ANY, for its own LDS round trips at the head of every k-step: two waves
+// per SIMD do not cover them, and a second one-hot table to pipeline k-steps does not fit 20 KiB
+// of LDS per wave).
 #ifndef TPQ_UM_CT
 #define TPQ_UM_CT 1
 #endif
 #ifndef TPQ_UM_EXP
-#define TPQ_UM_EXP 0  // experiments (tools/build_variant.sh): 1 = no MFMAs, 2 = no tile reloads, 4 = no one-hot
+#define TPQ_UM_EXP 0  // experiments (tools/build_variant.sh): 1 = no MFMAs, 2 = no tile reloads
 #endif
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 
-// (plain vector code, no inline asm: the compiler selects v_pk_sub_i16 / v_pk_sub_u16 clamp /
-// v_pk_mul_lo_u16 from it AND knows the instructions -- an asm version of the same three
-// instructions produced scheduling-dependent wrong sums: the hazard recogniser cannot see a VALU
-// write inside an asm block that an MFMA reads as its A operand a few cycles later)
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b) {
-  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b));
-}
-__device__ __forceinline__ uint32_t onehot_pair_bf16(uint32_t t) {
-  const u16x2 one = {1, 1}, bf16_one = {0x3F80, 0x3F80};
-  const u16x2 u = __builtin_elementwise_sub_sat(one, __builtin_bit_cast(u16x2, t));  // 1 where t == 0
-  return __builtin_bit_cast(uint32_t, u * bf16_one);
-}
+// (Lesson kept from the version that built the one-hot operand in registers with three
+// packed-u16 instructions per label pair: written as inline asm they produced scheduling-dependent
+// WRONG sums -- the hazard recogniser cannot see a VALU write inside an asm block that an MFMA reads
+// as its A operand a few cycles later; the same instructions selected by the compiler from plain
+// vector code (__builtin_elementwise_sub_sat, u16x2 multiply) were correct.)
 
 template <int CT, bool VEC>
 __global__ __launch_bounds__(64, (CT == 1 ? 2 : 1)) void centroid_accum_mfma_kernel(
     const float* __restrict__ data, const int64_t* __restrict__ labels, float* __restrict__ sums,
-    float* __restrict__ counts, int d, int64_t n, int k, int64_t points) {
+    float* __restrict__ counts, int d, int64_t n, int k) {
   constexpr int ND = 32 * CT;  // dimensions per wave
-  __shared__ __attribute__((aligned(16))) float xt[2][ND * kUmStride];
-  __shared__ __attribute__((aligned(16))) uint16_t lt[2][kUmP];
+  // one wave per block: its DS operations execute in order, so ONE tile buffer is enough (the
+  // stores of tile t+1 queue up behind the reads of tile t) and no barrier is ever needed
+  __shared__ __attribute__((aligned(16))) float xt[ND * kUmStride];
+  // the one-hot operand of the current k-step: [2 k-groups][256 clusters][8 points] bf16, all zero
+  // except one 1.0 per point (see below)
+  __shared__ __attribute__((aligned(16))) uint16_t otab[256 * 16];
   __shared__ int cnt[256];
   const int b = blockIdx.z;
   const int lane = threadIdx.x;
   const int l31 = lane & 31, half = lane >> 5;
   const int e0 = blockIdx.y * ND;
   const int nd = (d - e0) < ND ? (d - e0) : ND;  // dimensions of this block that exist
-  const int64_t i0 = (int64_t)blockIdx.x * points;
-  const int64_t i1 = (i0 + points) < n ? (i0 + points) : n;
+  // Tiles are dealt round-robin to the gridDim.x blocks of a (sub-problem, dimension tile): the
+  // blocks run side by side, so at any moment they read ADJACENT 256-byte pieces of the same
+  // 32 rows -- whole DRAM pages get used while they are open.  (With one contiguous point range
+  // per block every 256-byte access opened a page of its own: the kernel read at 3.4 TB/s.)
+  const int64_t step = (int64_t)gridDim.x * kUmP;
+  const int64_t i0 = (int64_t)blockIdx.x * kUmP;  // first tile of this block (exists: host)
+  const int64_t i1 = n;
   const int64_t* __restrict__ lrow = labels + (int64_t)b * n;
   const float* __restrict__ dbase = data + ((int64_t)b * d + e0) * n;
   f32x16 acc[8][CT];  // [cluster row tile][dimension column tile]
@@ -626,8 +624,9 @@ __global__ __launch_bounds__(64, (CT == 1 ? 2 : 1)) void centroid_accum_mfma_ker
       for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
 #pragma unroll
   for (int u = 0; u < 4; ++u) cnt[lane + 64 * u] = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) reinterpret_cast<u32x4v*>(otab)[lane + 64 * u] = u32x4v{0u, 0u, 0u, 0u};
   const bool count_here = blockIdx.y == 0;
-  const uint32_t l31_pk = (uint32_t)l31 * 0x00010001u;
 
   // Tiles travel global -> registers -> LDS, TWO tiles ahead of the MFMAs: the loads of tile t+2
   // are issued in four quarters, one per MFMA k-step of tile t (so the wave's load issue hides
@@ -661,37 +660,51 @@ __global__ __launch_bounds__(64, (CT == 1 ? 2 : 1)) void centroid_accum_mfma_ker
       st.label = lrow[st.label_valid ? lp : i0];
     }
   };
-  auto store_tile = [&](const Staged& st, int buf) {
+  int lab_cur = -1;  // label of point (tile in LDS) + lane, -1 = none
+  auto store_tile = [&](const Staged& st) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int row = VEC ? 4 * j + vrow : j;
-      *reinterpret_cast<xreg_t*>(&xt[buf][row * kUmStride + vpt]) = st.x[j];
+      *reinterpret_cast<xreg_t*>(&xt[row * kUmStride + vpt]) = st.x[j];
     }
-    lt[buf][lane] = (st.label_valid && st.label >= 0 && st.label < k) ? (uint16_t)st.label : (uint16_t)0xFFFF;
+    lab_cur = (st.label_valid && st.label >= 0 && st.label < k) ? (int)st.label : -1;
   };
-  // one tile: MFMAs from LDS buffer `buf`; `fill` receives tile it+2; `drain` (tile it+1) goes to
-  // the other LDS buffer afterwards
-  auto run_tile = [&](int64_t p0, int buf, Staged& fill, const Staged& drain) {
+  // one tile: MFMAs from the LDS tile; `fill` receives tile it+2; `drain` (tile it+1) replaces the
+  // LDS tile afterwards.
+  // The one-hot A operand costs NO VALU work: the [256 clusters][16 points] bf16 matrix of a
+  // k-step lives in LDS, all zero; the 16 lanes that own the k-step's points each store one 1.0
+  // at [label][point] (ds_write_b16), every lane then reads its 8 row tiles as ds_read_b128 --
+  // 16 contiguous bytes = the 8 consecutive points of its k-group, exactly the fragment -- and the
+  // writers store the zero back.  (Built in registers from packed label pairs the operand took
+  // 96 VALU instructions per k-step, 3 per pair and row tile, next to 44 for the bf16 splitting:
+  // the two waves of a SIMD then issue as many VALU cycles as MFMA cycles and the update ran at
+  // 5.2 ms against 2.5 ms of matrix-pipe time.)
+  auto run_tile = [&](int64_t p0, Staged& fill, const Staged& drain) {
     // (no "is there a tile t+1 / t+2" branches: beyond the range the loads read clamped addresses
-    // and the stores fill a buffer nobody reads.  With conditional loads the compiler's waitcnt
+    // and the store fills a tile nobody reads.  With conditional loads the compiler's waitcnt
     // bookkeeping merges the two paths and falls back to vmcnt(0) before the LDS stores, i.e. it
     // waits for the loads of tile t+2 that were only just issued)
-    if (count_here) {
-      const int l = lt[buf][lane];
-      if (l != 0xFFFF) atomicAdd(&cnt[l], 1);  // integer LDS atomic: fast
-    }
+    if (count_here && lab_cur >= 0) atomicAdd(&cnt[lab_cur], 1);  // integer LDS atomic: fast
+    // layout [k-group (2)][cluster (256)][8 points]: the 16 lanes of a ds_read_b128 group then read
+    // 256 contiguous bytes (with [cluster][16 points] rows two lanes of a group met on a bank:
+    // SQ_LDS_BANK_CONFLICT was 36 % of the LDS cycles)
+    uint16_t* oslot = &otab[((lane >> 3) & 1) * 2048 + (lab_cur >= 0 ? lab_cur : 0) * 8 + (lane & 7)];
 #pragma unroll
     for (int ks = 0; ks < kUmP / 16; ++ks) {
-      if (!(TPQ_UM_EXP & 2)) load_quarter(fill, p0 + 2 * kUmP, ks);
+      if (!(TPQ_UM_EXP & 2)) load_quarter(fill, p0 + 2 * step, ks);
+      const bool writer = (lane >> 4) == ks && lab_cur >= 0;
+      if (writer) *oslot = (uint16_t)0x3F80;  // bf16 1.0
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       const int pts = 16 * ks + 8 * half;  // this lane's 8 points (its k-group)
-      const u32x4v lp = *reinterpret_cast<const u32x4v*>(&lt[buf][pts]);  // 4 packed label pairs
-      uint32_t dl[4];
-#pragma unroll
-      for (int pr = 0; pr < 4; ++pr) dl[pr] = pk_sub_u16(lp[pr], l31_pk);
+      const bf16x8* orow = reinterpret_cast<const bf16x8*>(&otab[half * 2048 + l31 * 8]);
+      bf16x8 aring[3];  // A operands are fetched two row tiles ahead of their MFMAs
+      aring[0] = orow[0];
+      aring[1] = orow[32];
       bf16x8 piece[3][CT];  // [hi, mid, lo][column tile]
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        const float* xrow = &xt[buf][(32 * ct + l31) * kUmStride + pts];
+        const float* xrow = &xt[(32 * ct + l31) * kUmStride + pts];
         const float4 xa = *reinterpret_cast<const float4*>(xrow);
         const float4 xb = *reinterpret_cast<const float4*>(xrow + 4);
         const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
@@ -709,12 +722,8 @@ __global__ __launch_bounds__(64, (CT == 1 ? 2 : 1)) void centroid_accum_mfma_ker
       // the accumulator tiles take turns: an MFMA never waits for the one issued before it
 #pragma unroll
       for (int rt = 0; rt < 8; ++rt) {
-        u32x4v aw;
-#pragma unroll
-        for (int pr = 0; pr < 4; ++pr)
-          aw[pr] = (TPQ_UM_EXP & 4) ? (dl[pr] + rt)
-                                    : onehot_pair_bf16(rt == 0 ? dl[pr] : (dl[pr] ^ (uint32_t)(32 * rt * 0x00010001)));
-        const bf16x8 a = __builtin_bit_cast(bf16x8, aw);
+        if (rt + 2 < 8) aring[(rt + 2) % 3] = orow[32 * (rt + 2)];  // 32 rows x 16 B
+        const bf16x8 aop = aring[rt % 3];
         // (all column tiles always: a wave-uniform branch around the second one when d <= 32
         // broke the MFMA interleaving and cost more than the multiplies it saved)
 #pragma unroll
@@ -722,17 +731,19 @@ __global__ __launch_bounds__(64, (CT == 1 ? 2 : 1)) void centroid_accum_mfma_ker
 #pragma unroll
           for (int ct = 0; ct < CT; ++ct) {
             if (TPQ_UM_EXP & 1) {
-              acc[rt][ct][pc] += (float)a[pc] + (float)piece[pc][ct][rt];
+              acc[rt][ct][pc] += (float)aop[pc] + (float)piece[pc][ct][rt];
               continue;
             }
-            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, piece[pc][ct], acc[rt][ct], 0, 0, 0);
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aop, piece[pc][ct], acc[rt][ct], 0, 0, 0);
           }
       }
+      __builtin_amdgcn_wave_barrier();
+      if (writer) *oslot = (uint16_t)0;  // after the last read of this k-step has been issued
     }
-    store_tile(drain, buf ^ 1);
-    // one wave per block: its DS operations execute in order, so the next tile's reads see these
-    // stores without a barrier -- and a __syncthreads() would bring an s_waitcnt vmcnt(0) with it,
-    // i.e. wait for the loads of tile t+2 that were only just issued
+    store_tile(drain);
+    // the next tile's reads see these stores without a barrier (in-order DS) -- and a
+    // __syncthreads() would bring an s_waitcnt vmcnt(0) with it, i.e. wait for the loads of tile
+    // t+2 that were only just issued
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   };
@@ -741,15 +752,15 @@ __global__ __launch_bounds__(64, (CT == 1 ? 2 : 1)) void centroid_accum_mfma_ker
   sa.label_valid = sb.label_valid = false;
 #pragma unroll
   for (int qt = 0; qt < 4; ++qt) load_quarter(sa, i0, qt);
-  store_tile(sa, 0);
+  store_tile(sa);
 #pragma unroll
-  for (int qt = 0; qt < 4; ++qt) load_quarter(sa, i0 + kUmP, qt);  // clamped when out of range
+  for (int qt = 0; qt < 4; ++qt) load_quarter(sa, i0 + step, qt);  // clamped when out of range
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
-  for (int64_t p0 = i0; p0 < i1; p0 += 2 * kUmP) {
-    run_tile(p0, 0, sb, sa);                             // tile 2j: fill sb (2j+2), drain sa (2j+1)
-    if (p0 + kUmP < i1) run_tile(p0 + kUmP, 1, sa, sb);  // tile 2j+1: fill sa (2j+3), drain sb (2j+2)
+  for (int64_t p0 = i0; p0 < i1; p0 += 2 * step) {
+    run_tile(p0, sb, sa);                             // tile 2j: fill sb (2j+2), drain sa (2j+1)
+    if (p0 + step < i1) run_tile(p0 + step, sa, sb);  // tile 2j+1: fill sa (2j+3), drain sb (2j+2)
   }
 #pragma unroll
   for (int rt = 0; rt < 8; ++rt)
@@ -853,22 +864,20 @@ extern "C" int tpq_compute_centroids(const float* data, const int64_t* labels, f
     if (k <= 256 && d >= 32) {  // wide PQ-codebook shape: bf16 matrix cores
       constexpr int CT = TPQ_UM_CT;
       const int dtiles = (d + 32 * CT - 1) / (32 * CT);
-      // one wave per block; 2 / CT waves per SIMD resident -> aim for a few rounds of 2048 / CT blocks
+      // blocks per (sub-problem, dimension tile): a few rounds of the 2048 / CT resident waves,
+      // but at least 64 tiles (4096 points) per block -- every block ends with 256 x 32 CT global
+      // atomics -- and never more blocks than tiles
       int64_t chunks = (4096 / CT) / ((int64_t)l * dtiles);
+      const int64_t n_tiles = (n + kUmP - 1) / kUmP;
+      if (chunks > n_tiles / 64) chunks = n_tiles / 64;
       if (chunks < 1) chunks = 1;
-      int64_t points = (n + chunks - 1) / chunks;
-      if (points < 4096) points = 4096;
-#ifdef TPQ_UM_POINTS
-      points = TPQ_UM_POINTS;
-#endif
-      points = (points + kUmP - 1) / kUmP * kUmP;
-      const dim3 grid((unsigned)((n + points - 1) / points), dtiles, l);
+      const dim3 grid((unsigned)chunks, dtiles, l);
       if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(data) & 15) == 0)
         hipLaunchKernelGGL((centroid_accum_mfma_kernel<CT, true>), grid, dim3(64), 0, st, data, labels,
-                           sums, counts, d, n, k, points);
+                           sums, counts, d, n, k);
       else
         hipLaunchKernelGGL((centroid_accum_mfma_kernel<CT, false>), grid, dim3(64), 0, st, data, labels,
-                           sums, counts, d, n, k, points);
+                           sums, counts, d, n, k);
       TPQ_LAUNCH_CHECK("centroid_accum_mfma_kernel");
       const int64_t total = (int64_t)l * d * k;
       hipLaunchKernelGGL(centroid_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
