@@ -207,6 +207,14 @@ int tpq_ivfpq_coarse_probe(const float* query, const float* centroids,
 int tpq_smart_probing(const float* topk_sims, int64_t* n_probe_list, int rows, int n_probe,
                       float temperature, tpq_stream_t stream);
 
+/* id -> address, linear form (BaseContainer(use_inverse_id_mapping=False))
+ * replaces get_address_by_id   torchpq/kernels/cuda/get_address_by_id.cu:8-44
+ * (wrapper GetAddressByIdCuda, torchpq/container/BaseContainer.py:79-98): every id against every
+ * stored id, O(n_ids x capacity); address[i] = smallest slot with address2id == ids[i], else -1
+ * (negative ids are never found: free slots hold -1). */
+int tpq_get_address_by_id(const int64_t* address2id, int64_t capacity, const int64_t* ids,
+                          int64_t* address, int64_t n_ids, tpq_stream_t stream);
+
 /* a-7  address -> id           torchpq/container/BaseContainer.py:58-65 */
 int tpq_get_id_by_address(const int64_t* address2id, int64_t capacity, const int64_t* address,
                           int64_t* ids, int64_t n, tpq_stream_t stream);

@@ -136,3 +136,37 @@ def test_empty(module):
     module.add(make_data(100), cells=make_cells(module, 100))
     module.empty()
     assert module.n_items == 0 and (module._cell_size == 0).all() and (module._is_empty == 1).all()
+
+
+def test_linear_get_address_by_id_without_inverse_mapping():
+    """use_inverse_id_mapping=False: ids are resolved by the linear search of
+    the reference (kernels/cuda/get_address_by_id.cu:8-44, tpq_get_address_by_id) -- no table is
+    built -- and agree with the table path; remove(ids=...) works through it."""
+    from torchpq_amd.container import CellContainer
+    torch.manual_seed(3)
+    kw = dict(code_size=CODE_SIZE, n_cells=N_CELLS, dtype="uint8", device=DEV, initial_size=16,
+              expand_step_size=16, expand_mode="double", contiguous_size=4)
+    lin = CellContainer(use_inverse_id_mapping=False, **kw)
+    tab = CellContainer(use_inverse_id_mapping=True, **kw)
+    n = 5000
+    data = make_data(n)
+    cells = torch.randint(N_CELLS, (n,), device=DEV, dtype=torch.long)
+    ids = torch.randperm(10 ** 6, device=DEV)[:n] * 7 + 3
+    for c in (lin, tab):
+        c.add(data[:, :3000].contiguous(), cells[:3000], ids[:3000])
+        c.add(data[:, 3000:].contiguous(), cells[3000:], ids[3000:])
+    probe = torch.cat([ids[torch.randperm(n, device=DEV)[:700]],
+                       torch.tensor([-5, -1, 0, 1, 2, 10 ** 9], device=DEV)])
+    a_lin, a_tab = lin.get_address_by_id(probe), tab.get_address_by_id(probe)
+    assert lin._id2address is None and lin._sparse_id_map is None     # no table was created
+    assert torch.equal(a_lin, a_tab)
+    assert bool((a_lin[-6:] == -1).all()) and bool((a_lin[:700] >= 0).all())
+    assert torch.equal(lin._address2id[a_lin[:700]], probe[:700])
+    assert torch.equal(lin.get_address_by_id(probe.reshape(2, -1)), a_lin.reshape(2, -1))
+    gone = ids[::5].contiguous()
+    lin.remove(ids=gone)
+    tab.remove(ids=gone)
+    assert lin.n_items == tab.n_items == n - gone.shape[0]
+    assert torch.equal(lin._address2id, tab._address2id) and torch.equal(lin._storage, tab._storage)
+    assert bool((lin.get_address_by_id(gone) == -1).all())
+    assert lin.get_address_by_id(torch.empty(0, dtype=torch.long, device=DEV)).shape == (0,)

@@ -47,6 +47,7 @@ SIGNATURES = {
     "tpq_ivfpq_coarse_probe": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f,
                                     _vp, _sz, _vp]),
     "tpq_get_id_by_address": (_i, [_vp, _i64, _vp, _vp, _i64, _vp]),
+    "tpq_get_address_by_id": (_i, [_vp, _i64, _vp, _vp, _i64, _vp]),
     "tpq_max_sim": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tpq_compute_centroids_workspace_bytes": (_sz, [_i, _i, _i]),
     "tpq_compute_centroids": (_i, [_vp, _vp, _vp, _i, _i, _i64, _i, _vp, _sz, _vp]),

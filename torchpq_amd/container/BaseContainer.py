@@ -5,7 +5,7 @@ import torch
 
 from .. import util
 from ..CustomModule import CustomModule
-from ..kernels import GetIdByAddressHip
+from ..kernels import GetAddressByIdHip, GetIdByAddressHip
 
 
 class BaseContainer(CustomModule, ABC):
@@ -33,6 +33,7 @@ class BaseContainer(CustomModule, ABC):
         self.register_buffer("_id2address", None)
         self._sparse_id_map = None  # (sorted ids, their addresses) when ids are too sparse for a table
         self._get_id_by_address_hip = GetIdByAddressHip()
+        self._get_address_by_id_hip = GetAddressByIdHip()
 
     @property
     def capacity(self):
@@ -79,6 +80,9 @@ class BaseContainer(CustomModule, ABC):
         after every add/remove (the reference keeps serving a stale one)."""
         assert util.check_dtype(ids, torch.int64)
         ids = ids.to(self.device)
+        if not self.use_inverse_id_mapping:
+            # the reference's linear search (kernels/cuda/get_address_by_id.cu:8-44): no table kept
+            return self._get_address_by_id_hip(self._address2id, ids.reshape(-1)).reshape(ids.shape)
         if self._id2address is None and self._sparse_id_map is None:
             self.create_inverse_id_mapping()
         if self._sparse_id_map is not None:

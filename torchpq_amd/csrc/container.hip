@@ -124,6 +124,40 @@ __global__ __launch_bounds__(256) void pq_decode_kernel(const float* __restrict_
     out[((int64_t)j * ds + e) * n + i] = codebook[((int64_t)j * ds + e) * 256 + c];
 }
 
+// ---- get_address_by_id, linear form (use_inverse_id_mapping=False) ---------------------------
+// replaces get_address_by_id (torchpq/kernels/cuda/get_address_by_id.cu:8-44): every id is compared
+// with every stored id -- O(n_ids x capacity), as in the reference; the result is the SMALLEST
+// address holding the id (the reference's CPU form, BaseContainer.py:67-77), -1 when absent.
+// grid (address chunks, id tiles of 256): a block stages 256 ids in LDS and streams its addresses.
+__global__ __launch_bounds__(256) void address_by_id_init_kernel(int64_t* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = INT64_MAX;
+}
+__global__ __launch_bounds__(256) void address_by_id_kernel(const int64_t* __restrict__ a2i,
+                                                           int64_t cap,
+                                                           const int64_t* __restrict__ ids,
+                                                           int64_t* __restrict__ out, int64_t n_ids,
+                                                           int64_t per_block) {
+  __shared__ int64_t want[256];
+  const int64_t i0 = (int64_t)blockIdx.y * 256;
+  const int64_t wi = i0 + threadIdx.x;
+  want[threadIdx.x] = wi < n_ids ? ids[wi] : -1;
+  __syncthreads();
+  const int n_want = (int)((n_ids - i0) < 256 ? (n_ids - i0) : 256);
+  const int64_t a0 = (int64_t)blockIdx.x * per_block;
+  const int64_t a1 = (a0 + per_block) < cap ? (a0 + per_block) : cap;
+  for (int64_t a = a0 + threadIdx.x; a < a1; a += 256) {
+    const int64_t v = a2i[a];
+    if (v < 0) continue;  // free slot
+    for (int j = 0; j < n_want; ++j)
+      if (want[j] == v) atomicMin(reinterpret_cast<unsigned long long*>(&out[i0 + j]), (unsigned long long)a);
+  }
+}
+__global__ __launch_bounds__(256) void address_by_id_finish_kernel(int64_t* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n && out[i] == INT64_MAX) out[i] = -1;
+}
+
 }  // namespace tpq
 
 using namespace tpq;
@@ -209,5 +243,28 @@ extern "C" int tpq_pq_decode(const float* codebook, const uint8_t* codes, float*
   hipLaunchKernelGGL(pq_decode_kernel, dim3((unsigned)((n + 255) / 256), m), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), codebook, codes, out, ds, n);
   TPQ_LAUNCH_CHECK("pq_decode_kernel");
+  return TPQ_OK;
+}
+
+extern "C" int tpq_get_address_by_id(const int64_t* address2id, int64_t capacity, const int64_t* ids,
+                                     int64_t* address, int64_t n_ids, tpq_stream_t stream) {
+  TPQ_REQUIRE(capacity >= 0 && n_ids >= 0, "get_address_by_id: bad sizes");
+  if (n_ids == 0) return TPQ_OK;
+  TPQ_REQUIRE(ids && address && (address2id || capacity == 0), "get_address_by_id: null pointer");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const unsigned nb = (unsigned)((n_ids + 255) / 256);
+  hipLaunchKernelGGL(address_by_id_init_kernel, dim3(nb), dim3(256), 0, st, address, n_ids);
+  TPQ_LAUNCH_CHECK("address_by_id_init_kernel");
+  if (capacity > 0) {
+    TPQ_REQUIRE(nb <= 65535, "get_address_by_id: too many ids for one call (%lld)", (long long)n_ids);
+    int64_t chunks = (capacity + 4095) / 4096;
+    if (chunks > 4096) chunks = 4096;
+    const int64_t per_block = ((capacity + chunks - 1) / chunks + 255) / 256 * 256;
+    hipLaunchKernelGGL(address_by_id_kernel, dim3((unsigned)((capacity + per_block - 1) / per_block), nb),
+                       dim3(256), 0, st, address2id, capacity, ids, address, n_ids, per_block);
+    TPQ_LAUNCH_CHECK("address_by_id_kernel");
+  }
+  hipLaunchKernelGGL(address_by_id_finish_kernel, dim3(nb), dim3(256), 0, st, address, n_ids);
+  TPQ_LAUNCH_CHECK("address_by_id_finish_kernel");
   return TPQ_OK;
 }

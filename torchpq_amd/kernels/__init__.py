@@ -15,7 +15,7 @@ from .._lib import check, load, ptr, require_gpu, stream_ptr
 __all__ = [
     "IVFPQTopkHip", "IVFPQTop1Hip", "ResidualPart1Hip", "ResidualSlotTermsHip", "AdcLutHip", "TopkSelectHip", "CoarseSelectHip", "CoarseProbeHip", "Top1SelectHip",
     "Top32SelectHip", "SmartProbingHip", "MaxSimHip", "ComputeCentroidsHip", "GetIOAHip",
-    "GetWriteAddressHip", "GetCellByAddressHip", "GetIdByAddressHip", "PQDecodeHip",
+    "GetWriteAddressHip", "GetCellByAddressHip", "GetIdByAddressHip", "GetAddressByIdHip", "PQDecodeHip",
     "ScatterCodesHip", "PackCodesHip", "packed_chunk_width", "PACKED_M",
 ]
 
@@ -609,6 +609,26 @@ class GetIdByAddressHip:
                                                ptr(out), flat.shape[0], stream_ptr(flat.device)),
                   "tpq_get_id_by_address")
         return out.view(shape)
+
+
+class GetAddressByIdHip:
+    """id -> address by comparing every id with every stored id (kernels/GetAddressByIdCuda.py,
+    kernels/cuda/get_address_by_id.cu:8-44): the use_inverse_id_mapping=False path of
+    BaseContainer.get_address_by_id; smallest matching address, -1 when absent."""
+
+    def __init__(self, tpb=256):
+        pass
+
+    def __call__(self, address2id, ids):
+        assert address2id.dtype == ids.dtype == torch.int64
+        ids = ids.contiguous()
+        require_gpu(address2id, ids)
+        out = torch.empty_like(ids)
+        with torch.cuda.device(ids.device):
+            check(load().tpq_get_address_by_id(ptr(address2id), address2id.shape[0], ptr(ids), ptr(out),
+                                               ids.shape[0], stream_ptr(ids.device)),
+                  "tpq_get_address_by_id")
+        return out
 
 
 class PQDecodeHip:
