@@ -264,6 +264,19 @@ int tpq_get_cell_by_address(const int64_t* address, const int64_t* cell_start,
                             const int64_t* cell_capacity, int64_t* cells, int64_t n_address,
                             int64_t n_cells, tpq_stream_t stream);
 
+/* a-6  expand: re-lay the lists out for larger per-cell capacities
+ * replaces CellContainer.expand  torchpq/container/CellContainer.py:249-311 (a torch.cat of the whole
+ * storage per expanding cell).  Cell c moves from [old_start[c], + old_capacity[c]) to
+ * [new_start[c], + new_capacity[c]) (new_capacity >= old_capacity, new_start = exclusive prefix sum
+ * of new_capacity); the added tail of every cell is initialised free (codes 0, id -1, is_empty 1).
+ * storage u8 [m/4][old_slots][4] -> new_storage u8 [m/4][new_slots][4]; the new buffers need no
+ * initialisation by the caller. */
+int tpq_grow_cells(const uint8_t* storage, const int64_t* address2id, const uint8_t* is_empty,
+                   const int64_t* old_start, const int64_t* old_capacity, const int64_t* new_start,
+                   const int64_t* new_capacity, uint8_t* new_storage, int64_t* new_address2id,
+                   uint8_t* new_is_empty, int64_t old_slots, int64_t new_slots, int n_cells, int m,
+                   tpq_stream_t stream);
+
 /* a-13  PQ decode   replaces PQDecodeCuda  torchpq/kernels/cuda/pq_decode.cu:8-53
  * codebook f32 [m][ds][256], codes u8 [m][n] -> out f32 [m*ds][n] */
 int tpq_pq_decode(const float* codebook, const uint8_t* codes, float* out, int m, int ds, int64_t n,

@@ -55,6 +55,7 @@ SIGNATURES = {
     "tpq_get_ioa": (_i, [_vp, _vp, _i64, _i64, _vp, _sz, _vp]),
     "tpq_get_write_address": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp]),
     "tpq_get_cell_by_address": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "tpq_grow_cells": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _vp]),
     "tpq_pq_decode": (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp]),
     "tpq_scatter_codes": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _vp]),
     "tpq_ubench_stream_read": (_i, [_vp, _sz, _vp, _i, _vp]),

@@ -9,8 +9,8 @@ scan layout (csrc/scan_layout.h); it is kept in step by add() and rebuilt lazily
 import torch
 
 from .. import util
-from ..kernels import (GetCellByAddressHip, GetIOAHip, GetWriteAddressHip, PackCodesHip,
-                       ScatterCodesHip)
+from ..kernels import (GetCellByAddressHip, GetIOAHip, GetWriteAddressHip, GrowCellsHip,
+                       PackCodesHip, ScatterCodesHip)
 from .BaseContainer import BaseContainer
 
 
@@ -54,6 +54,7 @@ class CellContainer(BaseContainer):
         self._get_write_address_hip = GetWriteAddressHip()
         self._scatter_codes_hip = ScatterCodesHip()
         self._pack_codes_hip = PackCodesHip()
+        self._grow_cells_hip = GrowCellsHip()
 
     # ---- derived state -------------------------------------------------------------------------
     @property
@@ -138,22 +139,16 @@ class CellContainer(BaseContainer):
     def _grow(self, new_capacity):
         """Re-lay the buffers out for per-cell capacities `new_capacity` (>= current).  Same final
         layout as the reference's per-cell torch.cat loop (:249-311) -- each cell keeps its slots
-        and gains free ones at its end -- in one gather instead of O(capacity) per cell."""
+        and gains free ones at its end -- in one kernel pass (tpq_grow_cells) instead of
+        O(capacity) per cell."""
         old_cap = self._cell_capacity
         if bool((new_capacity == old_cap).all().item()):
             return 0
-        dev = self._storage.device
         new_start = torch.cumsum(new_capacity, 0) - new_capacity
-        cell = torch.repeat_interleave(torch.arange(self.n_cells, device=dev), old_cap)
-        new_index = torch.arange(self.capacity, device=dev) + (new_start - self._cell_start)[cell]
         total = int(new_capacity.sum().item())
-        storage = torch.zeros(self._storage.shape[0], total, self._storage.shape[2], device=dev,
-                              dtype=self._storage.dtype)
-        storage[:, new_index] = self._storage
-        a2i = torch.full((total,), -1, device=dev, dtype=torch.long)
-        a2i[new_index] = self._address2id
-        is_empty = torch.ones(total, device=dev, dtype=torch.uint8)
-        is_empty[new_index] = self._is_empty
+        storage, a2i, is_empty = self._grow_cells_hip(
+            self._storage, self._address2id, self._is_empty, self._cell_start, old_cap.contiguous(),
+            new_start.contiguous(), new_capacity.contiguous(), total)
         added = total - self.capacity
         del self._storage, self._address2id, self._is_empty
         self.register_buffer("_storage", storage)

@@ -158,6 +158,29 @@ __global__ __launch_bounds__(256) void address_by_id_finish_kernel(int64_t* __re
   if (i < n && out[i] == INT64_MAX) out[i] = -1;
 }
 
+// ---- expand(): re-lay the inverted lists out for larger per-cell capacities ---------------------
+// replaces the per-cell torch.cat loop of CellContainer.expand (torchpq/container/CellContainer.py:
+// 249-311: O(capacity) work PER expanding cell).  One pass: cell c's slots move from
+// [old_start, old_start + old_cap) to [new_start, ...), its new tail is initialised free.
+// grid (n_cells, Y): block (c, y) walks slots y*256 + t, step Y*256, of the cell's NEW range.
+__global__ __launch_bounds__(256) void grow_cells_kernel(
+    const uint32_t* __restrict__ codes, const int64_t* __restrict__ a2i,
+    const uint8_t* __restrict__ is_empty, const int64_t* __restrict__ old_start,
+    const int64_t* __restrict__ old_cap, const int64_t* __restrict__ new_start,
+    const int64_t* __restrict__ new_cap, uint32_t* __restrict__ new_codes,
+    int64_t* __restrict__ new_a2i, uint8_t* __restrict__ new_is_empty, int64_t old_slots,
+    int64_t new_slots, int G) {
+  const int c = blockIdx.x;
+  const int64_t os = old_start[c], oc = old_cap[c], ns = new_start[c], nc = new_cap[c];
+  for (int64_t s = (int64_t)blockIdx.y * 256 + threadIdx.x; s < nc; s += (int64_t)gridDim.y * 256) {
+    const bool had = s < oc;
+    new_a2i[ns + s] = had ? a2i[os + s] : -1;
+    new_is_empty[ns + s] = had ? is_empty[os + s] : (uint8_t)1;
+    for (int g = 0; g < G; ++g)
+      new_codes[(int64_t)g * new_slots + ns + s] = had ? codes[(int64_t)g * old_slots + os + s] : 0u;
+  }
+}
+
 }  // namespace tpq
 
 using namespace tpq;
@@ -266,5 +289,29 @@ extern "C" int tpq_get_address_by_id(const int64_t* address2id, int64_t capacity
   }
   hipLaunchKernelGGL(address_by_id_finish_kernel, dim3(nb), dim3(256), 0, st, address, n_ids);
   TPQ_LAUNCH_CHECK("address_by_id_finish_kernel");
+  return TPQ_OK;
+}
+
+extern "C" int tpq_grow_cells(const uint8_t* storage, const int64_t* address2id, const uint8_t* is_empty,
+                              const int64_t* old_start, const int64_t* old_capacity,
+                              const int64_t* new_start, const int64_t* new_capacity,
+                              uint8_t* new_storage, int64_t* new_address2id, uint8_t* new_is_empty,
+                              int64_t old_slots, int64_t new_slots, int n_cells, int m,
+                              tpq_stream_t stream) {
+  TPQ_REQUIRE(storage && address2id && is_empty && old_start && old_capacity && new_start &&
+                  new_capacity && new_storage && new_address2id && new_is_empty,
+              "grow_cells: null pointer");
+  TPQ_REQUIRE(m >= 4 && m % 4 == 0, "grow_cells: n_subvectors=%d must be a positive multiple of 4", m);
+  TPQ_REQUIRE(n_cells >= 1 && old_slots >= 0 && new_slots >= old_slots, "grow_cells: bad sizes");
+  if (new_slots == 0) return TPQ_OK;
+  int64_t y = (new_slots / n_cells + 2047) / 2048;
+  if (y < 1) y = 1;
+  if (y > 256) y = 256;
+  hipLaunchKernelGGL(grow_cells_kernel, dim3((unsigned)n_cells, (unsigned)y), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const uint32_t*>(storage),
+                     address2id, is_empty, old_start, old_capacity, new_start, new_capacity,
+                     reinterpret_cast<uint32_t*>(new_storage), new_address2id, new_is_empty, old_slots,
+                     new_slots, m / 4);
+  TPQ_LAUNCH_CHECK("grow_cells_kernel");
   return TPQ_OK;
 }

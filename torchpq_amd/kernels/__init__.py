@@ -15,7 +15,7 @@ from .._lib import check, load, ptr, require_gpu, stream_ptr
 __all__ = [
     "IVFPQTopkHip", "IVFPQTop1Hip", "ResidualPart1Hip", "ResidualSlotTermsHip", "AdcLutHip", "TopkSelectHip", "CoarseSelectHip", "CoarseProbeHip", "Top1SelectHip",
     "Top32SelectHip", "SmartProbingHip", "MaxSimHip", "ComputeCentroidsHip", "GetIOAHip",
-    "GetWriteAddressHip", "GetCellByAddressHip", "GetIdByAddressHip", "GetAddressByIdHip", "PQDecodeHip",
+    "GetWriteAddressHip", "GetCellByAddressHip", "GetIdByAddressHip", "GetAddressByIdHip", "GrowCellsHip", "PQDecodeHip",
     "ScatterCodesHip", "PackCodesHip", "packed_chunk_width", "PACKED_M",
 ]
 
@@ -629,6 +629,28 @@ class GetAddressByIdHip:
                                                ids.shape[0], stream_ptr(ids.device)),
                   "tpq_get_address_by_id")
         return out
+
+
+class GrowCellsHip:
+    """CellContainer.expand in one pass (container/CellContainer.py:249-311): every cell moves to
+    its place in the larger layout, new tails initialised free.  Returns the three new buffers."""
+
+    def __call__(self, storage, address2id, is_empty, old_start, old_capacity, new_start, new_capacity,
+                 new_slots):
+        g, old_slots, cs = storage.shape
+        assert cs == 4 and storage.dtype == torch.uint8
+        require_gpu(storage, address2id, is_empty, old_start, old_capacity, new_start, new_capacity)
+        dev = storage.device
+        new_storage = torch.empty(g, new_slots, 4, device=dev, dtype=torch.uint8)
+        new_a2i = torch.empty(new_slots, device=dev, dtype=torch.int64)
+        new_empty = torch.empty(new_slots, device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            check(load().tpq_grow_cells(ptr(storage), ptr(address2id), ptr(is_empty), ptr(old_start),
+                                        ptr(old_capacity), ptr(new_start), ptr(new_capacity),
+                                        ptr(new_storage), ptr(new_a2i), ptr(new_empty), old_slots,
+                                        new_slots, old_start.shape[0], g * 4, stream_ptr(dev)),
+                  "tpq_grow_cells")
+        return new_storage, new_a2i, new_empty
 
 
 class PQDecodeHip:
