@@ -57,6 +57,11 @@ def fx_kmeans_fit():
 
 
 @pytest.fixture(scope="session")
+def fx_cosine():
+    return load_golden("fx_cosine")
+
+
+@pytest.fixture(scope="session")
 def fx_residual():
     return load_golden("fx_residual")
 

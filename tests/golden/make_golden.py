@@ -268,6 +268,49 @@ def fx_kmeans_fit(torch, tq):
     print("fx_kmeans_fit ok: errors", [round(e, 3) for e in errs[:5]], "redo inertia", inert)
 
 
+def fx_cosine(torch, tq):
+    """distance="cosine": reference train / add on CPU (IVFPQIndex.py:234-260,316-364: inputs
+    normalised, coarse quantiser euclidean on the normalised vectors, PQ k-means and the ADC table
+    by dot product -- codec/PQCodec.py:62-75 with cos_sim(normalize=False)), the reference's coarse
+    sims and LUT for normalised queries; scan results from the oracle (no CPU scan upstream)."""
+    d, m, n_cells, n, nq, n_probe = 32, 8, 16, 2500, 12, 4
+    rng = np.random.default_rng(8)
+    base = sift_like(rng, d, n)
+    np.random.seed(8)
+    torch.manual_seed(8)
+    idx = tq.index.IVFPQIndex(d_vector=d, n_subvectors=m, n_cells=n_cells, initial_size=256,
+                              distance="cosine", device="cpu")
+    xb = torch.from_numpy(base.copy())
+    idx.train(xb.clone())
+    ids = idx.add(xb.clone())
+    sd = {k: v.numpy().copy() for k, v in idx.state_dict().items() if v is not None}
+    queries = sift_like(rng, d, nq)
+    xq = tq.util.normalize(torch.from_numpy(queries.copy()), dim=0)  # search() normalises (:480-481)
+    ref_sims = tq.metric.negative_squared_l2_distance(xq.clone(), idx.vq_codec.codebook.clone()).numpy()
+    ref_lut = idx.pq_codec.precompute_adc(xq.clone()).numpy()
+    topk_sims, cells = torch.from_numpy(ref_sims).topk(n_probe, dim=1)
+    # every stored code's value through the reference's decode: sum_j LUT == q . decode(code)
+    cap = idx._storage.shape[1]
+    codes_all = idx.get_data_by_address(torch.arange(cap))
+    ref_decode = idx.pq_codec.decode(codes_all).numpy()
+    ref_dot = (xq.numpy().T.astype(np.float64) @ ref_decode.astype(np.float64)).astype(np.float32)
+    out = dict(d=d, m=m, n_cells=n_cells, n=n, nq=nq, n_probe=n_probe, ks=np.array([1, 10]),
+               base=base, queries=queries, queries_normalized=xq.numpy(), add_ids=ids.numpy(),
+               ref_sims=ref_sims, ref_lut=ref_lut, ref_cells=cells.numpy(), ref_dot_decode=ref_dot)
+    for k, v in sd.items():
+        out["sd." + k] = v
+    cs = sd["_cell_start"][out["ref_cells"]]
+    sz = sd["_cell_size"][out["ref_cells"]]
+    npl = np.full(nq, n_probe, np.int64)
+    for k in (1, 10):
+        v, a = orc.scan_topk(sd["_storage"], ref_lut, sd["_is_empty"], cs, sz, npl, k)
+        out[f"orc_vals_k{k}"] = v
+        out[f"orc_addr_k{k}"] = a
+        out[f"orc_ids_k{k}"] = orc.get_id_by_address(sd["_address2id"], a)
+    np.savez_compressed(os.path.join(OUT, "fx_cosine.npz"), **out)
+    print("fx_cosine ok: n_items", int(sd["_cell_size"].sum()), "lut range", float(ref_lut.min()), float(ref_lut.max()))
+
+
 def fx_residual(torch, tq):
     """pq_use_residual=True: reference train/add on CPU, reference part1/part2/full tables
     (IVFPQIndex.py:160-170, 366-405); scan results from the oracle (no CPU scan in the reference)."""
@@ -403,6 +446,7 @@ def main():
         "fx_kmeans": lambda: fx_kmeans(torch, tq),
         "fx_kmeans_fit": lambda: fx_kmeans_fit(torch, tq),
         "fx_residual": lambda: fx_residual(torch, tq),
+        "fx_cosine": lambda: fx_cosine(torch, tq),
         "fx_ties_tomb": lambda: fx_ties_and_tomb(torch, tq),
         "fx_layout": lambda: fx_layout(torch, tq),
     }

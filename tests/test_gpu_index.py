@@ -511,3 +511,38 @@ def test_is_trained_sees_in_place_writes():
     assert c.is_trained is False
     c._is_trained.copy_(torch.tensor(True))
     assert c.is_trained is True
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_cosine_index_on_reference_trained_state_dict(fx_cosine, packed):
+    """distance="cosine" end to end on a reference-trained index (fx_cosine): search() normalises
+    the queries (IVFPQIndex.py:480-481), probes with the euclidean coarse quantiser, builds the
+    dot-product LUT; results bit-equal the oracle on the index's own probe, the LUT kernel matches
+    the reference's precompute_adc, ids match the golden oracle run."""
+    import torchpq_amd.kernels as K
+    fx = fx_cosine
+    idx = _index_from_fixture(fx, distance="cosine")
+    idx.n_probe = int(fx["n_probe"])
+    idx.use_smart_probing = False
+    idx.use_packed_layout = packed
+    lut = K.AdcLutHip()(T(fx["queries_normalized"]), idx.pq_codec.codebook, "cosine")
+    np.testing.assert_allclose(N(lut), fx["ref_lut"], rtol=1e-4, atol=1e-6)
+    assert np.array_equal(N(lut), c_oracle.adc_lut(fx["queries_normalized"], N(idx.pq_codec.codebook), "cosine"))
+    xn = N(util_normalize(T(fx["queries"])))
+    for k in (1, 10):
+        v, i = idx.search(T(fx["queries"]), k=k)           # un-normalised in, as a user would call it
+        ev, ei, cells, _ = _expected_search(idx, N(util_normalize(T(fx["queries"]))), k)
+        assert np.array_equal(N(v), ev) and np.array_equal(N(i), ei)
+        same_cells = [set(a) == set(b) for a, b in zip(cells.tolist(), fx["ref_cells"].tolist())]
+        assert np.mean(same_cells) > 0.9
+        fin = np.isfinite(fx[f"orc_vals_k{k}"])
+        np.testing.assert_allclose(N(v)[fin], fx[f"orc_vals_k{k}"][fin], rtol=1e-3, atol=1e-5)
+        assert (N(i) == fx[f"orc_ids_k{k}"]).mean() > 0.95
+    assert np.allclose(xn, fx["queries_normalized"], atol=1e-6)
+    # values are cosine similarities of the PQ reconstruction: within [-1, 1] up to PQ error
+    assert float(v.max()) <= 1.05 and float(v.min()) >= -1.05
+
+
+def util_normalize(x):
+    from torchpq_amd import util
+    return util.normalize(x, dim=0)

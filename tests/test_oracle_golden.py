@@ -314,3 +314,35 @@ def test_kmeans_fit_driver_matches_reference(fx_kmeans_fit, case, numerics):
         ref_in = fx["redo_inertia" if case == "redo" else "redo_b_inertia"]
         np.testing.assert_allclose(inertias, ref_in, rtol=1e-4)
         assert int(np.argmin(inertias)) == int(np.argmin(ref_in)) == (0 if case == "redo" else 1)
+
+
+def test_cosine_index_against_reference(fx_cosine):
+    """distance="cosine" (reference-trained on CPU, make_golden.py::fx_cosine): the oracle's LUT for
+    the normalised queries equals the reference's precompute_adc (plain dot products), the scan
+    value identity sum_j LUT[j, code_j] == q . decode(code) holds for every stored slot with the
+    right-hand side from the reference's decode, and the oracle's top-k are the k largest of those
+    among the probed slots."""
+    fx = fx_cosine
+    pq = _sd(fx, "pq_codec.kmeans.centroids")
+    xq = fx["queries_normalized"]
+    for lut in (orc.adc_lut(xq, pq, "cosine"), c_oracle.adc_lut(xq, pq, "cosine")):
+        np.testing.assert_allclose(lut, fx["ref_lut"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(orc.neg_sq_l2(xq, _sd(fx, "vq_codec.kmeans.centroids")), fx["ref_sims"],
+                               rtol=1e-4, atol=1e-5)
+    storage, is_empty = _sd(fx, "_storage"), _sd(fx, "_is_empty")
+    slots = np.arange(storage.shape[1])
+    nq, n_probe = int(fx["nq"]), int(fx["n_probe"])
+    for q in range(nq):
+        v = orc.scan_values(storage, fx["ref_lut"][:, q, :], slots)
+        np.testing.assert_allclose(v, fx["ref_dot_decode"][q], rtol=1e-4, atol=1e-5)
+    cs = _sd(fx, "_cell_start")[fx["ref_cells"]]
+    sz = _sd(fx, "_cell_size")[fx["ref_cells"]]
+    npl = np.full(nq, n_probe, np.int64)
+    for k in (1, 10):
+        v, a = c_oracle.scan_topk(storage, fx["ref_lut"], is_empty, cs, sz, npl, k)
+        assert np.array_equal(v, fx[f"orc_vals_k{k}"]) and np.array_equal(a, fx[f"orc_addr_k{k}"])
+        for q in range(nq):
+            sl = orc.probed_slots(cs[q], sz[q], npl[q])
+            sl = sl[is_empty[sl] == 0]
+            exact = np.sort(fx["ref_dot_decode"][q][sl])[::-1][:k]
+            np.testing.assert_allclose(v[q][:exact.size], exact, rtol=1e-4, atol=1e-5)
