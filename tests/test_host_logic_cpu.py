@@ -13,6 +13,10 @@ def test_scan_split_heuristic():
     # with a work hint every wave keeps >= 4 tiles: 32 cells x 1024 slots = 512 tiles -> 16 splits
     assert scan._n_split(1, "cuda:0", slots_hint=32 * 1024) == 16
     assert scan._n_split(1, "cuda:0", slots_hint=100) == 1
+    short = IVFPQTopkHip(m=16)             # four 4-wave workgroups per CU (r02)
+    short.n_cus = 256
+    assert short._n_split(1024, "cuda:0") == 1 and short._n_split(512, "cuda:0") == 2
+    assert short._n_split(1, "cuda:0", slots_hint=32 * 1024) == 32   # 512 tiles / (4 waves x 4 tiles)
     big = IVFPQTopkHip(m=120)              # one 16-wave workgroup per CU
     big.n_cus = 256
     assert big._n_split(1000, "cuda:0") == 1 and big._n_split(64, "cuda:0") == 4

@@ -509,8 +509,13 @@ __device__ __forceinline__ void finalize_and_write(const ScanArgs& a, int q, con
 }
 
 // waves per workgroup: 8 while two workgroups share a CU (LUT <= 64 KiB); 16 when the LUT is so
-// large that only one workgroup fits (m > 64, e.g. GIST m=120: 120 KiB) -- same 16 waves per CU
-constexpr int packed_waves(int M) { return M <= 64 ? 8 : 16; }
+// large that only one workgroup fits (m > 64, e.g. GIST m=120: 120 KiB) -- same 16 waves per CU.
+// Short codes (m <= 32, LUT <= 32 KiB): 4 waves, FOUR workgroups per CU -- a query is then a
+// quarter of the CU's waves, so its fixed costs (launch, staging, end-of-query barrier, counting
+// rounds, refinement: ~40 % of a query's life at m=16) overlap with three other queries' streaming
+// instead of one (r02, 10 000 queries x 32 probes: m=8 0.98 -> 0.79 ms, 16 1.30 -> 1.12,
+// 24 1.63 -> 1.51, 32 1.98 -> 1.73)
+constexpr int packed_waves(int M) { return M <= 32 ? 4 : (M <= 64 ? 8 : 16); }
 // Short codes are instruction-bound, not bandwidth-bound (~61 + 3.4 m cycles per 64-slot
 // tile per CU, the 61 being table walk, address arithmetic, exec-mask handling, threshold poll and
 // ballot): a lane therefore takes S slots (64 apart) per iteration and pays that part once.

@@ -23,7 +23,10 @@ static int launch_packed(ScanArgs a, ResidualArgs ra, hipStream_t st) {
                      dim3(packed_waves(M) * 64), lds, st, a, ra, delta_rel);
   TPQ_LAUNCH_CHECK("scan_packed_kernel");
   const int n_lists = a.n_split * packed_waves(M);
-  const int W = n_lists / 2 < 8 ? n_lists / 2 : 8;  // 4 (one split, 8 waves) or 8
+  // merge waves per query: the largest power of two <= min(8, n_lists / 2) that divides n_lists
+  // (n_lists = n_split x 4 / 8 / 16 waves: 2, 4 or 8)
+  int W = 8;
+  while (W > 1 && (W > n_lists / 2 || n_lists % W != 0)) W >>= 1;
   const size_t merge_lds = (size_t)W * R * 64 * 8;
   rc = set_lds(scan_merge_refine_kernel<R, M, RES>, merge_lds, "scan_merge_refine_kernel");
   if (rc) return rc;

@@ -51,13 +51,14 @@ class IVFPQTopkHip:
         walks >= 4 tiles: a wave that sees a single tile admits all 64 slots and the merge drowns."""
         if self.n_cus is None:
             self.n_cus = torch.cuda.get_device_properties(device).multi_processor_count
-        # two 8-wave workgroups per CU while the LUT is <= 64 KiB, one 16-wave workgroup above
-        target = (2 if self.m <= 64 else 1) * self.n_cus
+        # four 4-wave workgroups per CU for short codes (m <= 32), two 8-wave ones while the LUT is
+        # <= 64 KiB, one 16-wave workgroup above (csrc/scan_device.h packed_waves)
+        target = (4 if self.m <= 32 else 2 if self.m <= 64 else 1) * self.n_cus
         if n_query >= target:
             return 1
         split = max(1, min(64, target // max(n_query, 1)))
         if slots_hint is not None:
-            waves = 8 if self.m <= 64 else 16
+            waves = 4 if self.m <= 32 else 8 if self.m <= 64 else 16
             split = max(1, min(split, int(slots_hint) // (64 * waves * 4)))
         return split
 
