@@ -528,9 +528,10 @@ constexpr int packed_tile_shift(int M) { return 6 + TPQ_SLOTS_LOG2; }
 // (r02 sweep, 10 000 queries x 32 probes, ms for S = 1 / 2 / 4: m=28 1.97 / 2.06 / 2.04,
 // m=32 2.25 / 2.05 / 1.98, m=40 2.37 / 2.44 / 2.47, m=48 2.84 / 2.65 / 4.82, m=56 3.35 / 3.21 / -,
 // m=64 3.09 / 5.84 / -: the 16-byte-chunk layouts (m % 16 == 0) gain until the second tile's
-// registers spill)
+// registers spill; with 4-wave workgroups (m <= 32): m=16 1.17 / 1.13 / 1.12, m=24 1.62 / 1.52 /
+// 1.58, m=28 1.93 / 1.81 / 1.78, m=32 2.02 / 1.82 / 1.76)
 constexpr int packed_slots(int M) {
-  return M <= 8 ? 4 : (M <= 24 ? 2 : (M == 32 ? 4 : ((M == 48 || M == 56) ? 2 : 1)));
+  return M <= 8 ? 4 : (M <= 24 ? 2 : (M <= 32 ? 4 : ((M == 48 || M == 56) ? 2 : 1)));
 }
 constexpr int packed_tile_shift(int M) { return packed_slots(M) == 4 ? 8 : (packed_slots(M) == 2 ? 7 : 6); }
 #endif
