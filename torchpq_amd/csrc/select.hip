@@ -386,31 +386,38 @@ __global__ __launch_bounds__(256, 2) void coarse_sims_kernel(const float* __rest
   }
 }
 
-// Small problems (few centroid groups x query chunks): 64-query x 256-centroid tiles, both
-// operands through LDS in double-buffered k-batches of 16 -- twice the blocks of the kernel above.
+// Small problems (few centroid groups x query chunks): 64-query x (64 CT)-centroid tiles, both
+// operands through LDS in double-buffered k-batches of 16.  CT = 4 (256 centroids per block): twice
+// the blocks of the kernel above; CT = 1 (64 centroids): eight times -- a 1000-query GIST batch
+// (d = 960, 1024 cells) is 64 blocks at CT = 4, a quarter of the chip each walking 960 dimensions,
+// and 256 at CT = 1.
 constexpr int kCsKB = 16;
 
+template <int CT>
 __global__ __launch_bounds__(256) void coarse_sims_small_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ C,
                                                          float* __restrict__ sims, int d, int nq,
                                                          int n_cells) {
+  constexpr int W = 64 * CT;  // centroids per block: 2 wave columns x CT tiles x 32
   __shared__ float As[2][kCsKB][64];
-  __shared__ float Bs[2][kCsKB][256];
+  __shared__ float Bs[2][kCsKB][W];
   __shared__ float q2s[64];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int l31 = lane & 31, half = lane >> 5;
-  const int qb = blockIdx.x * 64, cb = blockIdx.y * 256;
-  const int wq = 32 * (wave & 1), wc = 128 * (wave >> 1);
+  const int qb = blockIdx.x * 64, cb = blockIdx.y * W;
+  const int wq = 32 * (wave & 1), wc = 32 * CT * (wave >> 1);
 
-  // staging: A batch = 16 rows x 64 queries (4 elements per thread), B batch = 16 rows x 256
-  // centroids (16 per thread); a thread's elements of one row are contiguous across the wave
+  // staging: A batch = 16 rows x 64 queries (4 elements per thread), B batch = 16 rows x W
+  // centroids (4 CT per thread); a thread's elements of one row are contiguous across the wave
   const int a_col = tid & 63, a_row0 = tid >> 6;  // rows a_row0 + 4u
   const bool a_ok = qb + a_col < nq;
-  const bool b_ok = cb + tid < n_cells;
+  constexpr int BR = 256 / W;                     // B rows covered by one pass of the block (1 or 4)
+  const int b_col = tid % W, b_row0 = tid / W;    // rows b_row0 + BR u
+  const bool b_ok = cb + b_col < n_cells;
   const float* __restrict__ xa = x + (a_ok ? qb + a_col : 0);
-  const float* __restrict__ cbp = C + (b_ok ? cb + tid : 0);
-  float ra[4], rb[kCsKB];
+  const float* __restrict__ cbp = C + (b_ok ? cb + b_col : 0);
+  float ra[4], rb[kCsKB / BR];
   auto load_batch = [&](int k0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -418,8 +425,8 @@ __global__ __launch_bounds__(256) void coarse_sims_small_kernel(const float* __r
       ra[u] = (a_ok && k < d) ? xa[(int64_t)k * nq] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < kCsKB; ++u) {
-      const int k = k0 + u;
+    for (int u = 0; u < kCsKB / BR; ++u) {
+      const int k = k0 + b_row0 + BR * u;
       rb[u] = (b_ok && k < d) ? cbp[(int64_t)k * n_cells] : 0.f;
     }
   };
@@ -427,13 +434,13 @@ __global__ __launch_bounds__(256) void coarse_sims_small_kernel(const float* __r
 #pragma unroll
     for (int u = 0; u < 4; ++u) As[buf][a_row0 + 4 * u][a_col] = ra[u];
 #pragma unroll
-    for (int u = 0; u < kCsKB; ++u) Bs[buf][u][tid] = rb[u];
+    for (int u = 0; u < kCsKB / BR; ++u) Bs[buf][b_row0 + BR * u][b_col] = rb[u];
   };
 
-  f32x16 acc[4];
-  float b2[4], a2 = 0.f;
+  f32x16 acc[CT];
+  float b2[CT], a2 = 0.f;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < CT; ++t) {
     b2[t] = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(256) void coarse_sims_small_kernel(const float* __r
       const float a = As[buf][2 * kk + half][wq + l31];
       a2 = fmaf(a, a, a2);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < CT; ++t) {
         const float b = Bs[buf][2 * kk + half][wc + 32 * t + l31];
         b2[t] = fmaf(b, b, b2[t]);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
@@ -461,11 +468,11 @@ __global__ __launch_bounds__(256) void coarse_sims_small_kernel(const float* __r
   }
   a2 += __shfl_xor(a2, 32, 64);
 #pragma unroll
-  for (int t = 0; t < 4; ++t) b2[t] += __shfl_xor(b2[t], 32, 64);
+  for (int t = 0; t < CT; ++t) b2[t] += __shfl_xor(b2[t], 32, 64);
   if (wave < 2 && half == 0) q2s[32 * wave + l31] = a2;
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < CT; ++t) {
     const int c = cb + wc + 32 * t + l31;
     if (c >= n_cells) continue;
 #pragma unroll
@@ -562,9 +569,15 @@ extern "C" int tpq_ivfpq_coarse_probe(const float* query, const float* centroids
   float* gmax = sims + (size_t)nq * n_cells;
   GroupFilter gf{nullptr, 0};
   if ((long long)qgroups * chunks < 512) {
-    hipLaunchKernelGGL(coarse_sims_small_kernel, dim3((nq + 63) / 64, (n_cells + 255) / 256),
-                       dim3(256), 0, reinterpret_cast<hipStream_t>(stream), query, centroids, sims,
-                       d, nq, n_cells);
+    const long long blocks4 = (long long)((nq + 63) / 64) * ((n_cells + 255) / 256);
+    if (blocks4 < 192)  // under three quarters of the CUs: 64-centroid tiles, 4x the blocks
+      hipLaunchKernelGGL(coarse_sims_small_kernel<1>, dim3((nq + 63) / 64, (n_cells + 63) / 64),
+                         dim3(256), 0, reinterpret_cast<hipStream_t>(stream), query, centroids, sims,
+                         d, nq, n_cells);
+    else
+      hipLaunchKernelGGL(coarse_sims_small_kernel<4>, dim3((nq + 63) / 64, (n_cells + 255) / 256),
+                         dim3(256), 0, reinterpret_cast<hipStream_t>(stream), query, centroids, sims,
+                         d, nq, n_cells);
   } else {
     int per_block = (int)(((long long)qgroups * chunks) / 1024);
     per_block = per_block < 1 ? 1 : (per_block > 8 ? 8 : per_block);
