@@ -241,11 +241,15 @@ def attach_traffic(roofline, name):
         return
     try:
         pj = json.load(open(prof))
-        algo = roofline["algorithmic_bytes_per_launch"]
+        algo = roofline.get("algorithmic_bytes_per_launch")
         if pj.get("source_fingerprint") != source_fingerprint():
             roofline["traffic_note"] = f"profiles/{PROFILE_TAG}_{name}.json is from other kernel sources: not attached"
             return
-        if abs(pj["algorithmic_bytes_per_launch"] - algo) <= 0.02 * algo:
+        if algo is None:  # compute-bound kernel (flops roofline): the HBM bytes it read, as measured
+            roofline["traffic"] = round(pj["hbm_side_read_bytes_corrected"])
+            roofline["traffic_source"] = (f"profiles/{PROFILE_TAG}_{name}.json (rocprofv3 --pmc "
+                                          "FETCH_SIZE x2 x1KiB, same command, same sources)")
+        elif abs(pj["algorithmic_bytes_per_launch"] - algo) <= 0.02 * algo:
             roofline["traffic"] = round(pj["hbm_side_read_bytes_corrected"])
             roofline["traffic_source"] = (f"profiles/{PROFILE_TAG}_{name}.json (rocprofv3 --pmc "
                                           "FETCH_SIZE x2 x1KiB, same command, same sources)")
