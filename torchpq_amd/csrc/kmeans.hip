@@ -70,27 +70,33 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
   const int l31 = lane & 31, half = lane >> 5;
   const int i = blockIdx.x * 128 + wave * 32 + l31;  // this lane's point
   const bool iv = i < m;
-  const float* __restrict__ Ab = A + (int64_t)b * d * m + (iv ? i : 0);
-  const float* __restrict__ Bb = B + (int64_t)b * d * n;
+  // Every global load below is `uniform row pointer [per-lane 32-bit offset]`: the row pointer
+  // lives in SGPRs, the offset in ONE VGPR per operand, rows past d are clamped to d-1 and
+  // neutralised afterwards (no exec-mask branches).  (Round 1 formed a 64-bit per-lane address
+  // for each of the 24 loads of a slab: 48 address registers, the kernel sat at its 256-VGPR cap
+  // with two registers left for the MFMA A operands, and every pair of MFMAs waited for its own
+  // LDS round trip -- ds_read2, s_waitcnt lgkmcnt(0), 2 MFMAs, repeat: 80-86 TF/s.)
+  const float* __restrict__ Ab = A + (int64_t)b * d * m;  // uniform
+  const float* __restrict__ Bb = B + (int64_t)b * d * n;  // uniform
+  const uint32_t xoff = iv ? (uint32_t)i : 0u;            // this lane's column of A (a valid one)
+  auto a_row = [&](int k) -> const float* { return Ab + (int64_t)(k < d ? k : d - 1) * m; };
+  auto b_row = [&](int k) -> const float* { return Bb + (int64_t)(k < d ? k : d - 1) * n; };
 
   // |a|^2, one ascending-k fma chain per point; 16 loads in flight per step (a plain loop waits
   // out one memory latency per dimension)
   float a2 = 0.f;
-  if (euclidean && iv) {
-    const float* __restrict__ p = Ab;
+  if (euclidean) {
     int k = 0;
     for (; k + 16 <= d; k += 16) {
       float x[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) x[u] = p[(int64_t)u * m];
+      for (int u = 0; u < 16; ++u) x[u] = a_row(k + u)[xoff];
 #pragma unroll
       for (int u = 0; u < 16; ++u) a2 = fmaf(x[u], x[u], a2);
-      p += 16 * (int64_t)m;
     }
     for (; k < d; ++k) {
-      const float x = *p;
+      const float x = a_row(k)[xoff];
       a2 = fmaf(x, x, a2);
-      p += m;
     }
   }
 
@@ -102,27 +108,30 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
     const int nc = (n - c0) < kMsCent ? (n - c0) : kMsCent;
     const int nt = (nc + 31) >> 5;
     const bool cv = (int)threadIdx.x < nc;  // this thread's centroid column of the chunk exists
-    const float* __restrict__ Bc = Bb + c0 + (cv ? (int)threadIdx.x : 0);
+    const uint32_t coff = (uint32_t)c0 + (cv ? threadIdx.x : 0u);
     float rs[kMsKC];       // staged slab: row u, column threadIdx.x
     float xc[kMsKC / 2], xn[kMsKC / 2];
     auto load_slab = [&](int kb) {
-      const float* __restrict__ p = Bc + (int64_t)kb * n;  // one running pointer, not 16 addresses
 #pragma unroll
-      for (int u = 0; u < kMsKC; ++u) {
-        rs[u] = (cv && kb + u < d) ? *p : 0.f;
-        p += n;
-      }
+      for (int u = 0; u < kMsKC; ++u) rs[u] = b_row(kb + u)[coff];
+    };
+    // rows past d must multiply as zero: the centroid side is zeroed (uniform condition), so the
+    // point side may hold a clamped row
+    auto mask_slab = [&](int kb) {
+#pragma unroll
+      for (int u = 0; u < kMsKC; ++u) rs[u] = (kb + u < d) ? rs[u] : 0.f;
     };
     auto store_slab = [&](float* dst) {
 #pragma unroll
       for (int u = 0; u < kMsKC; ++u) dst[u * kMsCent + threadIdx.x] = rs[u];
     };
     auto load_x = [&](int kb, float (&x)[kMsKC / 2]) {
-      const float* __restrict__ p = Ab + (int64_t)(kb + half) * m;
+      // B operand [k][col=point]: this half-wave owns k = kb + 2j + half
 #pragma unroll
       for (int j = 0; j < kMsKC / 2; ++j) {
-        x[j] = (iv && kb + 2 * j + half < d) ? *p : 0.f;  // B operand [k][col=point]
-        p += 2 * (int64_t)m;
+        const float* r0 = a_row(kb + 2 * j);
+        const float* r1 = a_row(kb + 2 * j + 1);
+        x[j] = (half ? r1 : r0)[xoff];
       }
     };
     // |b|^2 of the chunk's centroids comes for free: thread t stages column t of every slab, in
@@ -135,6 +144,7 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
     load_slab(0);
     load_x(0, xc);
     __syncthreads();  // every wave finished the previous chunk (reads of cs and b2s)
+    mask_slab(0);
     square_slab();
     if (n_slabs == 1) b2s[threadIdx.x] = bsq;
     store_slab(cs);
@@ -154,14 +164,32 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
       }
       // (rows beyond the chunk's last centroid are staged as zeros and masked in the epilogue, so
       // all 8 row tiles are always multiplied: no per-MFMA predicate in the hot loop)
+      // A operands (8 centroid rows per k-step) are read from LDS one k-step AHEAD of their MFMAs
+      const float* crow0 = cur + half * kMsCent + l31;  // A operand [row=centroid][k = 2j + half]
+      float an[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) an[t] = crow0[t * 32];
 #pragma unroll
       for (int j = 0; j < kMsKC / 2; ++j) {
-        const float* crow = cur + (2 * j + half) * kMsCent + l31;  // A operand [row=centroid][k]
+        float ac[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) ac[t] = an[t];
+        if (j + 1 < kMsKC / 2) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) an[t] = crow0[(2 * (j + 1)) * kMsCent + t * 32];
+        }
 #pragma unroll
         for (int t = 0; t < 8; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(crow[t * 32], xc[j], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t], xc[j], acc[t], 0, 0, 0);
+        // order inside the k-step: the next k-step's LDS reads first, then the 8 MFMAs (left to
+        // itself the scheduler sinks the reads behind six of the MFMAs and the next k-step starts
+        // by waiting for them); the barrier keeps later k-steps' reads from being hoisted here
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // DS read
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // MFMA
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (more) {
+        mask_slab((sb + 1) * kMsKC);
         square_slab();
         if (sb + 2 == n_slabs) b2s[threadIdx.x] = bsq;  // the chain is complete
         store_slab(cs + ((sb + 1) & 1) * kMsSlab);
@@ -812,7 +840,9 @@ extern "C" int tpq_max_sim(const float* A, const float* B, float* vals, int64_t*
   // centroids resident in LDS, 256 at a time (one launch per chunk; PQ codebooks need one)
   // (beyond one chunk of centroids the double-buffered generic kernel wins from d > 64 on:
   // 1 M x 1024: d=64 84 vs 62 TF/s, d=96 47 vs 71, d=128 60 vs 78)
-  if (d <= 128 && n <= 65536 && (n <= 256 || d <= 64)) {
+  // (the codebook kernel addresses a sub-problem's data through one buffer resource with 32-bit
+  // offsets: slices of 2 GiB or more -- d * m * 4 bytes -- go to the generic kernel's 64-bit pointers)
+  if (d <= 128 && n <= 65536 && (n <= 256 || d <= 64) && (int64_t)d * m * 4 <= 0x7fffffffLL) {
     const int dh = (d + 1) / 2;
     if (dh <= 1) return launch_codebook<1>(A, B, vals, inds, l, d, m, n, euclid, st);
     if (dh <= 2) return launch_codebook<2>(A, B, vals, inds, l, d, m, n, euclid, st);
