@@ -166,3 +166,33 @@ def _oracle_fit(data, init, steps):
         data, init.copy(), 1, steps, 0.0, init.shape[2],
         assign=lambda a, b: c_oracle.max_sim(a, b, "euclidean", "expanded"))
     return cen, lab, None
+
+
+def test_kmeans_public_helpers():
+    """the reference's public helper surface on KMeans / MultiKMeans (KMeans.py:117-283): sim
+    helpers never mutate their inputs (the reference's in-place CPU forms do), kmeans++ seeding
+    returns data points, memory helpers answer"""
+    from torchpq_amd.clustering import KMeans, MultiKMeans
+    rng = np.random.default_rng(4)
+    a = T(rng.standard_normal((16, 300)).astype(np.float32))
+    b = T(rng.standard_normal((16, 20)).astype(np.float32))
+    a0, b0 = a.clone(), b.clone()
+    e = KMeans.euc_sim(a, b)
+    c = KMeans.cos_sim(a, b)
+    assert torch.equal(a, a0) and torch.equal(b, b0)
+    ref = -((N(a).T[:, None, :] - N(b).T[None, :, :]) ** 2).sum(-1)
+    np.testing.assert_allclose(N(e), ref, rtol=1e-4, atol=1e-4)
+    an, bn = N(a) / np.linalg.norm(N(a), axis=0), N(b) / np.linalg.norm(N(b), axis=0)
+    np.testing.assert_allclose(N(c), an.T @ bn, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(N(MultiKMeans.euc_sim(a[None], b[None]))[0], ref, rtol=1e-4, atol=1e-4)
+    np.random.seed(1)
+    km = KMeans(n_clusters=8, init_mode="kmeans++", max_iter=2)
+    seeds = km.kmeanspp(a)
+    assert seeds.shape == (16, 8)
+    cols = N(a).T
+    assert all(any(np.array_equal(s, col) for col in cols) for s in N(seeds).T)   # seeds are data points
+    labels = km.fit(a)
+    assert labels.shape == (300,) and km.centroids.shape == (16, 8)
+    assert KMeans.remaining_memory("cuda:0") > 0 and MultiKMeans.does_it_fit((4, 4), device="cuda:0")
+    assert not MultiKMeans.does_it_fit((1 << 40,), device="cuda:0")
+    km.warmup_kernels()

@@ -32,6 +32,25 @@ class KMeans(CustomModule):
     calculate_error = staticmethod(MultiKMeans.calculate_error)
     calculate_inertia = staticmethod(MultiKMeans.calculate_inertia)
 
+    remaining_memory = staticmethod(MultiKMeans.remaining_memory)
+    does_it_fit = staticmethod(MultiKMeans.does_it_fit)
+
+    def warmup_kernels(self):
+        self._multi.warmup_kernels()
+
+    @staticmethod
+    def cos_sim(a, b, normalize=True, inplace=False):
+        """[d, m] x [d, n] -> [m, n] (KMeans.py:155-181); never mutates its inputs"""
+        return MultiKMeans.cos_sim(a[None], b[None], normalize=normalize)[0]
+
+    @staticmethod
+    def euc_sim(a, b, inplace=False):
+        """[d, m] x [d, n] -> [m, n] negative squared L2 (KMeans.py:184-209)"""
+        return MultiKMeans.euc_sim(a[None], b[None])[0]
+
+    def kmeanspp(self, data):
+        return self._multi.kmeanspp(data[None])[0]
+
     def sim(self, a, b, inplace=False, normalize=True):
         return self._multi.sim(a[None], b[None], normalize=normalize)[0]
 

@@ -37,6 +37,31 @@ class MultiKMeans(CustomModule):
         self.max_sim_hip = MaxSimHip(dim=2, distance=distance)
         self.compute_centroids_hip = ComputeCentroidsHip()
 
+    # -- memory helpers of the reference's public surface (:117-139); nothing here chunks by them:
+    #    the assign kernel never materialises the [l, n, k] similarity tensor ----------------------
+    @staticmethod
+    def remaining_memory(device):
+        """free bytes on `device` (HBM not reserved by the caching allocator)"""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("torchpq_amd runs on an AMD GPU (torch device 'cuda')")
+        free, _ = torch.cuda.mem_get_info(device)
+        return free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+
+    @staticmethod
+    def does_it_fit(size, device="cuda:0", dtype=torch.float):
+        try:
+            torch.empty(size, device=device, dtype=dtype)
+        except Exception:
+            return False
+        return True
+
+    def warmup_kernels(self):
+        """the library is compiled ahead of time: nothing to warm up (the reference JIT-compiles
+        its CuPy kernels on first use, :225-229)"""
+        from .. import _lib
+        _lib.load()
+
     # -- similarity helpers (reference: cos_sim :155-181, euc_sim :184-209, sim :211-223) ------
     @staticmethod
     def calculate_error(a, b):
