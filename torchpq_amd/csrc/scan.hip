@@ -190,18 +190,21 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
     return dispatch_ref(a, Rr, st);
   }
   const int n_lists = n_split * packed_waves(m);
-  rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, R, n_lists), "ivfpq_scan_packed");
+  const int RL = list_regs_scan(k, packed_waves(m));  // registers of the per-wave lists (<= R)
+  a.small_lists = RL < R ? 1 : 0;
+  rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, RL, n_lists), "ivfpq_scan_packed");
   if (rc) return rc;
-  fill_ws(a, workspace, R, n_lists);
+  fill_ws(a, workspace, RL, n_lists);
 #ifdef TPQ_SCAN_PROFILE
   a.prof = g_scan_prof;
 #endif
-  if (ra) {  // residual: the scan kernel may raise a flag itself (slot covered by two probes)
+  if (ra || a.small_lists) {  // the scan kernel may raise a flag itself (residual: a slot covered by
+                              // two probes; large k: a wave's short list overflowed)
     rc = check_hip(hipMemsetAsync(a.flags, 0, (size_t)nq * 4, st), "ivfpq_scan_packed memset");
     if (rc) return rc;
   }
   switch (m) {
-#define TPQ_CASE_M(M) case M: rc = dispatch_packed_##M(a, ra, R, st); break;
+#define TPQ_CASE_M(M) case M: rc = dispatch_packed_##M(a, ra, RL, R, st); break;
     TPQ_PACKED_M_LIST(TPQ_CASE_M)
 #undef TPQ_CASE_M
     default: rc = TPQ_ERR_UNSUPPORTED; break;

@@ -32,6 +32,7 @@ struct ScanArgs {
   int64_t n_slots;
   int nq, max_nprobe, m, k, n_split;
   unsigned long long* prof;  // -DTPQ_SCAN_PROFILE builds: [nq][16] phase timestamps (10 ns ticks)
+  int small_lists;           // packed path, large k: per-wave lists hold fewer than k + 8 entries
 };
 
 #ifdef TPQ_SCAN_PROFILE
@@ -501,7 +502,7 @@ __device__ __forceinline__ void finalize_and_write(const ScanArgs& a, int q, con
   const Key klast = readlane_key(top.k[R - 1], 63);
   const bool overflow = (key_index(klast) != kPadIdx) && !(key_value(klast) < ek - delta2);
   write_final<R>(a, q, top);
-  if constexpr (RES) {  // flags were zeroed by the host; the scan may already have raised this one
+  if (RES || a.small_lists) {  // flags were zeroed by the host; the scan may already have raised this one
     if (lane_id() == 0 && overflow) a.flags[q] = 1;
   } else {
     if (lane_id() == 0) a.flags[q] = overflow ? 1 : 0;
@@ -945,6 +946,15 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
     }
     TPQ_PROF(a, blockIdx.x, 7);
     const float cut = sel.tau - delta2;
+    if (a.small_lists) {
+      // Large k: the per-wave lists hold 64R < k + 8 entries (tiles are dealt round-robin, so a
+      // wave's share of the top-k is ~k/NW; R is sized for twice that).  A wave whose list is FULL
+      // of candidates that can still matter may have evicted one that matters too: flag the query
+      // for the exact kernel.  (A list whose worst entry is below the cut lost nothing: everything
+      // it evicted was worse still.)
+      const Key kl = readlane_key(sel.top.k[R - 1], 63);
+      if (key_index(kl) != kPadIdx && key_value(kl) >= cut && lane == 0) a.flags[q] = 1;
+    }
     constexpr int RR = refine_rows(M);
     uint32_t* scratch = scratch_all + wave * RR * (M / 4 + 1);
     WaveTopK<R> ex;
@@ -1018,7 +1028,8 @@ __global__ __launch_bounds__(64) void scan_merge_kernel(ScanArgs a) {
 // wave-uniform early-exit test of insert_sorted) with the loads issued a group ahead of the
 // merges, then the W partial lists are tree-merged through LDS.  Small batches run with many
 // splits per query (512 lists at nq = 1): one wave folding them serially took 0.2 ms.
-template <int R, int M, bool RES>
+// RL = registers per dumped list (64 RL entries each), R = registers of the merged result.
+template <int RL, int R, int M, bool RES>
 __global__ __launch_bounds__(512) void scan_merge_refine_kernel(ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int q = blockIdx.x;
@@ -1029,14 +1040,14 @@ __global__ __launch_bounds__(512) void scan_merge_refine_kernel(ScanArgs a) {
   WaveTopK<R> top;
   top.init();
   const unsigned* __restrict__ bv =
-      reinterpret_cast<const unsigned*>(a.ws_vals) + (int64_t)q * n_lists * (R * 64);
+      reinterpret_cast<const unsigned*>(a.ws_vals) + (int64_t)q * n_lists * (RL * 64);
   const unsigned* __restrict__ bi =
-      reinterpret_cast<const unsigned*>(a.ws_idx) + (int64_t)q * n_lists * (R * 64);
-  const int T = n_mine * R;  // item t: rank chunk t / n_mine of my (t % n_mine)-th list
+      reinterpret_cast<const unsigned*>(a.ws_idx) + (int64_t)q * n_lists * (RL * 64);
+  const int T = n_mine * RL;  // item t: rank chunk t / n_mine of my (t % n_mine)-th list
   auto load_item = [&](int t) -> Key {
     if (t >= T) return pad_key();
     const int r = t / n_mine, l = (t - r * n_mine) * W + wave;
-    const int64_t o = (int64_t)l * (R * 64) + r * 64 + lane;
+    const int64_t o = (int64_t)l * (RL * 64) + r * 64 + lane;
     return Key{bv[o], bi[o]};
   };
   constexpr int G = 4;
@@ -1075,6 +1086,21 @@ static int pow2_ceil(int r) {
 static int list_regs(int k) { return pow2_ceil((k + 63) / 64); }  // 1, 2, 4, 8, 16
 constexpr int kBandSlack = 8;  // spare list entries the packed path wants beyond k
 static int list_regs_packed(int k) { return pow2_ceil((k + kBandSlack + 63) / 64); }
+// Registers of the per-wave lists of the packed scan.  Tiles are dealt round-robin, so a wave's share
+// of the top-k is ~k/NW: the lists are sized for at least 2k entries over the workgroup (64 RL per
+// wave) instead of k + 8 per wave.  Folding 64 candidates into a 512- or 1024-entry sorted list used
+// to dominate large k (k = 1000: 12.8 ms against 3.1 ms at k = 100, C2).  A wave that fills its list
+// with candidates that still matter flags the query for the exact kernel (scan_packed_kernel).
+#ifndef TPQ_SCAN_MIN_RL_K
+#define TPQ_SCAN_MIN_RL_K 1  // experiment knob: below this k the lists keep the full k + 8
+#endif
+static int list_regs_scan(int k, int nw) {
+  const int rp = list_regs_packed(k);
+  if (k < TPQ_SCAN_MIN_RL_K) return rp;
+  int rl = 1;
+  while (rl < rp && nw * 64 * rl < 2 * k) rl <<= 1;
+  return rl;
+}
 
 static size_t scan_lds_bytes_ref(int m, int R, int max_nprobe, int fused_floats) {
   const int lut_bytes = m * 1024;
@@ -1098,7 +1124,7 @@ static int fused_floats_of(const ScanArgs& a) { return a.lut ? 0 : a.m * a.ds + 
 #define TPQ_PACKED_M_LIST(X) \
   X(4) X(8) X(12) X(16) X(20) X(24) X(28) X(32) X(40) X(48) X(56) X(64) X(96) X(120) X(128)
 #define TPQ_DECLARE_PACKED(M) \
-  int dispatch_packed_##M(const ScanArgs& a, const ResidualArgs* ra, int R, hipStream_t st);
+  int dispatch_packed_##M(const ScanArgs& a, const ResidualArgs* ra, int RL, int R, hipStream_t st);
 TPQ_PACKED_M_LIST(TPQ_DECLARE_PACKED)
 #undef TPQ_DECLARE_PACKED
 

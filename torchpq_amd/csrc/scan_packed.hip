@@ -9,17 +9,17 @@
 
 namespace tpq {
 
-template <int R, int M, bool RES>
+template <int RL, int R, int M, bool RES>
 static int launch_packed(ScanArgs a, ResidualArgs ra, hipStream_t st) {
-  size_t lds = scan_lds_bytes_packed(M, R, a.max_nprobe, fused_floats_of(a), RES);
+  size_t lds = scan_lds_bytes_packed(M, RL, a.max_nprobe, fused_floats_of(a), RES);
 #ifdef TPQ_EXTRA_LDS  // experiment: force fewer workgroups per CU
   lds += TPQ_EXTRA_LDS;
 #endif
-  int rc = set_lds(scan_packed_kernel<R, M, RES>, lds, "scan_packed_kernel");
+  int rc = set_lds(scan_packed_kernel<RL, M, RES>, lds, "scan_packed_kernel");
   if (rc) return rc;
   // delta = 1.05 * 2 (M-1) u * sum_j max|LUT_j|,  u = 2^-24   (residual: M+1 roundings, see kernel)
   const float delta_rel = 1.05f * 2.0f * 5.9604645e-8f * (float)(RES ? M + 1 : M - 1);
-  hipLaunchKernelGGL((scan_packed_kernel<R, M, RES>), dim3((unsigned)a.nq * a.n_split),
+  hipLaunchKernelGGL((scan_packed_kernel<RL, M, RES>), dim3((unsigned)a.nq * a.n_split),
                      dim3(packed_waves(M) * 64), lds, st, a, ra, delta_rel);
   TPQ_LAUNCH_CHECK("scan_packed_kernel");
   const int n_lists = a.n_split * packed_waves(M);
@@ -28,31 +28,40 @@ static int launch_packed(ScanArgs a, ResidualArgs ra, hipStream_t st) {
   int W = 8;
   while (W > 1 && (W > n_lists / 2 || n_lists % W != 0)) W >>= 1;
   const size_t merge_lds = (size_t)W * R * 64 * 8;
-  rc = set_lds(scan_merge_refine_kernel<R, M, RES>, merge_lds, "scan_merge_refine_kernel");
+  rc = set_lds(scan_merge_refine_kernel<RL, R, M, RES>, merge_lds, "scan_merge_refine_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL((scan_merge_refine_kernel<R, M, RES>), dim3(a.nq), dim3(W * 64), merge_lds, st, a);
+  hipLaunchKernelGGL((scan_merge_refine_kernel<RL, R, M, RES>), dim3(a.nq), dim3(W * 64), merge_lds, st, a);
   TPQ_LAUNCH_CHECK("scan_merge_refine_kernel");
   return TPQ_OK;
 }
 
 template <int M, bool RES>
-static int dispatch_r(const ScanArgs& a, const ResidualArgs& ra, int R, hipStream_t st) {
-  switch (R) {
-    case 1: return launch_packed<1, M, RES>(a, ra, st);
-    case 2: return launch_packed<2, M, RES>(a, ra, st);
-    case 4: return launch_packed<4, M, RES>(a, ra, st);
-    case 8: return launch_packed<8, M, RES>(a, ra, st);
-    default: return launch_packed<16, M, RES>(a, ra, st);
+static int dispatch_r(const ScanArgs& a, const ResidualArgs& ra, int RL, int R, hipStream_t st) {
+  if (RL == R) {
+    switch (R) {
+      case 1: return launch_packed<1, 1, M, RES>(a, ra, st);
+      case 2: return launch_packed<2, 2, M, RES>(a, ra, st);
+      case 4: return launch_packed<4, 4, M, RES>(a, ra, st);
+      case 8: return launch_packed<8, 8, M, RES>(a, ra, st);
+      default: return launch_packed<16, 16, M, RES>(a, ra, st);
+    }
   }
+  // short per-wave lists (list_regs_scan): every (RL < R) pair
+#define TPQ_PAIR(A, B) if (RL == A && R == B) return launch_packed<A, B, M, RES>(a, ra, st);
+  TPQ_PAIR(1, 2) TPQ_PAIR(1, 4) TPQ_PAIR(1, 8) TPQ_PAIR(1, 16) TPQ_PAIR(2, 4) TPQ_PAIR(2, 8)
+  TPQ_PAIR(2, 16) TPQ_PAIR(4, 8) TPQ_PAIR(4, 16) TPQ_PAIR(8, 16)
+#undef TPQ_PAIR
+  set_error("scan_packed: no instantiation for list registers (%d, %d)", RL, R);
+  return TPQ_ERR_UNSUPPORTED;
 }
 
 #define TPQ_CAT2(a, b) a##b
 #define TPQ_CAT(a, b) TPQ_CAT2(a, b)
 
-int TPQ_CAT(dispatch_packed_, TPQ_PACKED_M)(const ScanArgs& a, const ResidualArgs* ra, int R,
+int TPQ_CAT(dispatch_packed_, TPQ_PACKED_M)(const ScanArgs& a, const ResidualArgs* ra, int RL, int R,
                                             hipStream_t st) {
-  if (ra) return dispatch_r<TPQ_PACKED_M, true>(a, *ra, R, st);
-  return dispatch_r<TPQ_PACKED_M, false>(a, ResidualArgs{}, R, st);
+  if (ra) return dispatch_r<TPQ_PACKED_M, true>(a, *ra, RL, R, st);
+  return dispatch_r<TPQ_PACKED_M, false>(a, ResidualArgs{}, RL, R, st);
 }
 
 }  // namespace tpq
