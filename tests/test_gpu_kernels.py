@@ -136,6 +136,40 @@ def test_scan_random_vs_oracle(K, m, k, n_probe, n_split, layout, tomb, dup):
         assert np.array_equal(N(v2), ev) and np.array_equal(N(a2), ea)
 
 
+@pytest.mark.parametrize("m,k,n_split", [(64, 256, 1), (64, 200, 2), (16, 100, 1), (32, 500, 1)])
+def test_scan_short_lists_overflow_is_redone_exactly(K, m, k, n_split):
+    """The packed scan sizes its per-wave candidate lists for 2k entries over the workgroup
+    (scan_device.h list_regs_scan), counting on the round-robin tile deal to spread the top-k.  Here
+    every one of the 1024 best vectors of query 0 sits in a 64-slot block whose tile goes to wave 0
+    (blocks 2048 slots apart: tile index = 0 mod 32 for 64-, 128- and 256-slot tiles), so wave 0's list
+    overflows with live candidates; the query must be flagged and redone by the exact kernel, and
+    the result must still be the oracle's, bit for bit.  (A library built with
+    -DTPQ_EXP_NO_OVERFLOW_FLAG fails all four cases: the flag is what makes them pass.)"""
+    rng = np.random.default_rng(m * 1000 + k)
+    n, nq = 32768, 3
+    lut = (rng.standard_normal((m, nq, 256)) * 100).astype(np.float32)
+    codes = rng.integers(0, 256, (n, m), dtype=np.uint8)
+    best = lut[:, 0, :].argmax(axis=1).astype(np.uint8)
+    top = np.nonzero((np.arange(n) // 64) % 32 == 0)[0]
+    codes[top] = best
+    for t in top:  # distinct scores: two random subvectors keep their random code
+        j = rng.choice(m, 2, replace=False)
+        codes[t, j] = rng.integers(0, 256, 2)
+    storage = np.ascontiguousarray(codes.reshape(n, m // 4, 4).transpose(1, 0, 2))
+    is_empty = np.zeros(n, np.uint8)
+    cs = np.zeros((nq, 1), np.int64)
+    sz = np.full((nq, 1), n, np.int64)
+    npl = np.ones(nq, np.int64)
+    ev, ea = c_oracle.scan_topk(storage, lut, is_empty, cs, sz, npl, k)
+    assert np.isin(ea[0], top).all()  # the construction holds: query 0's answer is inside the blocks
+    scan = K.IVFPQTopkHip(m=m)
+    st = T(storage)
+    v, a = scan.topk(st, T(lut), T(is_empty), T(cs), T(sz), T(npl), n_candidates=k,
+                     packed=K.PackCodesHip()(st), n_split=n_split)
+    assert np.array_equal(N(v), ev)
+    assert np.array_equal(N(a), ea)
+
+
 def test_scan_packed_falls_back_when_lds_is_short(K):
     """m=128 with a 700-entry probe table does not fit 160 KiB next to the 128-KiB LUT: the packed
     entry point must still answer (reference-layout kernel), bit-exactly."""

@@ -953,7 +953,9 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
       // for the exact kernel.  (A list whose worst entry is below the cut lost nothing: everything
       // it evicted was worse still.)
       const Key kl = readlane_key(sel.top.k[R - 1], 63);
+#ifndef TPQ_EXP_NO_OVERFLOW_FLAG  // knock-out for tests/test_gpu_kernels.py's adversarial case
       if (key_index(kl) != kPadIdx && key_value(kl) >= cut && lane == 0) a.flags[q] = 1;
+#endif
     }
     constexpr int RR = refine_rows(M);
     uint32_t* scratch = scratch_all + wave * RR * (M / 4 + 1);
