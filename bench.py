@@ -359,7 +359,7 @@ def secondary_c4(device, stream_peak, steps=5):
                         f"{nq} queries per GPU, search() end to end (coarse probe + fused LUT + scan)",
             "value": round(nq * steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / steps * 1e3, 4),
             "code_bytes_resident": int(idx._storage.numel()),
-            "roofline": hbm_roofline(algo, scan_ms, "scan_packed_kernel<2,64,false> + merge", stream_peak,
+            "roofline": hbm_roofline(algo, scan_ms, "scan_packed_kernel<1,64,false> + merge", stream_peak,
                                      bytes_per_query=round(algo / nq, 1))}
 
 

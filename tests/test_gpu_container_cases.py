@@ -170,3 +170,27 @@ def test_linear_get_address_by_id_without_inverse_mapping():
     assert torch.equal(lin._address2id, tab._address2id) and torch.equal(lin._storage, tab._storage)
     assert bool((lin.get_address_by_id(gone) == -1).all())
     assert lin.get_address_by_id(torch.empty(0, dtype=torch.long, device=DEV)).shape == (0,)
+
+
+def test_base_container_expand_grows_the_id_table():
+    """BaseContainer.expand (BaseContainer.py:112-127): one step of free addresses, the step doubling
+    first in "double" mode; ids already stored keep their addresses."""
+    from torchpq_amd.container.BaseContainer import BaseContainer
+
+    class Bare(BaseContainer):
+        def add(self):
+            pass
+
+        def remove(self):
+            pass
+
+    for mode, want in (("double", [16, 16 + 16, 16 + 16 + 32]), ("step", [16, 24, 32])):
+        c = Bare(device=DEV, initial_size=16, expand_step_size=8, expand_mode=mode)
+        c._address2id[:3] = torch.tensor([7, 5, 9], device=DEV)
+        sizes = [c.capacity]
+        for _ in range(2):
+            c.expand()
+            sizes.append(c.capacity)
+        assert sizes == want, (mode, sizes)
+        assert c._address2id[:3].tolist() == [7, 5, 9] and bool((c._address2id[3:] == -1).all())
+        assert c.get_id_by_address(torch.tensor([1, sizes[-1] - 1], device=DEV)).tolist() == [5, -1]

@@ -4,7 +4,7 @@
 -- the spilled registers are saved before the tile loop and restored after it; inside the loop only
 the cold list-flush branch stores one).
 
-    python tools/check_scan_isa.py [--m 64] [--r 2] [--out profiles/r02_scan_isa.json]
+    python tools/check_scan_isa.py [--m 64] [--r 1] [--out profiles/r02_scan_isa.json]
 """
 import argparse
 import json
@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--m", type=int, default=64)
-    ap.add_argument("--r", type=int, default=2)
+    ap.add_argument("--r", type=int, default=1)
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     with tempfile.TemporaryDirectory() as td:

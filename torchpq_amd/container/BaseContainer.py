@@ -102,6 +102,17 @@ class BaseContainer(CustomModule, ABC):
         self._max_id = int(a2i.max().item()) if a2i.numel() else -1
         self.device = str(a2i.device)
 
+    def expand(self):
+        """Grow the id table by one step (BaseContainer.py:112-127): `expand_step_size` doubles first
+        in "double" mode; new addresses are free (-1).  Subclasses that also own storage override it
+        (CellContainer.expand grows per cell)."""
+        if self.expand_mode == "double":
+            self.expand_step_size *= 2
+        a2i = torch.cat([self._address2id, torch.full(
+            (self.expand_step_size,), -1, device=self._address2id.device, dtype=torch.long)])
+        del self._address2id
+        self.register_buffer("_address2id", a2i)
+
     @abstractmethod
     def add(self):
         pass
