@@ -233,6 +233,19 @@ int tpq_get_id_by_address(const int64_t* address2id, int64_t capacity, const int
 int tpq_max_sim(const float* A, const float* B, float* vals, int64_t* inds, int l, int d, int m,
                 int n, int metric, tpq_stream_t stream);
 
+/* a-8 (training path)  the same (max, arg-max) on the bf16 matrix cores with fp32-level accuracy
+ * replaces the max_sim call of the Lloyd loop, torchpq/clustering/MultiKMeans.py:415-453
+ *          (get_labels :301-333 -> MaxSimCuda, kernel max_sim_tn torchpq/kernels/cuda/max_sim.cu:182-309)
+ * Every fp32 operand is split exactly into three bf16 pieces and the six piece products of order
+ * <= 4 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16: |error of a.b| <= 2^-23 sum|a_k b_k| from
+ * the dropped products plus fp32 accumulation rounding -- the accuracy class of the fp32 fma
+ * chain, but not its bits: near-ties (relative gap < ~1e-6) may pick a different index than
+ * tpq_max_sim.  Shapes: d <= 64, any n (256 centroids per pass), padded slice 16 ceil(d/16) m
+ * floats < 2 GiB (tpq_max_sim_split_supported); otherwise TPQ_ERR_UNSUPPORTED. */
+int tpq_max_sim_split_supported(int d, int64_t m, int n);
+int tpq_max_sim_split(const float* A, const float* B, float* vals, int64_t* inds, int l, int d, int m,
+                      int n, int metric, tpq_stream_t stream);
+
 /* a-9  k-means update
  * replaces ComputeCentroidsCuda.__call__  torchpq/kernels/ComputeCentroidsCuda.py:43-81
  *          kernel compute_centroids       torchpq/kernels/cuda/compute_centroids.cu:10-86

@@ -317,6 +317,83 @@ def test_max_sim_bit_exact_vs_c_oracle(K, l, d, m, n, distance):
         assert np.array_equal(N(i2), ei[0]) and np.array_equal(N(v2), ev[0])
 
 
+def _max_sim_f64(A, B, distance):
+    """float64 similarities [l, m, n] and their scale sum|a_k b_k| (+ norms): the yardstick both
+    assign kernels are held to"""
+    a, b = A.astype(np.float64), B.astype(np.float64)
+    dots = np.einsum("ldm,ldn->lmn", a, b)
+    absd = np.einsum("ldm,ldn->lmn", np.abs(a), np.abs(b))
+    if distance == "euclidean":
+        a2, b2 = (a * a).sum(1)[:, :, None], (b * b).sum(1)[:, None, :]
+        return 2 * dots - a2 - b2, 2 * absd + a2 + b2
+    return dots, absd
+
+
+@pytest.mark.parametrize("l,d,m,n,scale", [(2, 64, 3000, 256, 10.0), (1, 17, 1000, 200, 1e3),
+                                           (3, 33, 777, 300, 1e-3), (1, 12, 5000, 37, 1.0),
+                                           (1, 48, 300, 600, 10.0), (2, 64, 40, 256, 1.0),
+                                           (1, 1, 500, 9, 1.0)])
+@pytest.mark.parametrize("distance", ["euclidean", "inner"])
+def test_max_sim_split_has_fp32_accuracy(K, l, d, m, n, scale, distance):
+    """tpq_max_sim_split (exact 3-way bf16 split, six piece products on the bf16 matrix cores) is
+    held to what the fp32 kernel delivers, measured against float64: maxima within 1e-6 of the
+    scale sum|a_k b_k| (+ norms) -- the bound is 2^-23 from the dropped products plus accumulation
+    rounding -- and no worse than 4x the fp32 kernel's own worst error; the arg-max is the float64
+    arg-max or a near-tie (gap <= 2e-6 of the scale); ragged shapes: d not a multiple of 16, n not a
+    multiple of 32, n > 256 (second pass folds into the first), m below one block."""
+    rng = np.random.default_rng(l * 1000 + d * 10 + n)
+    A = (rng.standard_normal((l, d, m)) * scale).astype(np.float32)
+    B = (A[:, :, rng.integers(0, m, n)] + 0.1 * scale * rng.standard_normal((l, d, n))).astype(np.float32)
+    B[:, :, n // 2] = B[:, :, 0]  # duplicate centroid: exact tie -> smallest index
+    assert K.MaxSimHip.split_supported(d, m, n)
+    sims, mag = _max_sim_f64(A, B, distance)
+    best = sims.max(axis=2)
+    err = {}
+    for prec in ("fp32", "bf16x3"):
+        v, i = K.MaxSimHip(distance=distance, precision=prec)(T(A), T(B), dim=2, mode="tn")
+        v, i = N(v), N(i)
+        assert i.dtype == np.int64 and i.min() >= 0 and i.max() < n
+        at = np.take_along_axis(sims, i[:, :, None], 2)[:, :, 0]
+        sc = np.take_along_axis(mag, i[:, :, None], 2)[:, :, 0]
+        err[prec] = (np.abs(v - at) / sc).max()
+        assert err[prec] <= 1e-6, (prec, err[prec])
+        assert ((best - at) <= 2e-6 * sc).all(), prec
+        if prec == "bf16x3":  # the duplicate never beats its original
+            assert not (i == n // 2).any()
+            ie = N(K.MaxSimHip(distance=distance)(T(A), T(B), dim=2, mode="tn")[1])
+            assert (i == ie).mean() >= 0.999
+    assert err["bf16x3"] <= 4 * err["fp32"] + 1e-8, err
+
+
+def test_max_sim_split_is_exact_on_small_integers(K):
+    """SIFT-like data (integers 0..255) and integer centroids: every value is one bf16 piece, all
+    products and sums are exact in fp32, so the split kernel returns the oracle's bits"""
+    rng = np.random.default_rng(5)
+    A = rng.integers(0, 256, (2, 32, 2000)).astype(np.float32)
+    B = rng.integers(0, 256, (2, 32, 256)).astype(np.float32)
+    v, i = K.MaxSimHip(distance="euclidean", precision="bf16x3")(T(A), T(B), dim=2, mode="tn")
+    ev, ei = c_oracle.max_sim(A, B, "euclidean", "expanded")
+    assert np.array_equal(N(i), ei) and np.array_equal(N(v), ev)
+
+
+def test_max_sim_split_rejects_what_it_does_not_cover(K):
+    from torchpq_amd import _lib
+    lib = _lib.load()
+    assert not K.MaxSimHip.split_supported(65, 1000, 256)
+    assert not K.MaxSimHip.split_supported(64, 2 ** 24, 256)  # padded slice >= 2 GiB
+    A, B = T(np.zeros((1, 65, 8), np.float32)), T(np.zeros((1, 65, 4), np.float32))
+    v, i = torch.empty(1, 8, device=DEV), torch.empty(1, 8, device=DEV, dtype=torch.int64)
+    rc = lib.tpq_max_sim_split(_lib.ptr(A), _lib.ptr(B), _lib.ptr(v), _lib.ptr(i), 1, 65, 8, 4,
+                               _lib.METRIC_NEG_SQ_L2, _lib.stream_ptr(DEV))
+    assert rc == _lib.ERR_UNSUPPORTED and b"max_sim_split" in lib.tpq_last_error()
+    # the wrapper falls back to the fp32 kernel for such shapes
+    A = T(np.random.default_rng(0).standard_normal((1, 65, 100)).astype(np.float32))
+    B = A[:, :, :7].contiguous()
+    v1, i1 = K.MaxSimHip(precision="bf16x3")(A, B, dim=2)
+    v0, i0 = K.MaxSimHip()(A, B, dim=2)
+    assert torch.equal(v1, v0) and torch.equal(i1, i0)
+
+
 def test_max_sim_and_centroids_match_reference_golden(K, fx_kmeans):
     fx = fx_kmeans
     v, lab = K.MaxSimHip()(T(fx["data"]), T(fx["init"]), dim=2, mode="tn")

@@ -36,7 +36,7 @@ CASES = {  # name -> (init key, n_redo, max_iter, tol key or value, seed key)
 }
 
 
-def _run_gpu(fx, case, single=False):
+def _run_gpu(fx, case, single=False, precision="bf16x3"):
     from torchpq_amd.clustering import KMeans, MultiKMeans
     init_key, n_redo, max_iter, tol, seed = CASES[case]
     tol = float(fx[tol]) if isinstance(tol, str) else tol
@@ -44,10 +44,12 @@ def _run_gpu(fx, case, single=False):
     if seed is not None:
         np.random.seed(int(fx[seed]))
     if single:
-        km = KMeans(n_clusters=init.shape[2], n_redo=n_redo, max_iter=max_iter, tol=tol)
+        km = KMeans(n_clusters=init.shape[2], n_redo=n_redo, max_iter=max_iter, tol=tol,
+                    assign_precision=precision)
         labels = km.fit(T(fx["data"][0]), T(init[0]))
         return N(km.centroids)[None], N(labels)[None]
-    mk = MultiKMeans(n_clusters=init.shape[2], n_redo=n_redo, max_iter=max_iter, tol=tol)
+    mk = MultiKMeans(n_clusters=init.shape[2], n_redo=n_redo, max_iter=max_iter, tol=tol,
+                     assign_precision=precision)
     labels = mk.fit(T(fx["data"]), T(init))
     return N(mk.centroids), N(labels)
 
@@ -63,10 +65,15 @@ def _near_tie_ok(data, centroids_before_last_assign, got, exp):
     return True
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("case", list(CASES))
-def test_multikmeans_fit_vs_oracle_and_reference(fx_kmeans_fit, case):
+def test_multikmeans_fit_vs_oracle_and_reference(fx_kmeans_fit, case, precision, monkeypatch):
+    """both arithmetic modes of the Lloyd loop's assign step ("bf16x3" is the default; the fixture's
+    d = 8 lies below MultiKMeans.split_min_d, so the threshold is lowered to run the split kernel)"""
+    from torchpq_amd.clustering import MultiKMeans
+    monkeypatch.setattr(MultiKMeans, "split_min_d", 1)
     fx = fx_kmeans_fit
-    cen, labels = _run_gpu(fx, case)
+    cen, labels = _run_gpu(fx, case, precision=precision)
     init_key, n_redo, max_iter, tol, seed = CASES[case]
     tol = float(fx[tol]) if isinstance(tol, str) else tol
     if seed is not None:
@@ -137,16 +144,19 @@ def test_kmeans_single_problem_fit(fx_kmeans_fit, case):
     np.testing.assert_allclose(cen, o_cen, rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("l,d,n,k,steps", [(2, 16, 5000, 256, 3), (1, 64, 4000, 64, 2),
-                                           (4, 2, 20000, 256, 3)])
-def test_fit_random_data_vs_oracle(l, d, n, k, steps):
+                                           (4, 2, 20000, 256, 3), (2, 40, 3000, 300, 2)])
+def test_fit_random_data_vs_oracle(l, d, n, k, steps, precision):
     """Gaussian (signed, non-integer) data, codebook-sized problems (the MFMA update path):
     labels of the last assign equal the oracle's except at near-ties, centroids 1e-5"""
     from torchpq_amd.clustering import MultiKMeans
     rng = np.random.default_rng(l * 100 + d)
     data = rng.standard_normal((l, d, n)).astype(np.float32) * 3
     init = data[:, :, rng.choice(n, k, replace=False)].copy()
-    mk = MultiKMeans(n_clusters=k, max_iter=steps, tol=0.0)
+    mk = MultiKMeans(n_clusters=k, max_iter=steps, tol=0.0, assign_precision=precision)
+    used = mk._assign_kernel(d, n, k, training=True).precision
+    assert used == ("bf16x3" if precision == "bf16x3" and d >= mk.split_min_d else "fp32")
     labels = N(mk.fit(T(data), T(init)))
     cen = N(mk.centroids)
     o_cen, o_lab, _ = _oracle_fit(data, init, steps)

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("TPQ_AMD_LIB") or os.path.join(_HERE, "libtorchpq_amd.
 
 METRIC_NEG_SQ_L2 = 0
 METRIC_INNER = 1
+ERR_UNSUPPORTED = -4  # TPQ_ERR_UNSUPPORTED
 
 _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 
@@ -49,6 +50,8 @@ SIGNATURES = {
     "tpq_get_id_by_address": (_i, [_vp, _i64, _vp, _vp, _i64, _vp]),
     "tpq_get_address_by_id": (_i, [_vp, _i64, _vp, _vp, _i64, _vp]),
     "tpq_max_sim": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tpq_max_sim_split_supported": (_i, [_i, _i64, _i]),
+    "tpq_max_sim_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tpq_compute_centroids_workspace_bytes": (_sz, [_i, _i, _i]),
     "tpq_compute_centroids": (_i, [_vp, _vp, _vp, _i, _i, _i64, _i, _vp, _sz, _vp]),
     "tpq_get_ioa_workspace_bytes": (_sz, [_i64]),

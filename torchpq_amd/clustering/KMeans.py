@@ -7,14 +7,14 @@ from .MultiKMeans import MultiKMeans
 
 class KMeans(CustomModule):
     def __init__(self, n_clusters, n_redo=1, max_iter=100, tol=1e-4, distance="euclidean",
-                 init_mode="random", verbose=0, sm_size=None):
+                 init_mode="random", verbose=0, sm_size=None, assign_precision="bf16x3"):
         super().__init__()
         self.verbose = verbose
         self.register_buffer("centroids", None)
         # not a registered child: the state_dict key must stay "centroids" (KMeans.py:75)
         object.__setattr__(self, "_multi", MultiKMeans(
             n_clusters, n_redo=n_redo, max_iter=max_iter, tol=tol, distance=distance,
-            init_mode=init_mode, verbose=verbose))
+            init_mode=init_mode, verbose=verbose, assign_precision=assign_precision))
 
     # knobs live on the batched engine
     n_clusters = property(lambda s: s._multi.n_clusters)
@@ -27,6 +27,7 @@ class KMeans(CustomModule):
     max_iter = _knob("max_iter")
     n_redo = _knob("n_redo")
     tol = _knob("tol")
+    assign_precision = _knob("assign_precision")
     del _knob
 
     calculate_error = staticmethod(MultiKMeans.calculate_error)

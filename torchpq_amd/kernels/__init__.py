@@ -473,12 +473,25 @@ class SmartProbingHip:
 
 class MaxSimHip:
     """Batched arg-max similarity, mode "tn" (kernels/MaxSimCuda.py:296-340): A [l, d, m] or
-    [d, m], B [l, d, n] or [d, n] -> (vals, inds) over the n columns of B."""
+    [d, m], B [l, d, n] or [d, n] -> (vals, inds) over the n columns of B.
 
-    def __init__(self, dim=2, distance="euclidean", **_):
+    precision="fp32" (default): tpq_max_sim, ascending-k fp32 fma chains on the fp32 MFMA,
+    bit-exact against the oracle -- the encode / predict path.
+    precision="bf16x3": tpq_max_sim_split, exact 3-way bf16 split of both operands on the bf16
+    matrix cores (fp32-level accuracy, different rounding points; near-ties may resolve
+    differently) -- the Lloyd loop of MultiKMeans.fit; shapes it does not cover fall back to the
+    fp32 kernel (`split_supported`)."""
+
+    def __init__(self, dim=2, distance="euclidean", precision="fp32", **_):
         assert distance in ("euclidean", "inner", "cosine")
+        assert precision in ("fp32", "bf16x3")
         self.distance = distance
         self.dim = dim
+        self.precision = precision
+
+    @staticmethod
+    def split_supported(d, m, n):
+        return bool(load().tpq_max_sim_split_supported(int(d), int(m), int(n)))
 
     def __call__(self, A, B, dim=1, mode="tn"):
         assert mode == "tn", "only the 'tn' layout ([.., d, m] x [.., d, n]) is on the IVFPQ path"
@@ -498,9 +511,11 @@ class MaxSimHip:
         vals = torch.empty(l, m, device=A.device, dtype=torch.float32)
         inds = torch.empty(l, m, device=A.device, dtype=torch.int64)
         metric = _lib.METRIC_NEG_SQ_L2 if self.distance == "euclidean" else _lib.METRIC_INNER
+        lib = load()
+        split = self.precision == "bf16x3" and self.split_supported(d, m, n)
+        fn, name = (lib.tpq_max_sim_split, "tpq_max_sim_split") if split else (lib.tpq_max_sim, "tpq_max_sim")
         with torch.cuda.device(A.device):
-            check(load().tpq_max_sim(ptr(A), ptr(B), ptr(vals), ptr(inds), l, d, m, n, metric,
-                                     stream_ptr(A.device)), "tpq_max_sim")
+            check(fn(ptr(A), ptr(B), ptr(vals), ptr(inds), l, d, m, n, metric, stream_ptr(A.device)), name)
         if two_d:
             vals, inds = vals[0], inds[0]
         return vals, inds
