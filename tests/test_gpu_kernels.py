@@ -360,8 +360,12 @@ def test_max_sim_split_has_fp32_accuracy(K, l, d, m, n, scale, distance):
         assert ((best - at) <= 2e-6 * sc).all(), prec
         if prec == "bf16x3":  # the duplicate never beats its original
             assert not (i == n // 2).any()
+            # against the bit-exact kernel: the same labels except at float64 near-ties
             ie = N(K.MaxSimHip(distance=distance)(T(A), T(B), dim=2, mode="tn")[1])
-            assert (i == ie).mean() >= 0.999
+            ate = np.take_along_axis(sims, ie[:, :, None], 2)[:, :, 0]
+            assert (i == ie).mean() >= 0.99
+            assert (np.abs(at - ate)[i != ie] <= 4e-6 * sc[i != ie]).all(), \
+                (np.argwhere(i != ie), (np.abs(at - ate) / sc)[i != ie])
     assert err["bf16x3"] <= 4 * err["fp32"] + 1e-8, err
 
 

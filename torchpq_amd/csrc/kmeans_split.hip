@@ -60,6 +60,18 @@ __device__ __forceinline__ void take(float& best, int& besti, float val) {
                : "vcc");
 }
 
+// two values in one block (separate asm statements get a wait state between them)
+template <int CL0, int CL1>
+__device__ __forceinline__ void take2(float& best, int& besti, float v0, float v1) {
+  static_assert(CL0 >= 0 && CL0 <= 64 && CL1 >= 0 && CL1 <= 64, "inline constants");
+  asm volatile(
+      "v_cmp_ngt_f32 vcc, %2, %0\n\tv_cndmask_b32 %0, %2, %0, vcc\n\tv_cndmask_b32 %1, %4, %1, vcc\n\t"
+      "v_cmp_ngt_f32 vcc, %3, %0\n\tv_cndmask_b32 %0, %3, %0, vcc\n\tv_cndmask_b32 %1, %5, %1, vcc"
+      : "+v"(best), "+v"(besti)
+      : "v"(v0), "v"(v1), "n"(CL0), "n"(CL1)
+      : "vcc");
+}
+
 // x -> (x1, x2, x3), exact: x == x1 + x2 + x3
 __device__ __forceinline__ void split3(float x, __bf16& p1, __bf16& p2, __bf16& p3) {
   p1 = (__bf16)x;
@@ -75,7 +87,7 @@ __device__ __forceinline__ void split3(float x, __bf16& p1, __bf16& p2, __bf16& 
 constexpr int kSpTiles = TPQ_SP_TILES;  // 32-point tiles per wave (a block covers 8 x 32 x kSpTiles points)
 constexpr int kSpWaves = 8;
 #ifndef TPQ_SP_EXP
-#define TPQ_SP_EXP 0  // knock-outs (tools/build_variant.sh): 1 arg-max -> max, 2 no in-loop split, 4 no loads
+#define TPQ_SP_EXP 0  // knock-outs (tools/build_variant.sh): 2 no in-loop split, 4 no loads
 #endif
 
 constexpr size_t split_lds_bytes(int KS) { return (size_t)(8 * KS * 3 + 8) * 64 * 16; }
@@ -241,7 +253,8 @@ __global__ __launch_bounds__(kSpWaves * 64, 2) void max_sim_split_kernel(
   constexpr int NM = KS * 6;  // MFMAs per unit
   // unit U of the current tile into `acc`; `fin` = accumulator of the unit before it, whose 16
   // values go through the arg-max between this unit's MFMAs (from the second MFMA on)
-  auto unit = [&](auto u_c, f32x16& acc, const f32x16& fin, int& voff_next) {
+  auto unit = [&](auto u_c, f32x16& acc, const f32x16& fin, int& voff_next, const bf16x8 (&xs)[KS][3],
+                  bf16x8 (&xsn)[KS][3], float& a2n) {
     constexpr int U = decltype(u_c)::value, FU = (U + 7) & 7;
     const float best_before = best;
     {
@@ -263,7 +276,9 @@ __global__ __launch_bounds__(kSpWaves * 64, 2) void max_sim_split_kernel(
       static_for<0, 6>([&](auto t_c) {
         constexpr int t = decltype(t_c)::value;
         constexpr int mi = s * 6 + t;  // MFMA index within the unit
-        // smallest products first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1
+        // smallest products first: a3b1, a1b3, a2b2, a2b1, a1b2, a1b1 -- one chain per unit: the second
+        // wave of the SIMD fills the matrix pipe between dependent MFMAs (two chains per unit, even / odd
+        // MFMAs, measured slower: 10.2 vs 9.8 ms at C5)
         const bf16x8 aop = t == 0 ? a3 : (t == 1 || t >= 4) ? a1 : a2p;
         const bf16x8 bop = t == 0 ? xs[s][0] : t == 1 ? xs[s][2] : t == 2 ? xs[s][1] : t == 3 ? xs[s][0]
                                                                                     : t == 4 ? xs[s][1] : xs[s][0];
@@ -272,14 +287,15 @@ __global__ __launch_bounds__(kSpWaves * 64, 2) void max_sim_split_kernel(
         // last MFMA when the unit is too short)
         if constexpr (NM > 2 && mi >= 2) {
           constexpr int lo = ((mi - 2) * 16) / (NM - 2), hi = ((mi - 1) * 16) / (NM - 2);
-          static_for<lo, hi>([&](auto r_c) {
-            constexpr int r = decltype(r_c)::value;
-            if (TPQ_SP_EXP & 1) {
-              asm volatile("v_max_f32 %0, %0, %1" : "+v"(best) : "v"(fin[r]));
-            } else {
-              take<(r & 3) + 8 * (r >> 2)>(best, besti, fin[r]);
-            }
+          constexpr int np = (hi - lo) / 2;
+          static_for<0, np>([&](auto q_c) {
+            constexpr int r = lo + 2 * decltype(q_c)::value;
+            take2<(r & 3) + 8 * (r >> 2), ((r + 1) & 3) + 8 * ((r + 1) >> 2)>(best, besti, fin[r], fin[r + 1]);
           });
+          if constexpr ((hi - lo) & 1) {
+            constexpr int r = hi - 1;
+            take<(r & 3) + 8 * (r >> 2)>(best, besti, fin[r]);
+          }
         }
         // next tile's raw fragment: 2 KS loads per unit under units 0..3
         if constexpr (U < 4) {
@@ -292,6 +308,8 @@ __global__ __launch_bounds__(kSpWaves * 64, 2) void max_sim_split_kernel(
           });
         }
         // ... and split under units 4..7 (k-step U - 4): 8 elements over the unit's MFMA gaps
+        // (spreading load + split evenly over all 8 units, loads one tile further ahead, measured
+        // slower: 9.9 vs 9.55 ms at C5 -- 256 registers instead of 230)
         if constexpr (U >= 4 && U - 4 < KS) {
           constexpr int j0 = (mi * 8) / NM, j1 = ((mi + 1) * 8) / NM;
           if (!(TPQ_SP_EXP & 2))
@@ -305,35 +323,37 @@ __global__ __launch_bounds__(kSpWaves * 64, 2) void max_sim_split_kernel(
   using std::integral_constant;
 
   bool have_prev = false;
-#pragma unroll 1
-  for (int t = 0; t < kSpTiles; ++t) {
-    if ((blockIdx.x * kSpTiles + t) * (kSpWaves * 32) >= m) break;
+  // one tile: `cur` holds its B operands, `nxt` receives the next tile's (the two buffers swap
+  // roles from tile to tile: the loop below is unrolled by two instead of copying 12 KS registers)
+  auto tile = [&](int t, const bf16x8 (&cur)[KS][3], bf16x8 (&nxt)[KS][3], float a2cur, float& a2nxt) {
     int voff_next = frag_offset(t + 1, ivn, in_);
-    a2n = 0.f;
+    a2nxt = 0.f;
     // unit 0 carries the arg-max of the LAST unit of tile t-1 (accB = -inf before the first tile)
-    unit(integral_constant<int, 0>{}, accA, accB, voff_next);
+    unit(integral_constant<int, 0>{}, accA, accB, voff_next, cur, nxt, a2nxt);
     if (have_prev) finish_tile(iv_prev, i_prev, a2_prev);
     best = -INFINITY;
     besti = 0;
     bestu = 0;
-    unit(integral_constant<int, 1>{}, accB, accA, voff_next);
-    unit(integral_constant<int, 2>{}, accA, accB, voff_next);
-    unit(integral_constant<int, 3>{}, accB, accA, voff_next);
-    unit(integral_constant<int, 4>{}, accA, accB, voff_next);
-    unit(integral_constant<int, 5>{}, accB, accA, voff_next);
-    unit(integral_constant<int, 6>{}, accA, accB, voff_next);
-    unit(integral_constant<int, 7>{}, accB, accA, voff_next);
-    a2_prev = a2;
+    unit(integral_constant<int, 1>{}, accB, accA, voff_next, cur, nxt, a2nxt);
+    unit(integral_constant<int, 2>{}, accA, accB, voff_next, cur, nxt, a2nxt);
+    unit(integral_constant<int, 3>{}, accB, accA, voff_next, cur, nxt, a2nxt);
+    unit(integral_constant<int, 4>{}, accA, accB, voff_next, cur, nxt, a2nxt);
+    unit(integral_constant<int, 5>{}, accB, accA, voff_next, cur, nxt, a2nxt);
+    unit(integral_constant<int, 6>{}, accA, accB, voff_next, cur, nxt, a2nxt);
+    unit(integral_constant<int, 7>{}, accB, accA, voff_next, cur, nxt, a2nxt);
+    a2_prev = a2cur;
     iv_prev = iv;
     i_prev = i;
     have_prev = true;
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) xs[s][p] = xsn[s][p];
-    a2 = a2n;
     iv = ivn;
     i = in_;
+  };
+#pragma unroll 1
+  for (int t = 0; t < kSpTiles; t += 2) {
+    if ((blockIdx.x * kSpTiles + t) * (kSpWaves * 32) >= m) break;
+    tile(t, xs, xsn, a2, a2n);
+    if (t + 1 >= kSpTiles || (blockIdx.x * kSpTiles + t + 1) * (kSpWaves * 32) >= m) break;
+    tile(t + 1, xsn, xs, a2n, a2);
   }
   if (have_prev) {  // arg-max of the last unit of the last tile
     const float best_before = best;
