@@ -194,3 +194,52 @@ def test_base_container_expand_grows_the_id_table():
         assert sizes == want, (mode, sizes)
         assert c._address2id[:3].tolist() == [7, 5, 9] and bool((c._address2id[3:] == -1).all())
         assert c.get_id_by_address(torch.tensor([1, sizes[-1] - 1], device=DEV)).tolist() == [5, -1]
+
+
+def test_growth_arenas_keep_the_layout_and_exact_state_dict():
+    """Large containers grow inside two geometrically sized arenas that swap roles (CellContainer._grow):
+    the layout after a sequence of adds equals the one a fresh-allocation container produces, buffers
+    are contiguous prefixes of the arenas, few allocations happen, and state_dict() hands out
+    exact-size tensors."""
+    from torchpq_amd.container import CellContainer
+
+    def build(arena_min_bytes):
+        torch.manual_seed(3)
+        c = CellContainer(code_size=CODE_SIZE, n_cells=N_CELLS, dtype="uint8", device=DEV, initial_size=8,
+                          expand_step_size=8, expand_mode="step", use_inverse_id_mapping=True,
+                          contiguous_size=4)  # "step": every add below grows the storage by ~2 %
+        c.arena_min_bytes = arena_min_bytes
+        allocs, grows = set(), 0
+        for step in range(40):  # one large add, then many small ones: frequent growth by a few %
+            n = 60000 if step == 0 else 1500
+            cap = c.capacity
+            c.add(torch.randint(0, 256, (CODE_SIZE, n), device=DEV, dtype=torch.uint8),
+                  torch.randint(N_CELLS, (n,), device=DEV))
+            grows += int(c.capacity != cap)
+            allocs.add(c._storage.untyped_storage().data_ptr())
+        return c, (allocs, grows)
+
+    plain, plain_allocs = build(1 << 60)
+    arena, arena_allocs = build(0)
+    for name in ("_storage", "_address2id", "_is_empty", "_cell_start", "_cell_size", "_cell_capacity"):
+        assert torch.equal(getattr(plain, name), getattr(arena, name)), name
+    assert arena._storage.is_contiguous() and arena._storage.shape == plain._storage.shape
+    assert arena._storage.untyped_storage().nbytes() >= arena._storage.numel()
+    ptrs, grows = arena_allocs
+    assert grows >= 10 and len(ptrs) <= grows // 2, (grows, len(ptrs))  # growth re-uses the two arenas
+    sd = arena.state_dict()
+    for name in ("_storage", "_address2id", "_is_empty"):
+        t = sd[name]
+        assert t.untyped_storage().nbytes() == t.numel() * t.element_size(), name
+        assert torch.equal(t, getattr(plain, name))
+    # the spare side can be dropped and growth still works
+    arena.release_spare()
+    n = 40000
+    data = torch.randint(0, 256, (CODE_SIZE, n), device=DEV, dtype=torch.uint8)
+    cells = torch.randint(N_CELLS, (n,), device=DEV)
+    arena.add(data, cells)
+    plain.add(data, cells)
+    assert torch.equal(plain._storage, arena._storage) and torch.equal(plain._address2id, arena._address2id)
+    # load_state_dict detaches the container from its arenas
+    arena.load_state_dict(plain.state_dict())
+    assert arena._arena == {}

@@ -652,14 +652,23 @@ class GrowCellsHip:
     its place in the larger layout, new tails initialised free.  Returns the three new buffers."""
 
     def __call__(self, storage, address2id, is_empty, old_start, old_capacity, new_start, new_capacity,
-                 new_slots):
+                 new_slots, out=None):
+        """out = (storage, address2id, is_empty) buffers of the new size to fill (must not alias the
+        inputs), or None to allocate them"""
         g, old_slots, cs = storage.shape
         assert cs == 4 and storage.dtype == torch.uint8
         require_gpu(storage, address2id, is_empty, old_start, old_capacity, new_start, new_capacity)
         dev = storage.device
-        new_storage = torch.empty(g, new_slots, 4, device=dev, dtype=torch.uint8)
-        new_a2i = torch.empty(new_slots, device=dev, dtype=torch.int64)
-        new_empty = torch.empty(new_slots, device=dev, dtype=torch.uint8)
+        if out is None:
+            new_storage = torch.empty(g, new_slots, 4, device=dev, dtype=torch.uint8)
+            new_a2i = torch.empty(new_slots, device=dev, dtype=torch.int64)
+            new_empty = torch.empty(new_slots, device=dev, dtype=torch.uint8)
+        else:
+            new_storage, new_a2i, new_empty = out
+            assert new_storage.shape == (g, new_slots, 4) and new_storage.is_contiguous()
+            assert new_a2i.shape == (new_slots,) and new_empty.shape == (new_slots,)
+            assert new_storage.dtype == torch.uint8 and new_a2i.dtype == torch.int64 and new_empty.dtype == torch.uint8
+            assert new_storage.data_ptr() != storage.data_ptr() and new_a2i.data_ptr() != address2id.data_ptr()
         with torch.cuda.device(dev):
             check(load().tpq_grow_cells(ptr(storage), ptr(address2id), ptr(is_empty), ptr(old_start),
                                         ptr(old_capacity), ptr(new_start), ptr(new_capacity),
