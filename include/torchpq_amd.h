@@ -246,6 +246,24 @@ int tpq_max_sim_split_supported(int d, int64_t m, int n);
 int tpq_max_sim_split(const float* A, const float* B, float* vals, int64_t* inds, int l, int d, int m,
                       int n, int metric, tpq_stream_t stream);
 
+/* a-8 / a-11 (encode path)  the labels of tpq_max_sim, bit for bit, at bf16-matrix-core speed
+ * replaces the max_sim call behind VQCodec.encode / IVFPQIndex.add (coarse assign):
+ *          torchpq/index/IVFPQIndex.py:233-256 -> clustering/KMeans.py:440-452 (predict)
+ *          -> kernels/MaxSimCuda.py:296-340, kernel max_sim_tn torchpq/kernels/cuda/max_sim.cu:182-309
+ * A f32 [d][m] points, B f32 [d][n] centroids (one problem) -> inds i64 [m] = arg-max over the
+ * centroids of the oracle's fp32 arithmetic (ascending-k fmaf chains; ties -> smallest index).
+ * An error-bounded top-2 selection on split-bf16 MFMAs decides every point whose two best fast
+ * values differ by more than twice the bound; the others are re-evaluated exactly on the device.
+ * Shapes: d <= 128, m < 2^31, padded slice 16 ceil(d/16) m floats < 2 GiB; otherwise
+ * TPQ_ERR_UNSUPPORTED (use tpq_max_sim).  workspace: tpq_coarse_assign_workspace_bytes(d, m, n). */
+int tpq_coarse_assign_supported(int d, int64_t m, int n);
+size_t tpq_coarse_assign_workspace_bytes(int d, int64_t m, int n);
+/* diagnostics: byte offset inside the workspace of the int32 count of points the last call
+ * re-checked exactly */
+size_t tpq_coarse_assign_count_offset(int d, int64_t m, int n);
+int tpq_coarse_assign(const float* A, const float* B, int64_t* inds, int d, int64_t m, int n, int metric,
+                      void* workspace, size_t workspace_bytes, tpq_stream_t stream);
+
 /* a-9  k-means update
  * replaces ComputeCentroidsCuda.__call__  torchpq/kernels/ComputeCentroidsCuda.py:43-81
  *          kernel compute_centroids       torchpq/kernels/cuda/compute_centroids.cu:10-86

@@ -546,3 +546,31 @@ def test_cosine_index_on_reference_trained_state_dict(fx_cosine, packed):
 def util_normalize(x):
     from torchpq_amd import util
     return util.normalize(x, dim=0)
+
+
+def test_add_uses_the_fast_coarse_assign_and_cells_stay_exact(monkeypatch):
+    """IVFPQIndex.add -> VQCodec.encode -> KMeans.predict runs tpq_coarse_assign from
+    KMeans.fast_predict_min_work on (lowered here so a small index takes it): cells equal the
+    oracle's fp32 arg-max, bit for bit, and equal what the fp32 kernel path produces."""
+    from torchpq_amd import kernels as K
+    from torchpq_amd.clustering import KMeans
+    from torchpq_amd.index import IVFPQIndex
+    calls = []
+    orig = K.CoarseAssignHip.__call__
+    monkeypatch.setattr(K.CoarseAssignHip, "__call__", lambda self, A, B: (calls.append(A.shape), orig(self, A, B))[1])
+    rng = np.random.default_rng(11)
+    d, n = 64, 30000
+    centers = rng.standard_normal((d, 300)) * 4
+    base = (centers[:, rng.integers(0, 300, n)] + rng.standard_normal((d, n))).astype(np.float32)
+    np.random.seed(1)
+    idx = IVFPQIndex(d_vector=d, n_subvectors=16, n_cells=256, initial_size=64, device=DEV)
+    idx.train(T(base))
+    monkeypatch.setattr(KMeans, "fast_predict_min_work", 1 << 60)
+    slow = N(idx.vq_codec.encode(T(base)))
+    assert not calls
+    monkeypatch.setattr(KMeans, "fast_predict_min_work", 0)
+    ids, adr = idx.add(T(base), return_address=True)
+    assert calls and calls[0] == (d, n)
+    cells = N(idx.get_cell_by_address(adr))
+    _, cells_or = c_oracle.max_sim(base[None], N(idx.vq_codec.codebook)[None], "euclidean", "expanded")
+    assert np.array_equal(cells, cells_or[0]) and np.array_equal(cells, slow)

@@ -700,3 +700,75 @@ def test_code_layout_scatter_gather_matches_reference(K, fx_layout):
         c.set_data_by_address(T(fx[f"l{case}_codes"]), T(fx[f"l{case}_adr"]))
         assert np.array_equal(N(c._storage), ref_storage)
         assert np.array_equal(N(c.get_data_by_address(T(fx[f"l{case}_probe"]))), fx[f"l{case}_ref_gather"])
+
+
+# ---------------------------------------------------------------------------------------------
+# coarse assign: error-bounded selection on the bf16 matrix cores + exact re-check
+# ---------------------------------------------------------------------------------------------
+def _coarse_case(rng, d, m, n, kind):
+    if kind == "gauss":
+        A = (rng.standard_normal((d, m)) * 10).astype(np.float32)
+        B = (rng.standard_normal((d, n)) * 10).astype(np.float32)
+    elif kind == "sift":  # non-negative integers, centroids near data points
+        A = rng.integers(0, 200, (d, m)).astype(np.float32)
+        B = (A[:, rng.integers(0, m, n)] + rng.integers(-3, 4, (d, n))).astype(np.float32)
+    elif kind == "crowded":  # every centroid within a few ulps of the same vector: all points ambiguous
+        A = (rng.standard_normal((d, m)) * 10).astype(np.float32)
+        c0 = (rng.standard_normal((d, 1)) * 10).astype(np.float32)
+        B = np.nextafter(np.repeat(c0, n, 1), np.float32(np.inf) * rng.choice([-1, 1], (d, n))).astype(np.float32)
+        B[:, ::3] = c0  # and exact duplicates: ties -> smallest index
+    else:  # "ties": duplicated centroids, points sitting on centroids
+        B = (rng.standard_normal((d, n)) * 5).astype(np.float32)
+        B[:, n // 2:] = B[:, :n - n // 2]
+        A = B[:, rng.integers(0, n, m)].copy()
+        A[:, ::2] += (rng.standard_normal((d, (m + 1) // 2)) * 0.01).astype(np.float32)
+    return np.ascontiguousarray(A), np.ascontiguousarray(B)
+
+
+@pytest.mark.parametrize("d,m,n,kind", [(128, 3000, 1024, "sift"), (128, 1111, 300, "gauss"),
+                                        (100, 2000, 129, "gauss"), (17, 5000, 64, "sift"),
+                                        (64, 700, 2049, "ties"), (128, 600, 500, "crowded"),
+                                        (33, 513, 31, "ties"), (96, 40, 4000, "gauss"),
+                                        (1, 300, 5, "gauss")])
+@pytest.mark.parametrize("distance", ["euclidean", "inner"])
+def test_coarse_assign_labels_equal_the_exact_kernel_and_the_oracle(K, d, m, n, kind, distance):
+    """tpq_coarse_assign decides on a split-bf16 top-2 with a rigorous error bound and re-checks the
+    ambiguous points with the fp32 kernel: its labels are the oracle's, bit for bit -- on ragged
+    shapes (d not a multiple of 16, n not a multiple of 128, m below a block), exact ties
+    (duplicated centroids -> smallest index), points sitting on centroids, and a codebook whose
+    entries differ by single ulps (every point ambiguous: the answer comes from the re-check)."""
+    rng = np.random.default_rng(d * 1000 + n)
+    A, B = _coarse_case(rng, d, m, n, kind)
+    assert K.CoarseAssignHip.supported(d, m, n)
+    op = K.CoarseAssignHip(distance=distance)
+    got = N(op(T(A), T(B)))
+    _, want = c_oracle.max_sim(A[None], B[None], distance, "expanded")
+    assert got.dtype == np.int64 and np.array_equal(got, want[0])
+    share = op.last_rechecked() / m
+    if kind == "crowded":
+        assert share == 1.0   # nothing can be decided by the fast values
+    elif kind == "gauss" and d >= 64 and distance == "euclidean":
+        assert share < 0.5    # ... and normally most points are
+
+
+def test_coarse_assign_argument_errors(K):
+    from torchpq_amd import _lib
+    lib = _lib.load()
+    assert not K.CoarseAssignHip.supported(129, 1000, 256)
+    A, B = T(np.zeros((129, 8), np.float32)), T(np.zeros((129, 4), np.float32))
+    out = torch.empty(8, device=DEV, dtype=torch.int64)
+    ws = torch.empty(1 << 20, device=DEV, dtype=torch.uint8)
+    rc = lib.tpq_coarse_assign(_lib.ptr(A), _lib.ptr(B), _lib.ptr(out), 129, 8, 4, _lib.METRIC_NEG_SQ_L2,
+                               _lib.ptr(ws), ws.numel(), _lib.stream_ptr(DEV))
+    assert rc == _lib.ERR_UNSUPPORTED and b"coarse_assign" in lib.tpq_last_error()
+    A, B = T(np.zeros((64, 800), np.float32)), T(np.zeros((64, 400), np.float32))
+    need = lib.tpq_coarse_assign_workspace_bytes(64, 800, 400)
+    assert need > 0
+    out = torch.empty(800, device=DEV, dtype=torch.int64)
+    rc = lib.tpq_coarse_assign(_lib.ptr(A), _lib.ptr(B), _lib.ptr(out), 64, 800, 400, _lib.METRIC_NEG_SQ_L2,
+                               _lib.ptr(ws), need - 1, _lib.stream_ptr(DEV))
+    assert rc == -1 and b"workspace" in lib.tpq_last_error()
+    # all-zero data: every centroid ties -> index 0
+    rc = lib.tpq_coarse_assign(_lib.ptr(A), _lib.ptr(B), _lib.ptr(out), 64, 800, 400, _lib.METRIC_NEG_SQ_L2,
+                               _lib.ptr(ws), ws.numel(), _lib.stream_ptr(DEV))
+    assert rc == 0 and int(out.abs().max()) == 0

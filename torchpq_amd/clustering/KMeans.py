@@ -2,6 +2,7 @@
 MultiKMeans with 2-D tensors (data [d, n], centroids [d, n_clusters])."""
 
 from ..CustomModule import CustomModule
+from ..kernels import CoarseAssignHip
 from .MultiKMeans import MultiKMeans
 
 
@@ -72,8 +73,19 @@ class KMeans(CustomModule):
         self.register_buffer("centroids", self._multi.centroids[0].contiguous())
         return labels[0]
 
+    # predict() = the coarse assign of IVFPQIndex.add: from this much work on (points x centroids x
+    # dimensions) it runs tpq_coarse_assign -- error-bounded top-2 selection on the bf16 matrix
+    # cores + exact re-check, the SAME labels as the fp32 kernel, 3-4x faster -- below it the three
+    # launches cost more than they save
+    fast_predict_min_work = 1 << 27
+
     def predict(self, query):
         assert self.centroids is not None, "kmeans is not trained"
+        d, m = query.shape
+        n = self.centroids.shape[1]
+        if (self.distance in ("euclidean", "inner") and m * n * d >= self.fast_predict_min_work
+                and n >= 64 and CoarseAssignHip.supported(d, m, n)):
+            return CoarseAssignHip(distance=self.distance)(query, self.centroids)
         return self.get_labels(query, self.centroids)[1]
 
     def topk(self, query, k=128):

@@ -1,0 +1,421 @@
+// Bit-exact coarse assign (labels only) at bf16-matrix-core speed: error-bounded selection on a
+// split-bf16 MFMA kernel + exact re-check of the ambiguous points.
+//
+// tpq_coarse_assign returns, for every point, the SAME label tpq_max_sim returns (the arg-max of the
+// oracle's fp32 arithmetic: ascending-k fmaf chains, (2 acc - |a|^2) - |c|^2, ties -> smallest
+// index) -- it replaces the max_sim call behind VQCodec.encode / IVFPQIndex.add
+// (torchpq/index/IVFPQIndex.py:233-256 -> codec/VQCodec.py -> clustering/KMeans.py:440-452 ->
+// kernels/MaxSimCuda.py:296-340, kernel max_sim_tn torchpq/kernels/cuda/max_sim.cu:182-309), which
+// is 90 % of an add() at 16 384 cells.  The same idea as the list scan: a FAST value f
+// with a rigorous bound |f - g| <= delta on its distance from the real-number value g selects, the
+// exact arithmetic decides only where the selection cannot:
+//   1. assign_prep_kernel: the centroids, doubled (exact), split into NP bf16 pieces (NP = 2:
+//      c = c1 + c2 + r, |r| <= 2^-18 |c|) and laid out in MFMA-fragment order, 32 centroids per unit,
+//      plus -|c|^2 as an exact 3-piece fragment and max |c|^2;
+//   2. assign_fast_kernel: every wave keeps 32 CT points (split the same way) in registers for the
+//      whole sweep and streams ALL centroid units through a double-buffered LDS ring filled by
+//      global_load_lds (LDS-DMA: no staging registers); per 16 dimensions and 32 x 32 tile the
+//      products c2 a1, c1 a2, c1 a1 (NP = 2) go through v_mfma_f32_32x32x16_bf16; the epilogue keeps
+//      the best AND the second-best fast value per point (5 VALU per value);
+//      delta = 1.25 (eps_prod + (terms + 8) 2^-23) (|a| + |c|max)^2 covers the dropped products
+//      (3 x 2^-18 |a_k c_k| per term at NP = 2), a worst-case (truncating) fp32 accumulation of all
+//      MFMA terms, and the rounding of the exact chain itself.  A point whose two best fast values
+//      are further apart than 2 delta has its label decided: any other centroid is worse in
+//      the exact arithmetic too.  The rest (a few per cent at d = 128) are appended to a list;
+//   3. the bit-exact fp32-MFMA kernel (max_sim_kernel, kmeans.hip) over the listed points only: it
+//      reads the list and its length from device memory (no host round trip; the grid covers the
+//      worst case and surplus blocks leave at once).
+#include <type_traits>
+
+#include "common.h"
+
+namespace tpq {
+int launch_max_sim_list(const float* A, const float* B, int64_t* inds, int d, int m, int n, int euclid,
+                        const int* list, const int* count, hipStream_t st);  // kmeans.hip
+namespace afast {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I0 < I1) {
+    f(std::integral_constant<int, I0>{});
+    static_for<I0 + 1, I1>(f);
+  }
+}
+
+__device__ __forceinline__ void split3(float x, __bf16& p1, __bf16& p2, __bf16& p3) {
+  p1 = (__bf16)x;
+  const float r1 = x - (float)p1;
+  p2 = (__bf16)r1;
+  const float r2 = r1 - (float)p2;
+  p3 = (__bf16)r2;
+}
+
+// top-2 of fast values: (b1, b2, bi) <- v with in-unit index CL (inline constant).  A tie with b1
+// keeps the earlier index and makes b2 == b1: the point is then ambiguous by construction.
+template <int CL>
+__device__ __forceinline__ void take_top2(float& b1, float& b2, int& bi, float v) {
+  static_assert(CL >= 0 && CL <= 64, "inline constant");
+  float t;
+  asm volatile(
+      "v_cmp_ngt_f32 vcc, %4, %0\n\t"
+      "v_cndmask_b32 %2, %5, %2, vcc\n\t"
+      "v_min_f32 %3, %4, %0\n\t"
+      "v_max_f32 %0, %4, %0\n\t"
+      "v_max_f32 %1, %1, %3"
+      : "+v"(b1), "+v"(b2), "+v"(bi), "=&v"(t)
+      : "v"(v), "n"(CL)
+      : "vcc");
+}
+
+constexpr int kUnitsPerChunk = 4;  // 128 centroids per LDS buffer
+constexpr int kWaves = 8;
+constexpr int frags_per_unit(int KS, int NP) { return KS * NP + 1; }  // + the -|c|^2 fragment
+constexpr size_t chunk_bytes(int KS, int NP) { return (size_t)kUnitsPerChunk * frags_per_unit(KS, NP) * 1024; }
+constexpr int n_products(int NP) { return NP == 2 ? 3 : 6; }
+
+// ---- 1. centroid fragments -------------------------------------------------------------------
+// grid = units (32 centroids each), block = 64 lanes: lane (row = lane % 32, k-group = lane / 32)
+// holds 8 consecutive dimensions of its centroid per k-step, as the MFMA A operand wants them.
+// frags: [unit][1 + KS * NP][64 lanes] x 16 B, fragment 0 = -|c|^2 (euclidean) or 0 (inner) as three
+// exact pieces at k = 0, 1, 2; rows beyond n carry -3e38 there: they can never be first or second.
+template <int KS, int NP>
+__global__ __launch_bounds__(64) void assign_prep_kernel(const float* __restrict__ B, bf16x8* __restrict__ frags,
+                                                        unsigned* __restrict__ cmax2_bits, int d, int n,
+                                                        int euclid) {
+  const int unit = blockIdx.x, lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+  const int c = unit * 32 + l31;
+  bf16x8* out = frags + (size_t)unit * frags_per_unit(KS, NP) * 64 + lane;
+  float s = 0.f;  // ascending-k chain, as the exact kernels compute |c|^2
+  if (c < n)
+    for (int k = 0; k < d; ++k) {
+      const float x = B[(int64_t)k * n + c];
+      s = fmaf(x, x, s);
+    }
+  {
+    bf16x8 f = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (half == 0) {
+      __bf16 h, mm, lo;
+      split3(c < n ? (euclid ? -s : 0.f) : -3.0e38f, h, mm, lo);
+      f[0] = h;
+      f[1] = mm;
+      f[2] = lo;
+    }
+    out[0] = f;
+  }
+  if (half == 0 && c < n) atomicMax(cmax2_bits, __float_as_uint(s));  // s >= 0: bit order == value order
+#pragma unroll
+  for (int st = 0; st < KS; ++st) {
+    bf16x8 p[3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * st + 8 * half + j;
+      float x = (k < d && c < n) ? B[(int64_t)k * n + c] : 0.f;
+      if (euclid) x *= 2.f;
+      __bf16 h, mm, lo;
+      split3(x, h, mm, lo);
+      p[0][j] = h;
+      p[1][j] = mm;
+      p[2][j] = lo;
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) out[(1 + st * NP + q) * 64] = p[q];
+  }
+}
+
+// ---- 2. fast top-2 ---------------------------------------------------------------------------
+struct FastArgs {
+  const float* A;        // [d][m]
+  const bf16x8* frags;   // assign_prep_kernel
+  const unsigned* cmax2_bits;
+  int64_t* inds;         // [m] fast label (final for unambiguous points)
+  int* list;             // [m] ambiguous points
+  int* count;            // their number
+  int d, m, n_units, euclid;
+  float eps;             // eps_prod + (terms + 8) 2^-23
+};
+
+template <int KS, int NP, int CT>
+__global__ __launch_bounds__(kWaves * 64, 2) void assign_fast_kernel(FastArgs a) {
+  constexpr int FPU = frags_per_unit(KS, NP);
+  constexpr int CB = (int)chunk_bytes(KS, NP);
+  constexpr int NPR = n_products(NP);
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // two chunk buffers
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int m = a.m, d = a.d;
+  const int n_chunks = (a.n_units + kUnitsPerChunk - 1) / kUnitsPerChunk;  // the buffer is padded to whole chunks
+
+  // LDS-DMA of chunk j into buffer j & 1: the chunk is one contiguous run of 1-KiB fragments, in
+  // global memory as in LDS; wave w moves fragments w, w + 8, ...
+  auto stage = [&](int j) {
+    const char* src = reinterpret_cast<const char*>(a.frags) + (size_t)j * CB;
+    char* dst = smem + (j & 1) * CB;
+    for (int f = wave; f < CB / 1024; f += kWaves)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + f * 1024 + lane * 16),
+          (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+  };
+  stage(0);
+
+  // this wave's points: CT column tiles of 32; fragment = dimensions 16 s + 8 half + j
+  bf16x8 xs[CT][KS][NP];
+  float an2[CT];
+  int pt[CT];
+  bool pv[CT];
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)((int64_t)d * m * 4), 0x00020000);
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    pt[ct] = (blockIdx.x * kWaves + wave) * (32 * CT) + ct * 32 + l31;
+    pv[ct] = pt[ct] < m;
+    int voff = pv[ct] ? (8 * half * m + pt[ct]) * 4 : 0x7ffffff0;  // out of range -> 0
+    float s2 = 0.f;
+#pragma unroll
+    for (int st = 0; st < KS; ++st) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 0));
+        voff += j == 7 ? 9 * m * 4 : m * 4;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        __bf16 p[3];
+        split3(x[j], p[0], p[1], p[2]);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) xs[ct][st][q][j] = p[q];
+        s2 = fmaf(x[j], x[j], s2);
+      }
+    }
+    an2[ct] = s2 + __shfl_xor(s2, 32, 64);  // |a|^2 (any order: it only scales the bound)
+  }
+  bf16x8 bones = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (half == 0) {
+    bones[0] = (__bf16)1.0f;
+    bones[1] = (__bf16)1.0f;
+    bones[2] = (__bf16)1.0f;
+  }
+  float b1[CT], b2[CT];
+  int bi[CT], bu[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    b1[ct] = b2[ct] = -INFINITY;
+    bi[ct] = bu[ct] = 0;
+  }
+  f32x16 accA[CT], accB[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accB[ct][r] = -INFINITY;
+
+  constexpr int NM = CT * (1 + KS * NPR);  // MFMAs per unit
+  // unit U of the chunk in `base`; `fin` = accumulators of the unit before it (uid_fin), whose values
+  // go through the top-2 update between this unit's MFMAs
+  auto unit = [&](auto u_c, const bf16x8* base, f32x16 (&acc)[CT], const f32x16 (&fin)[CT], int uid_fin) {
+    constexpr int U = decltype(u_c)::value;
+    const bf16x8* up = base + U * FPU * 64 + lane;
+    float before[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) before[ct] = b1[ct];
+    bf16x8 ar[2][NP];
+    const bf16x8 cfrag = up[0];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) ar[0][q] = up[(1 + q) * 64];
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // epilogue slice after MFMA number mi (of NM): CT * 16 values spread over gaps [CT, NM)
+    auto slice = [&](auto mi_c) {
+      constexpr int mi = decltype(mi_c)::value;
+      if constexpr (mi >= CT) {
+        constexpr int tot = CT * 16;
+        constexpr int lo = ((mi - CT) * tot) / (NM - CT), hi = ((mi - CT + 1) * tot) / (NM - CT);
+        static_for<lo, hi>([&](auto e_c) {
+          constexpr int e = decltype(e_c)::value, ct = e / 16, r = e % 16;
+          take_top2<(r & 3) + 8 * (r >> 2)>(b1[ct], b2[ct], bi[ct], fin[ct][r]);
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    static_for<0, CT>([&](auto ct_c) {
+      constexpr int ct = decltype(ct_c)::value;
+      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, zero, 0, 0, 0);
+      slice(std::integral_constant<int, ct>{});
+    });
+    static_for<0, KS>([&](auto s_c) {
+      constexpr int st = decltype(s_c)::value;
+      if constexpr (st + 1 < KS) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) ar[(st + 1) & 1][q] = up[(1 + (st + 1) * NP + q) * 64];
+      }
+      static_for<0, NPR>([&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        // (centroid piece, point piece), smallest products first
+        //   NP = 2: (2,1) (1,2) (1,1);   NP = 3: (3,1) (1,3) (2,2) (2,1) (1,2) (1,1)
+        constexpr int ca = NP == 2 ? (t == 0 ? 1 : 0) : (t == 0 ? 2 : (t == 1 || t >= 4) ? 0 : 1);
+        constexpr int pa = NP == 2 ? (t == 1 ? 1 : 0) : (t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0);
+        static_for<0, CT>([&](auto ct_c) {
+          constexpr int ct = decltype(ct_c)::value;
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[st & 1][ca], xs[ct][st][pa], acc[ct], 0, 0, 0);
+          slice(std::integral_constant<int, CT * (1 + st * NPR + t) + ct>{});
+        });
+      });
+    });
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) bu[ct] = b1[ct] > before[ct] ? uid_fin : bu[ct];
+  };
+  using std::integral_constant;
+
+  __syncthreads();  // chunk 0 has landed (the barrier carries the vmcnt(0) of every wave's DMA)
+#pragma unroll 1
+  for (int j = 0; j < n_chunks; ++j) {
+    if (j + 1 < n_chunks) stage(j + 1);
+    const bf16x8* base = reinterpret_cast<const bf16x8*>(smem + (j & 1) * CB);
+    const int u0 = j * kUnitsPerChunk;
+    unit(integral_constant<int, 0>{}, base, accA, accB, u0 - 1);
+    unit(integral_constant<int, 1>{}, base, accB, accA, u0);
+    unit(integral_constant<int, 2>{}, base, accA, accB, u0 + 1);
+    unit(integral_constant<int, 3>{}, base, accB, accA, u0 + 2);
+    // every wave is done with buffer j & 1 (the next iteration's DMA overwrites it) and chunk j+1
+    // has landed
+    __syncthreads();
+  }
+  // the last unit's values (plain code: these reads follow the MFMAs directly)
+  const int uid_last = n_chunks * kUnitsPerChunk - 1;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const float before = b1[ct];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = accB[ct][r];
+      const float t = fminf(v, b1[ct]);
+      if (v > b1[ct]) bi[ct] = (r & 3) + 8 * (r >> 2);
+      b1[ct] = fmaxf(v, b1[ct]);
+      b2[ct] = fmaxf(b2[ct], t);
+    }
+    bu[ct] = b1[ct] > before ? uid_last : bu[ct];
+  }
+  const float cm2 = __uint_as_float(*a.cmax2_bits);
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    int idx = bu[ct] * 32 + bi[ct] + 4 * half;
+    const float o1 = __shfl_xor(b1[ct], 32, 64), o2 = __shfl_xor(b2[ct], 32, 64);
+    const int oi = __shfl_xor(idx, 32, 64);
+    const float B1 = fmaxf(b1[ct], o1);
+    const float B2 = fmaxf(fminf(b1[ct], o1), fmaxf(b2[ct], o2));
+    if (o1 > b1[ct] || (o1 == b1[ct] && oi < idx)) idx = oi;
+    if (half == 0 && pv[ct]) {
+      const float an = sqrtf(an2[ct]), cn = sqrtf(cm2);
+      const float scale = a.euclid ? (an + cn) * (an + cn) : an * cn;
+      const float delta = 1.25f * a.eps * scale;
+      a.inds[pt[ct]] = idx;
+      // (the negated comparison also sends NaN / Inf gaps to the exact kernel)
+      if (!(B1 - B2 > 2.f * delta)) a.list[atomicAdd(a.count, 1)] = pt[ct];
+    }
+  }
+}
+
+// ---- 3. exact re-check: max_sim_kernel (kmeans.hip, the bit-exact fp32-MFMA kernel) over the list ----
+struct Layout {
+  size_t frags_off, frags_bytes, cmax_off, count_off, list_off, total;
+};
+static Layout layout(int KS, int NP, int64_t m, int n) {
+  Layout L;
+  const int64_t units = (n + 31) / 32;
+  const int64_t chunks = (units + kUnitsPerChunk - 1) / kUnitsPerChunk;
+  L.frags_off = 0;
+  L.frags_bytes = (size_t)chunks * chunk_bytes(KS, NP);
+  L.cmax_off = L.frags_bytes;
+  L.count_off = L.cmax_off + 256;
+  L.list_off = L.count_off + 256;
+  L.total = L.list_off + (size_t)m * 4;
+  return L;
+}
+
+template <int KS, int NP, int CT>
+static int run(const float* A, const float* B, int64_t* inds, int d, int m, int n, int euclid, char* ws,
+               hipStream_t st) {
+  const Layout L = layout(KS, NP, m, n);
+  bf16x8* frags = reinterpret_cast<bf16x8*>(ws + L.frags_off);
+  unsigned* cmax = reinterpret_cast<unsigned*>(ws + L.cmax_off);
+  int* count = reinterpret_cast<int*>(ws + L.count_off);
+  int* list = reinterpret_cast<int*>(ws + L.list_off);
+  const int units = (n + 31) / 32;
+  const int units_padded = (units + kUnitsPerChunk - 1) / kUnitsPerChunk * kUnitsPerChunk;
+  int rc = check_hip(hipMemsetAsync(ws + L.cmax_off, 0, 512, st), "coarse_assign memset");
+  if (rc) return rc;
+  // padding units: rows beyond n get -3e38 norms and zero pieces from the kernel itself
+  hipLaunchKernelGGL((assign_prep_kernel<KS, NP>), dim3(units_padded), dim3(64), 0, st, B, frags, cmax, d, n,
+                     euclid);
+  TPQ_LAUNCH_CHECK("assign_prep_kernel");
+  const size_t lds = 2 * chunk_bytes(KS, NP);
+  auto kernel = assign_fast_kernel<KS, NP, CT>;
+  rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                 "assign_fast_kernel attr");
+  if (rc) return rc;
+  const int terms = KS * 16 * n_products(NP) + 3;
+  const float eps_prod = NP == 2 ? 3.0f / 262144.0f : 1.0f / 8388608.0f;  // 3 x 2^-18 | 2^-23
+  FastArgs fa{A, frags, cmax, inds, list, count, d, m, units_padded, euclid,
+              eps_prod + (float)(terms + 8) / 8388608.0f};
+  const int per_block = kWaves * 32 * CT;
+  hipLaunchKernelGGL(kernel, dim3((m + per_block - 1) / per_block), dim3(kWaves * 64), lds, st, fa);
+  TPQ_LAUNCH_CHECK("assign_fast_kernel");
+  return launch_max_sim_list(A, B, inds, d, m, n, euclid, list, count, st);
+}
+
+}  // namespace afast
+}  // namespace tpq
+
+using namespace tpq;
+
+#ifndef TPQ_AF_NP
+#define TPQ_AF_NP 2
+#endif
+#ifndef TPQ_AF_CT
+#define TPQ_AF_CT 2
+#endif
+
+static int af_ks(int d) { return d <= 32 ? 2 : (d <= 64 ? 4 : 8); }
+
+extern "C" int tpq_coarse_assign_supported(int d, int64_t m, int n) {
+  return (d >= 1 && d <= 128 && n >= 1 && n <= (1 << 24) && m >= 0 && m < (1LL << 31) &&
+          (int64_t)af_ks(d) * 16 * m * 4 <= 0x7fffffffLL)
+             ? 1
+             : 0;
+}
+
+extern "C" size_t tpq_coarse_assign_workspace_bytes(int d, int64_t m, int n) {
+  if (!tpq_coarse_assign_supported(d, m, n)) return 0;
+  return afast::layout(af_ks(d), TPQ_AF_NP, m, n).total;
+}
+
+// diagnostics: byte offset, inside the workspace, of the int32 number of points the last call sent
+// to the exact re-check
+extern "C" size_t tpq_coarse_assign_count_offset(int d, int64_t m, int n) {
+  if (!tpq_coarse_assign_supported(d, m, n)) return 0;
+  return afast::layout(af_ks(d), TPQ_AF_NP, m, n).count_off;
+}
+
+extern "C" int tpq_coarse_assign(const float* A, const float* B, int64_t* inds, int d, int64_t m, int n,
+                                 int metric, void* workspace, size_t workspace_bytes, tpq_stream_t stream) {
+  TPQ_REQUIRE(A && B && inds, "coarse_assign: null pointer");
+  TPQ_REQUIRE(metric == TPQ_METRIC_NEG_SQ_L2 || metric == TPQ_METRIC_INNER, "coarse_assign: bad metric %d", metric);
+  if (!tpq_coarse_assign_supported(d, m, n)) {
+    set_error("coarse_assign: shape d=%d m=%lld n=%d not supported (d <= 128, padded slice < 2 GiB); use tpq_max_sim",
+              d, (long long)m, n);
+    return TPQ_ERR_UNSUPPORTED;
+  }
+  if (m == 0) return TPQ_OK;
+  const size_t need = tpq_coarse_assign_workspace_bytes(d, m, n);
+  TPQ_REQUIRE(workspace && workspace_bytes >= need, "coarse_assign: workspace of %zu bytes needed", need);
+  const int euclid = metric == TPQ_METRIC_NEG_SQ_L2 ? 1 : 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  switch (af_ks(d)) {
+    case 2: return afast::run<2, TPQ_AF_NP, TPQ_AF_CT>(A, B, inds, d, (int)m, n, euclid, ws, st);
+    case 4: return afast::run<4, TPQ_AF_NP, TPQ_AF_CT>(A, B, inds, d, (int)m, n, euclid, ws, st);
+    default: return afast::run<8, TPQ_AF_NP, TPQ_AF_CT>(A, B, inds, d, (int)m, n, euclid, ws, st);
+  }
+}

@@ -61,15 +61,27 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
                                                          const float* __restrict__ B,
                                                          float* __restrict__ vals,
                                                          int64_t* __restrict__ inds, int d, int m,
-                                                         int n, int euclidean) {
+                                                         int n, int euclidean,
+                                                         const int* __restrict__ list,
+                                                         const int* __restrict__ count) {
+  // list != nullptr (tpq_coarse_assign's exact re-check): the points are columns list[0 .. *count)
+  // of A, results go to inds[list[p]], vals may be null; the grid covers the worst case and blocks
+  // beyond *count leave at once.
   extern __shared__ __attribute__((aligned(16))) float ms_smem[];
   float* cs = ms_smem;                  // [2][kMsKC][kMsCent]
   float* b2s = ms_smem + 2 * kMsSlab;   // [kMsCent]
   const int b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l31 = lane & 31, half = lane >> 5;
-  const int i = blockIdx.x * 128 + wave * 32 + l31;  // this lane's point
-  const bool iv = i < m;
+  const int pos = blockIdx.x * 128 + wave * 32 + l31;  // this lane's point (position in the list)
+  int m_eff = m;
+  if (list) {
+    m_eff = *count;
+    m_eff = m_eff < m ? m_eff : m;
+    if ((int)blockIdx.x * 128 >= m_eff) return;  // block-uniform
+  }
+  const bool iv = pos < m_eff;
+  const int i = list ? (iv ? list[pos] : 0) : pos;  // column of A / slot of the outputs
   // Every global load below is `uniform row pointer [per-lane 32-bit offset]`: the row pointer
   // lives in SGPRs, the offset in ONE VGPR per operand, rows past d are clamped to d-1 and
   // neutralised afterwards (no exec-mask branches).  (Round 1 formed a 64-bit per-lane address
@@ -229,9 +241,23 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
     besti = oi;
   }
   if (half == 0 && iv) {
-    vals[(int64_t)b * m + blockIdx.x * 128 + wave * 32 + l31] = best;
-    inds[(int64_t)b * m + blockIdx.x * 128 + wave * 32 + l31] = besti;
+    if (vals) vals[(int64_t)b * m + i] = best;
+    inds[(int64_t)b * m + i] = besti;
   }
+}
+
+// the exact kernel over a device-side list of points (one problem): see tpq_coarse_assign
+int launch_max_sim_list(const float* A, const float* B, int64_t* inds, int d, int m, int n, int euclid,
+                        const int* list, const int* count, hipStream_t st) {
+  const size_t ms_lds = (size_t)(2 * kMsSlab + kMsCent) * sizeof(float);
+  int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(max_sim_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ms_lds),
+                     "max_sim_kernel attr");
+  if (rc) return rc;
+  hipLaunchKernelGGL(max_sim_kernel, dim3((m + 127) / 128, 1), dim3(256), ms_lds, st, A, B,
+                     static_cast<float*>(nullptr), inds, d, m, n, euclid, list, count);
+  TPQ_LAUNCH_CHECK("max_sim_kernel (list)");
+  return TPQ_OK;
 }
 
 // ---- assign, codebook-sized problems (n <= 256 centroids, d <= 128): the PQ train/encode shape --
@@ -858,7 +884,8 @@ extern "C" int tpq_max_sim(const float* A, const float* B, float* vals, int64_t*
                           "max_sim_kernel attr");
   if (rc_attr) return rc_attr;
   hipLaunchKernelGGL(max_sim_kernel, dim3((m + 127) / 128, l), dim3(256), ms_lds, st, A, B, vals,
-                     inds, d, m, n, euclid);
+                     inds, d, m, n, euclid, static_cast<const int*>(nullptr),
+                     static_cast<const int*>(nullptr));
   TPQ_LAUNCH_CHECK("max_sim_kernel");
   return TPQ_OK;
 }

@@ -521,6 +521,46 @@ class MaxSimHip:
         return vals, inds
 
 
+class CoarseAssignHip:
+    """Labels of MaxSimHip (fp32), bit for bit, for ONE problem with many centroids -- the coarse
+    assign of IVFPQIndex.add / VQCodec.encode (kernels/MaxSimCuda.py:296-340 as called from
+    clustering/KMeans.py:440-452): A [d, m], B [d, n] -> labels [m] int64.  Error-bounded top-2
+    selection on the bf16 matrix cores + exact re-check of the ambiguous points on the device
+    (tpq_coarse_assign)."""
+
+    def __init__(self, distance="euclidean", **_):
+        assert distance in ("euclidean", "inner", "cosine")
+        self.distance = distance
+
+    @staticmethod
+    def supported(d, m, n):
+        return bool(load().tpq_coarse_assign_supported(int(d), int(m), int(n)))
+
+    def __call__(self, A, B):
+        assert A.dim() == 2 and B.dim() == 2 and A.shape[0] == B.shape[0]
+        assert A.dtype == B.dtype == torch.float32
+        A = A.contiguous()
+        B = B.contiguous()
+        require_gpu(A, B)
+        d, m = A.shape
+        n = B.shape[1]
+        lib = load()
+        inds = torch.empty(m, device=A.device, dtype=torch.int64)
+        ws_bytes = lib.tpq_coarse_assign_workspace_bytes(d, m, n)
+        ws = torch.empty(max(ws_bytes, 1), device=A.device, dtype=torch.uint8)
+        metric = _lib.METRIC_NEG_SQ_L2 if self.distance == "euclidean" else _lib.METRIC_INNER
+        with torch.cuda.device(A.device):
+            check(lib.tpq_coarse_assign(ptr(A), ptr(B), ptr(inds), d, m, n, metric, ptr(ws), ws_bytes,
+                                        stream_ptr(A.device)), "tpq_coarse_assign")
+        self._last = (ws, lib.tpq_coarse_assign_count_offset(d, m, n))
+        return inds
+
+    def last_rechecked(self):
+        """diagnostics (synchronises): points of the last call that went to the exact re-check"""
+        ws, off = self._last
+        return int(ws[off:off + 4].view(torch.int32).item())
+
+
 class ComputeCentroidsHip:
     """K-means update (kernels/ComputeCentroidsCuda.py:43-81): data [l, d, n], labels [l, n]
     -> centroids [l, d, k]; empty clusters -> 0."""
