@@ -254,6 +254,9 @@ int tpq_max_sim_split(const float* A, const float* B, float* vals, int64_t* inds
  * centroids of the oracle's fp32 arithmetic (ascending-k fmaf chains; ties -> smallest index).
  * An error-bounded top-2 selection on split-bf16 MFMAs decides every point whose two best fast
  * values differ by more than twice the bound; the others are re-evaluated exactly on the device.
+ * vals (optional, f32 [m]): the maximum itself -- the FAST value (within the bound, ~1e-5 of the
+ * scale) for points decided by the selection, the exact one for re-checked points: good for an
+ * inertia, not for bit comparisons.
  * Shapes: d <= 128, m < 2^31, padded slice 16 ceil(d/16) m floats < 2 GiB; otherwise
  * TPQ_ERR_UNSUPPORTED (use tpq_max_sim).  workspace: tpq_coarse_assign_workspace_bytes(d, m, n). */
 int tpq_coarse_assign_supported(int d, int64_t m, int n);
@@ -261,8 +264,8 @@ size_t tpq_coarse_assign_workspace_bytes(int d, int64_t m, int n);
 /* diagnostics: byte offset inside the workspace of the int32 count of points the last call
  * re-checked exactly */
 size_t tpq_coarse_assign_count_offset(int d, int64_t m, int n);
-int tpq_coarse_assign(const float* A, const float* B, int64_t* inds, int d, int64_t m, int n, int metric,
-                      void* workspace, size_t workspace_bytes, tpq_stream_t stream);
+int tpq_coarse_assign(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n,
+                      int metric, void* workspace, size_t workspace_bytes, tpq_stream_t stream);
 
 /* a-9  k-means update
  * replaces ComputeCentroidsCuda.__call__  torchpq/kernels/ComputeCentroidsCuda.py:43-81

@@ -557,7 +557,8 @@ def test_add_uses_the_fast_coarse_assign_and_cells_stay_exact(monkeypatch):
     from torchpq_amd.index import IVFPQIndex
     calls = []
     orig = K.CoarseAssignHip.__call__
-    monkeypatch.setattr(K.CoarseAssignHip, "__call__", lambda self, A, B: (calls.append(A.shape), orig(self, A, B))[1])
+    monkeypatch.setattr(K.CoarseAssignHip, "__call__",
+                        lambda self, A, B, **kw: (calls.append(A.shape), orig(self, A, B, **kw))[1])
     rng = np.random.default_rng(11)
     d, n = 64, 30000
     centers = rng.standard_normal((d, 300)) * 4
@@ -565,6 +566,7 @@ def test_add_uses_the_fast_coarse_assign_and_cells_stay_exact(monkeypatch):
     np.random.seed(1)
     idx = IVFPQIndex(d_vector=d, n_subvectors=16, n_cells=256, initial_size=64, device=DEV)
     idx.train(T(base))
+    calls.clear()  # (the coarse quantiser's training takes its labels from the same kernel)
     monkeypatch.setattr(KMeans, "fast_predict_min_work", 1 << 60)
     slow = N(idx.vq_codec.encode(T(base)))
     assert not calls

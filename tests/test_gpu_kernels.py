@@ -758,17 +758,17 @@ def test_coarse_assign_argument_errors(K):
     A, B = T(np.zeros((129, 8), np.float32)), T(np.zeros((129, 4), np.float32))
     out = torch.empty(8, device=DEV, dtype=torch.int64)
     ws = torch.empty(1 << 20, device=DEV, dtype=torch.uint8)
-    rc = lib.tpq_coarse_assign(_lib.ptr(A), _lib.ptr(B), _lib.ptr(out), 129, 8, 4, _lib.METRIC_NEG_SQ_L2,
+    rc = lib.tpq_coarse_assign(_lib.ptr(A), _lib.ptr(B), None, _lib.ptr(out), 129, 8, 4, _lib.METRIC_NEG_SQ_L2,
                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(DEV))
     assert rc == _lib.ERR_UNSUPPORTED and b"coarse_assign" in lib.tpq_last_error()
     A, B = T(np.zeros((64, 800), np.float32)), T(np.zeros((64, 400), np.float32))
     need = lib.tpq_coarse_assign_workspace_bytes(64, 800, 400)
     assert need > 0
     out = torch.empty(800, device=DEV, dtype=torch.int64)
-    rc = lib.tpq_coarse_assign(_lib.ptr(A), _lib.ptr(B), _lib.ptr(out), 64, 800, 400, _lib.METRIC_NEG_SQ_L2,
+    rc = lib.tpq_coarse_assign(_lib.ptr(A), _lib.ptr(B), None, _lib.ptr(out), 64, 800, 400, _lib.METRIC_NEG_SQ_L2,
                                _lib.ptr(ws), need - 1, _lib.stream_ptr(DEV))
     assert rc == -1 and b"workspace" in lib.tpq_last_error()
     # all-zero data: every centroid ties -> index 0
-    rc = lib.tpq_coarse_assign(_lib.ptr(A), _lib.ptr(B), _lib.ptr(out), 64, 800, 400, _lib.METRIC_NEG_SQ_L2,
+    rc = lib.tpq_coarse_assign(_lib.ptr(A), _lib.ptr(B), None, _lib.ptr(out), 64, 800, 400, _lib.METRIC_NEG_SQ_L2,
                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(DEV))
     assert rc == 0 and int(out.abs().max()) == 0

@@ -206,3 +206,35 @@ def test_kmeans_public_helpers():
     assert KMeans.remaining_memory("cuda:0") > 0 and MultiKMeans.does_it_fit((4, 4), device="cuda:0")
     assert not MultiKMeans.does_it_fit((1 << 40,), device="cuda:0")
     km.warmup_kernels()
+
+
+def test_single_problem_training_assign_takes_exact_labels_from_the_coarse_assign(monkeypatch):
+    """l = 1, many centroids (the coarse quantiser): the Lloyd loop's labels come from
+    tpq_coarse_assign and are the fp32 kernel's, bit for bit, at every step of a fit (compared on
+    shared centroids: the update's float atomics make two runs of the SAME fit differ in the last
+    bits of the centroids); the maxima it reports are the selection's fast values, within 1e-4."""
+    from torchpq_amd import kernels as K
+    from torchpq_amd.clustering import MultiKMeans
+    monkeypatch.setattr(MultiKMeans, "coarse_min_work", 0)
+    rng = np.random.default_rng(21)
+    d, n, k = 96, 20000, 300
+    centers = rng.standard_normal((d, 40)) * 6
+    data = (centers[:, rng.integers(0, 40, n)] + rng.standard_normal((d, n))).astype(np.float32)
+    cen = T(data[:, rng.choice(n, k, replace=False)].copy()[None])
+    calls = []
+    orig = K.CoarseAssignHip.__call__
+    monkeypatch.setattr(K.CoarseAssignHip, "__call__",
+                        lambda self, A, B, **kw: (calls.append(kw), orig(self, A, B, **kw))[1])
+    fast = MultiKMeans(n_clusters=k, assign_precision="bf16x3")
+    exact = MultiKMeans(n_clusters=k, assign_precision="fp32")
+    x = T(data[None])
+    for step in range(4):
+        v1, l1 = fast.get_labels(x, cen, training=True)
+        v0, l0 = exact.get_labels(x, cen, training=True)
+        assert torch.equal(l1, l0), step
+        np.testing.assert_allclose(N(v1), N(v0), rtol=1e-4, atol=1e-3 * float(np.abs(N(v0)).max()))
+        cen = exact.compute_centroids(x, l0)
+    assert len(calls) == 4 and all(c.get("return_vals") for c in calls)
+    # outside the Lloyd loop (predict, k-means++) the batched engine keeps the fp32 kernel
+    fast.get_labels(x, cen)
+    assert len(calls) == 4

@@ -55,7 +55,7 @@ SIGNATURES = {
     "tpq_coarse_assign_supported": (_i, [_i, _i64, _i]),
     "tpq_coarse_assign_workspace_bytes": (_sz, [_i, _i64, _i]),
     "tpq_coarse_assign_count_offset": (_sz, [_i, _i64, _i]),
-    "tpq_coarse_assign": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _vp, _sz, _vp]),
+    "tpq_coarse_assign": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _sz, _vp]),
     "tpq_compute_centroids_workspace_bytes": (_sz, [_i, _i, _i]),
     "tpq_compute_centroids": (_i, [_vp, _vp, _vp, _i, _i, _i64, _i, _vp, _sz, _vp]),
     "tpq_get_ioa_workspace_bytes": (_sz, [_i64]),

@@ -12,7 +12,7 @@ import torch
 
 from .. import metric
 from ..CustomModule import CustomModule
-from ..kernels import ComputeCentroidsHip, MaxSimHip
+from ..kernels import CoarseAssignHip, ComputeCentroidsHip, MaxSimHip
 
 
 class MultiKMeans(CustomModule):
@@ -131,12 +131,25 @@ class MultiKMeans(CustomModule):
             return self.max_sim_split_hip
         return self.max_sim_hip
 
+    # a single problem with many centroids (the coarse quantiser's training): the Lloyd loop takes its
+    # labels from tpq_coarse_assign -- the fp32 kernel's labels, bit for bit, 3-4x faster; the
+    # maxima that come with them are the selection's fast values (~1e-5 of the scale), used for the
+    # inertia only
+    coarse_min_work = 1 << 27
+
     def get_labels(self, data, centroids, training=False):
         """(max_sims [l, n], labels [l, n] int64); training=True: the Lloyd loop's assign, which may
         run on the bf16 matrix cores (`assign_precision`)"""
         if self.distance == "cosine":
             data = data / (data.norm(dim=-2, keepdim=True) + 1e-8)
             centroids = centroids / (centroids.norm(dim=-2, keepdim=True) + 1e-8)
+        l, d, n = data.shape
+        k = centroids.shape[2]
+        if (training and l == 1 and self.assign_precision == "bf16x3" and k >= 64
+                and n * k * d >= self.coarse_min_work and CoarseAssignHip.supported(d, n, k)):
+            op = CoarseAssignHip(distance="euclidean" if self.distance == "euclidean" else "inner")
+            vals, labels = op(data[0], centroids[0], return_vals=True)
+            return vals[None], labels[None]
         kernel = self._assign_kernel(data.shape[1], data.shape[2], centroids.shape[2], training)
         return kernel(data, centroids, dim=2, mode="tn")
 

@@ -10,7 +10,8 @@
 // with a rigorous bound |f - g| <= delta on its distance from the real-number value g selects, the
 // exact arithmetic decides only where the selection cannot:
 //   1. assign_prep_kernel: the centroids, doubled (exact), split into NP bf16 pieces (NP = 2:
-//      c = c1 + c2 + r, |r| <= 2^-18 |c|) and laid out in MFMA-fragment order, 32 centroids per unit,
+//      c = c1 + c2 + r, |r| <= 2^-16 |c|: a bf16 piece carries 8 significant bits, unit roundoff
+//      2^-8) and laid out in MFMA-fragment order, 32 centroids per unit,
 //      plus -|c|^2 as an exact 3-piece fragment and max |c|^2;
 //   2. assign_fast_kernel: every wave keeps 32 CT points (split the same way) in registers for the
 //      whole sweep and streams ALL centroid units through a double-buffered LDS ring filled by
@@ -18,7 +19,7 @@
 //      products c2 a1, c1 a2, c1 a1 (NP = 2) go through v_mfma_f32_32x32x16_bf16; the epilogue keeps
 //      the best AND the second-best fast value per point (5 VALU per value);
 //      delta = 1.25 (eps_prod + (terms + 8) 2^-23) (|a| + |c|max)^2 covers the dropped products
-//      (3 x 2^-18 |a_k c_k| per term at NP = 2), a worst-case (truncating) fp32 accumulation of all
+//      (c2 a2, r_c a, c r_a: 3 x 2^-16 |a_k c_k| per term at NP = 2), a worst-case (truncating) fp32 accumulation of all
 //      MFMA terms, and the rounding of the exact chain itself.  A point whose two best fast values
 //      are further apart than 2 delta has its label decided: any other centroid is worse in
 //      the exact arithmetic too.  The rest (a few per cent at d = 128) are appended to a list;
@@ -30,8 +31,8 @@
 #include "common.h"
 
 namespace tpq {
-int launch_max_sim_list(const float* A, const float* B, int64_t* inds, int d, int m, int n, int euclid,
-                        const int* list, const int* count, hipStream_t st);  // kmeans.hip
+int launch_max_sim_list(const float* A, const float* B, float* vals, int64_t* inds, int d, int m, int n,
+                        int euclid, const int* list, const int* count, hipStream_t st);  // kmeans.hip
 namespace afast {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -131,6 +132,7 @@ struct FastArgs {
   const bf16x8* frags;   // assign_prep_kernel
   const unsigned* cmax2_bits;
   int64_t* inds;         // [m] fast label (final for unambiguous points)
+  float* vals;           // optional [m]: the fast maximum, b1 - |a|^2 (|error| <= delta); exact for re-checked points
   int* list;             // [m] ambiguous points
   int* count;            // their number
   int d, m, n_units, euclid;
@@ -310,6 +312,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void assign_fast_kernel(FastArgs a)
       const float scale = a.euclid ? (an + cn) * (an + cn) : an * cn;
       const float delta = 1.25f * a.eps * scale;
       a.inds[pt[ct]] = idx;
+      if (a.vals) a.vals[pt[ct]] = a.euclid ? B1 - an2[ct] : B1;
       // (the negated comparison also sends NaN / Inf gaps to the exact kernel)
       if (!(B1 - B2 > 2.f * delta)) a.list[atomicAdd(a.count, 1)] = pt[ct];
     }
@@ -334,7 +337,7 @@ static Layout layout(int KS, int NP, int64_t m, int n) {
 }
 
 template <int KS, int NP, int CT>
-static int run(const float* A, const float* B, int64_t* inds, int d, int m, int n, int euclid, char* ws,
+static int run(const float* A, const float* B, float* vals, int64_t* inds, int d, int m, int n, int euclid, char* ws,
                hipStream_t st) {
   const Layout L = layout(KS, NP, m, n);
   bf16x8* frags = reinterpret_cast<bf16x8*>(ws + L.frags_off);
@@ -356,13 +359,15 @@ static int run(const float* A, const float* B, int64_t* inds, int d, int m, int 
                  "assign_fast_kernel attr");
   if (rc) return rc;
   const int terms = KS * 16 * n_products(NP) + 3;
-  const float eps_prod = NP == 2 ? 3.0f / 262144.0f : 1.0f / 8388608.0f;  // 3 x 2^-18 | 2^-23
-  FastArgs fa{A, frags, cmax, inds, list, count, d, m, units_padded, euclid,
+  // dropped products: NP = 2: c2 a2 + r_c a + c r_a <= 3 x 2^-16 |a_k c_k| (1 % slack for the second-order
+  // terms); NP = 3: c2 a3 + c3 a2 + c3 a3 <= 2^-23 |a_k c_k|
+  const float eps_prod = NP == 2 ? 3.03f / 65536.0f : 1.01f / 8388608.0f;
+  FastArgs fa{A, frags, cmax, inds, vals, list, count, d, m, units_padded, euclid,
               eps_prod + (float)(terms + 8) / 8388608.0f};
   const int per_block = kWaves * 32 * CT;
   hipLaunchKernelGGL(kernel, dim3((m + per_block - 1) / per_block), dim3(kWaves * 64), lds, st, fa);
   TPQ_LAUNCH_CHECK("assign_fast_kernel");
-  return launch_max_sim_list(A, B, inds, d, m, n, euclid, list, count, st);
+  return launch_max_sim_list(A, B, vals, inds, d, m, n, euclid, list, count, st);
 }
 
 }  // namespace afast
@@ -398,7 +403,7 @@ extern "C" size_t tpq_coarse_assign_count_offset(int d, int64_t m, int n) {
   return afast::layout(af_ks(d), TPQ_AF_NP, m, n).count_off;
 }
 
-extern "C" int tpq_coarse_assign(const float* A, const float* B, int64_t* inds, int d, int64_t m, int n,
+extern "C" int tpq_coarse_assign(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n,
                                  int metric, void* workspace, size_t workspace_bytes, tpq_stream_t stream) {
   TPQ_REQUIRE(A && B && inds, "coarse_assign: null pointer");
   TPQ_REQUIRE(metric == TPQ_METRIC_NEG_SQ_L2 || metric == TPQ_METRIC_INNER, "coarse_assign: bad metric %d", metric);
@@ -414,8 +419,8 @@ extern "C" int tpq_coarse_assign(const float* A, const float* B, int64_t* inds, 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   char* ws = reinterpret_cast<char*>(workspace);
   switch (af_ks(d)) {
-    case 2: return afast::run<2, TPQ_AF_NP, TPQ_AF_CT>(A, B, inds, d, (int)m, n, euclid, ws, st);
-    case 4: return afast::run<4, TPQ_AF_NP, TPQ_AF_CT>(A, B, inds, d, (int)m, n, euclid, ws, st);
-    default: return afast::run<8, TPQ_AF_NP, TPQ_AF_CT>(A, B, inds, d, (int)m, n, euclid, ws, st);
+    case 2: return afast::run<2, TPQ_AF_NP, TPQ_AF_CT>(A, B, vals, inds, d, (int)m, n, euclid, ws, st);
+    case 4: return afast::run<4, TPQ_AF_NP, TPQ_AF_CT>(A, B, vals, inds, d, (int)m, n, euclid, ws, st);
+    default: return afast::run<8, TPQ_AF_NP, TPQ_AF_CT>(A, B, vals, inds, d, (int)m, n, euclid, ws, st);
   }
 }

@@ -247,15 +247,15 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
 }
 
 // the exact kernel over a device-side list of points (one problem): see tpq_coarse_assign
-int launch_max_sim_list(const float* A, const float* B, int64_t* inds, int d, int m, int n, int euclid,
-                        const int* list, const int* count, hipStream_t st) {
+int launch_max_sim_list(const float* A, const float* B, float* vals, int64_t* inds, int d, int m, int n,
+                        int euclid, const int* list, const int* count, hipStream_t st) {
   const size_t ms_lds = (size_t)(2 * kMsSlab + kMsCent) * sizeof(float);
   int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(max_sim_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ms_lds),
                      "max_sim_kernel attr");
   if (rc) return rc;
-  hipLaunchKernelGGL(max_sim_kernel, dim3((m + 127) / 128, 1), dim3(256), ms_lds, st, A, B,
-                     static_cast<float*>(nullptr), inds, d, m, n, euclid, list, count);
+  hipLaunchKernelGGL(max_sim_kernel, dim3((m + 127) / 128, 1), dim3(256), ms_lds, st, A, B, vals, inds, d,
+                     m, n, euclid, list, count);
   TPQ_LAUNCH_CHECK("max_sim_kernel (list)");
   return TPQ_OK;
 }

@@ -536,7 +536,9 @@ class CoarseAssignHip:
     def supported(d, m, n):
         return bool(load().tpq_coarse_assign_supported(int(d), int(m), int(n)))
 
-    def __call__(self, A, B):
+    def __call__(self, A, B, return_vals=False):
+        """labels [m]; return_vals=True: (vals, labels) with vals the maximum similarity, approximate
+        (within the selection bound) except for re-checked points"""
         assert A.dim() == 2 and B.dim() == 2 and A.shape[0] == B.shape[0]
         assert A.dtype == B.dtype == torch.float32
         A = A.contiguous()
@@ -549,11 +551,12 @@ class CoarseAssignHip:
         ws_bytes = lib.tpq_coarse_assign_workspace_bytes(d, m, n)
         ws = torch.empty(max(ws_bytes, 1), device=A.device, dtype=torch.uint8)
         metric = _lib.METRIC_NEG_SQ_L2 if self.distance == "euclidean" else _lib.METRIC_INNER
+        vals = torch.empty(m, device=A.device, dtype=torch.float32) if return_vals else None
         with torch.cuda.device(A.device):
-            check(lib.tpq_coarse_assign(ptr(A), ptr(B), ptr(inds), d, m, n, metric, ptr(ws), ws_bytes,
-                                        stream_ptr(A.device)), "tpq_coarse_assign")
+            check(lib.tpq_coarse_assign(ptr(A), ptr(B), ptr(vals) if return_vals else None, ptr(inds), d, m, n,
+                                        metric, ptr(ws), ws_bytes, stream_ptr(A.device)), "tpq_coarse_assign")
         self._last = (ws, lib.tpq_coarse_assign_count_offset(d, m, n))
-        return inds
+        return (vals, inds) if return_vals else inds
 
     def last_rechecked(self):
         """diagnostics (synchronises): points of the last call that went to the exact re-check"""
