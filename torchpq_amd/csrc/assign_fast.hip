@@ -18,9 +18,9 @@
 //      global_load_lds (LDS-DMA: no staging registers); per 16 dimensions and 32 x 32 tile the
 //      products c2 a1, c1 a2, c1 a1 (NP = 2) go through v_mfma_f32_32x32x16_bf16; the epilogue keeps
 //      the best AND the second-best fast value per point (5 VALU per value);
-//      delta = 1.25 (eps_prod + (terms + 8) 2^-23) (|a| + |c|max)^2 covers the dropped products
+//      delta = 1.25 (eps_prod + (16 KS + 13) 2^-23) (|a| + |c|max)^2 covers the dropped products
 //      (c2 a2, r_c a, c r_a: 3 x 2^-16 |a_k c_k| per term at NP = 2), a worst-case (truncating) fp32 accumulation of all
-//      MFMA terms, and the rounding of the exact chain itself.  A point whose two best fast values
+//      MFMA terms (small products first: see the kernel), and the rounding of the exact chain itself.  A point whose two best fast values
 //      are further apart than 2 delta has its label decided: any other centroid is worse in
 //      the exact arithmetic too.  The rest (a few per cent at d = 128) are appended to a list;
 //   3. the bit-exact fp32-MFMA kernel (max_sim_kernel, kmeans.hip) over the listed points only: it
@@ -240,30 +240,73 @@ __global__ __launch_bounds__(kWaves * 64, 2) void assign_fast_kernel(FastArgs a)
       }
       __builtin_amdgcn_sched_barrier(0);
     };
-    static_for<0, CT>([&](auto ct_c) {
-      constexpr int ct = decltype(ct_c)::value;
-      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, zero, 0, 0, 0);
-      slice(std::integral_constant<int, ct>{});
-    });
-    static_for<0, KS>([&](auto s_c) {
-      constexpr int st = decltype(s_c)::value;
-      if constexpr (st + 1 < KS) {
+    if constexpr (NP == 2) {
+      // Order of accumulation = part of the error bound.  Every fp32 addition rounds relative to the
+      // partial sum it produces, so the small terms go FIRST: the 2 KS correction MFMAs (c2 a1, c1 a2:
+      // 32 KS additions on partial sums below 2^-7 S, S = sum |2 c_k a_k|), then the KS main MFMAs
+      // (c1 a1: 16 KS additions on partial sums up to S), then -|c|^2 (3 additions):
+      // (16 KS + 2 + 3) roundings of (S + |c|^2) in all, against 48 KS + 3 with the three products of
+      // a k-step issued together.
+      static_for<0, KS>([&](auto s_c) {
+        constexpr int st = decltype(s_c)::value;
+        if constexpr (st + 1 < KS) {
 #pragma unroll
-        for (int q = 0; q < NP; ++q) ar[(st + 1) & 1][q] = up[(1 + (st + 1) * NP + q) * 64];
-      }
-      static_for<0, NPR>([&](auto t_c) {
-        constexpr int t = decltype(t_c)::value;
-        // (centroid piece, point piece), smallest products first
-        //   NP = 2: (2,1) (1,2) (1,1);   NP = 3: (3,1) (1,3) (2,2) (2,1) (1,2) (1,1)
-        constexpr int ca = NP == 2 ? (t == 0 ? 1 : 0) : (t == 0 ? 2 : (t == 1 || t >= 4) ? 0 : 1);
-        constexpr int pa = NP == 2 ? (t == 1 ? 1 : 0) : (t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0);
-        static_for<0, CT>([&](auto ct_c) {
-          constexpr int ct = decltype(ct_c)::value;
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[st & 1][ca], xs[ct][st][pa], acc[ct], 0, 0, 0);
-          slice(std::integral_constant<int, CT * (1 + st * NPR + t) + ct>{});
+          for (int q = 0; q < 2; ++q) ar[(st + 1) & 1][q] = up[(1 + (st + 1) * 2 + q) * 64];
+        }
+        static_for<0, 2>([&](auto t_c) {
+          constexpr int t = decltype(t_c)::value;  // t = 0: (c2, a1); t = 1: (c1, a2)
+          static_for<0, CT>([&](auto ct_c) {
+            constexpr int ct = decltype(ct_c)::value;
+            if constexpr (st == 0 && t == 0) {
+              acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][1], xs[ct][0][0], zero, 0, 0, 0);
+            } else {
+              acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[st & 1][1 - t], xs[ct][st][t], acc[ct], 0, 0, 0);
+            }
+            slice(std::integral_constant<int, CT * (2 * st + t) + ct>{});
+          });
         });
       });
-    });
+      bf16x8 am[2];  // c1 of k-step s for the main pass, one k-step ahead
+      am[0] = up[1 * 64];
+      static_for<0, KS>([&](auto s_c) {
+        constexpr int st = decltype(s_c)::value;
+        if constexpr (st + 1 < KS) am[(st + 1) & 1] = up[(1 + (st + 1) * 2) * 64];
+        static_for<0, CT>([&](auto ct_c) {
+          constexpr int ct = decltype(ct_c)::value;
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[st & 1], xs[ct][st][0], acc[ct], 0, 0, 0);
+          slice(std::integral_constant<int, CT * (2 * KS + st) + ct>{});
+        });
+      });
+      static_for<0, CT>([&](auto ct_c) {
+        constexpr int ct = decltype(ct_c)::value;
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, acc[ct], 0, 0, 0);
+        slice(std::integral_constant<int, CT * 3 * KS + ct>{});
+      });
+    } else {
+      static_for<0, CT>([&](auto ct_c) {
+        constexpr int ct = decltype(ct_c)::value;
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, zero, 0, 0, 0);
+        slice(std::integral_constant<int, ct>{});
+      });
+      static_for<0, KS>([&](auto s_c) {
+        constexpr int st = decltype(s_c)::value;
+        if constexpr (st + 1 < KS) {
+#pragma unroll
+          for (int q = 0; q < NP; ++q) ar[(st + 1) & 1][q] = up[(1 + (st + 1) * NP + q) * 64];
+        }
+        static_for<0, NPR>([&](auto t_c) {
+          constexpr int t = decltype(t_c)::value;
+          // (centroid piece, point piece), smallest first: (3,1) (1,3) (2,2) (2,1) (1,2) (1,1)
+          constexpr int ca = t == 0 ? 2 : (t == 1 || t >= 4) ? 0 : 1;
+          constexpr int pa = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
+          static_for<0, CT>([&](auto ct_c) {
+            constexpr int ct = decltype(ct_c)::value;
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[st & 1][ca], xs[ct][st][pa], acc[ct], 0, 0, 0);
+            slice(std::integral_constant<int, CT * (1 + st * NPR + t) + ct>{});
+          });
+        });
+      });
+    }
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) bu[ct] = b1[ct] > before[ct] ? uid_fin : bu[ct];
   };
@@ -358,7 +401,8 @@ static int run(const float* A, const float* B, float* vals, int64_t* inds, int d
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                  "assign_fast_kernel attr");
   if (rc) return rc;
-  const int terms = KS * 16 * n_products(NP) + 3;
+  // roundings of the full-size partial sum (see the accumulation order in the kernel)
+  const int terms = NP == 2 ? KS * 16 + 2 + 3 : KS * 16 * n_products(NP) + 3;
   // dropped products: NP = 2: c2 a2 + r_c a + c r_a <= 3 x 2^-16 |a_k c_k| (1 % slack for the second-order
   // terms); NP = 3: c2 a3 + c3 a2 + c3 a3 <= 2^-23 |a_k c_k|
   const float eps_prod = NP == 2 ? 3.03f / 65536.0f : 1.01f / 8388608.0f;
