@@ -18,7 +18,8 @@
 //      global_load_lds (LDS-DMA: no staging registers); per 16 dimensions and 32 x 32 tile the
 //      products c2 a1, c1 a2, c1 a1 (NP = 2) go through v_mfma_f32_32x32x16_bf16; the epilogue keeps
 //      the best AND the second-best fast value per point (5 VALU per value);
-//      delta = 1.25 (eps_prod + (16 KS + 13) 2^-23) (|a| + |c|max)^2 covers the dropped products
+//      delta = 1.25 [(eps_prod + (16 KS + 13) 2^-23) (|a - mu| + |c - mu|max)^2 + (d + 4) 2^-24 (|a| + |c|max)^2]
+//      (mu = mean centroid: distances are translation-invariant) covers the dropped products
 //      (c2 a2, r_c a, c r_a: 3 x 2^-16 |a_k c_k| per term at NP = 2), a worst-case (truncating) fp32 accumulation of all
 //      MFMA terms (small products first: see the kernel), and the rounding of the exact chain itself.  A point whose two best fast values
 //      are further apart than 2 delta has its label decided: any other centroid is worse in
@@ -82,18 +83,43 @@ constexpr int n_products(int NP) { return NP == 2 ? 3 : 6; }
 // holds 8 consecutive dimensions of its centroid per k-step, as the MFMA A operand wants them.
 // frags: [unit][1 + KS * NP][64 lanes] x 16 B, fragment 0 = -|c|^2 (euclidean) or 0 (inner) as three
 // exact pieces at k = 0, 1, 2; rows beyond n carry -3e38 there: they can never be first or second.
+// Centring (euclidean only).  Distances are translation-invariant, so the FAST values are computed on
+// points and centroids shifted by mu = the mean centroid: the bound of the fast path scales with
+// (|a - mu| + |c - mu|max)^2 instead of (|a| + |c|max)^2 -- 2-4x smaller on non-negative data such as
+// SIFT -- while the error of the exact chain, which works on the raw data, keeps the raw norms.
+// mu[k] = mean over the centroids of dimension k (one block per dimension); zero for inner product.
+__global__ __launch_bounds__(256) void assign_mean_kernel(const float* __restrict__ B, float* __restrict__ mu,
+                                                         int n, int euclid) {
+  __shared__ float red[256];
+  const int k = blockIdx.x;
+  float s = 0.f;
+  if (euclid)
+    for (int c = threadIdx.x; c < n; c += 256) s += B[(int64_t)k * n + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) mu[k] = red[0] / (float)n;
+}
+
+// cmax2_bits[0] = max |c - mu|^2, cmax2_bits[1] = max |c|^2
 template <int KS, int NP>
 __global__ __launch_bounds__(64) void assign_prep_kernel(const float* __restrict__ B, bf16x8* __restrict__ frags,
-                                                        unsigned* __restrict__ cmax2_bits, int d, int n,
+                                                        unsigned* __restrict__ cmax2_bits,
+                                                        const float* __restrict__ mu, int d, int n,
                                                         int euclid) {
   const int unit = blockIdx.x, lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
   const int c = unit * 32 + l31;
   bf16x8* out = frags + (size_t)unit * frags_per_unit(KS, NP) * 64 + lane;
-  float s = 0.f;  // ascending-k chain, as the exact kernels compute |c|^2
+  float s = 0.f, sraw = 0.f;  // |c - mu|^2 of the shifted centroid the fast path uses, and |c|^2
   if (c < n)
     for (int k = 0; k < d; ++k) {
-      const float x = B[(int64_t)k * n + c];
+      const float xr = B[(int64_t)k * n + c];
+      const float x = xr - mu[k];
       s = fmaf(x, x, s);
+      sraw = fmaf(xr, xr, sraw);
     }
   {
     bf16x8 f = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -106,14 +132,17 @@ __global__ __launch_bounds__(64) void assign_prep_kernel(const float* __restrict
     }
     out[0] = f;
   }
-  if (half == 0 && c < n) atomicMax(cmax2_bits, __float_as_uint(s));  // s >= 0: bit order == value order
+  if (half == 0 && c < n) {  // non-negative floats: bit order == value order
+    atomicMax(cmax2_bits, __float_as_uint(s));
+    atomicMax(cmax2_bits + 1, __float_as_uint(sraw));
+  }
 #pragma unroll
   for (int st = 0; st < KS; ++st) {
     bf16x8 p[3];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = 16 * st + 8 * half + j;
-      float x = (k < d && c < n) ? B[(int64_t)k * n + c] : 0.f;
+      float x = (k < d && c < n) ? B[(int64_t)k * n + c] - mu[k] : 0.f;
       if (euclid) x *= 2.f;
       __bf16 h, mm, lo;
       split3(x, h, mm, lo);
@@ -130,13 +159,15 @@ __global__ __launch_bounds__(64) void assign_prep_kernel(const float* __restrict
 struct FastArgs {
   const float* A;        // [d][m]
   const bf16x8* frags;   // assign_prep_kernel
-  const unsigned* cmax2_bits;
+  const unsigned* cmax2_bits;  // [0] max |c - mu|^2, [1] max |c|^2
+  const float* mu;             // [16 KS] centring vector (zero beyond d and for inner product)
   int64_t* inds;         // [m] fast label (final for unambiguous points)
   float* vals;           // optional [m]: the fast maximum, b1 - |a|^2 (|error| <= delta); exact for re-checked points
   int* list;             // [m] ambiguous points
   int* count;            // their number
   int d, m, n_units, euclid;
-  float eps;             // eps_prod + (terms + 8) 2^-23
+  float eps;             // fast path: eps_prod + (terms + 8) 2^-23, relative to (|a - mu| + |c - mu|max)^2
+  float eps_exact;       // the exact chain's own rounding: (d + 4) 2^-24, relative to (|a| + |c|max)^2
 };
 
 template <int KS, int NP, int CT>
@@ -164,7 +195,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void assign_fast_kernel(FastArgs a)
 
   // this wave's points: CT column tiles of 32; fragment = dimensions 16 s + 8 half + j
   bf16x8 xs[CT][KS][NP];
-  float an2[CT];
+  float an2[CT], an2raw[CT];  // |a - mu|^2 and |a|^2
   int pt[CT];
   bool pv[CT];
   const __amdgpu_buffer_rsrc_t rsrc =
@@ -174,25 +205,30 @@ __global__ __launch_bounds__(kWaves * 64, 2) void assign_fast_kernel(FastArgs a)
     pt[ct] = (blockIdx.x * kWaves + wave) * (32 * CT) + ct * 32 + l31;
     pv[ct] = pt[ct] < m;
     int voff = pv[ct] ? (8 * half * m + pt[ct]) * 4 : 0x7ffffff0;  // out of range -> 0
-    float s2 = 0.f;
+    float s2 = 0.f, s2raw = 0.f;
 #pragma unroll
     for (int st = 0; st < KS; ++st) {
-      float x[8];
+      float x[8], mk[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 0));
+        mk[j] = a.mu[16 * st + 8 * half + j];
         voff += j == 7 ? 9 * m * 4 : m * 4;
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
+        // lanes without a point and dimensions beyond d read 0 and stay 0 (mu is 0 beyond d)
+        const float xc = pv[ct] ? x[j] - mk[j] : 0.f;
         __bf16 p[3];
-        split3(x[j], p[0], p[1], p[2]);
+        split3(xc, p[0], p[1], p[2]);
 #pragma unroll
         for (int q = 0; q < NP; ++q) xs[ct][st][q][j] = p[q];
-        s2 = fmaf(x[j], x[j], s2);
+        s2 = fmaf(xc, xc, s2);
+        s2raw = fmaf(x[j], x[j], s2raw);
       }
     }
-    an2[ct] = s2 + __shfl_xor(s2, 32, 64);  // |a|^2 (any order: it only scales the bound)
+    an2[ct] = s2 + __shfl_xor(s2, 32, 64);  // (any order: the norms only scale the bound)
+    an2raw[ct] = s2raw + __shfl_xor(s2raw, 32, 64);
   }
   bf16x8 bones = {0, 0, 0, 0, 0, 0, 0, 0};
   if (half == 0) {
@@ -341,7 +377,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void assign_fast_kernel(FastArgs a)
     }
     bu[ct] = b1[ct] > before ? uid_last : bu[ct];
   }
-  const float cm2 = __uint_as_float(*a.cmax2_bits);
+  const float cm2 = __uint_as_float(a.cmax2_bits[0]), cm2raw = __uint_as_float(a.cmax2_bits[1]);
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     int idx = bu[ct] * 32 + bi[ct] + 4 * half;
@@ -352,8 +388,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void assign_fast_kernel(FastArgs a)
     if (o1 > b1[ct] || (o1 == b1[ct] && oi < idx)) idx = oi;
     if (half == 0 && pv[ct]) {
       const float an = sqrtf(an2[ct]), cn = sqrtf(cm2);
-      const float scale = a.euclid ? (an + cn) * (an + cn) : an * cn;
-      const float delta = 1.25f * a.eps * scale;
+      const float anr = sqrtf(an2raw[ct]), cnr = sqrtf(cm2raw);
+      const float delta = 1.25f * (a.euclid ? a.eps * (an + cn) * (an + cn) + a.eps_exact * (anr + cnr) * (anr + cnr)
+                                            : (a.eps + a.eps_exact) * anr * cnr);
       a.inds[pt[ct]] = idx;
       if (a.vals) a.vals[pt[ct]] = a.euclid ? B1 - an2[ct] : B1;
       // (the negated comparison also sends NaN / Inf gaps to the exact kernel)
@@ -364,7 +401,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void assign_fast_kernel(FastArgs a)
 
 // ---- 3. exact re-check: max_sim_kernel (kmeans.hip, the bit-exact fp32-MFMA kernel) over the list ----
 struct Layout {
-  size_t frags_off, frags_bytes, cmax_off, count_off, list_off, total;
+  size_t frags_off, frags_bytes, cmax_off, count_off, mu_off, list_off, total;
 };
 static Layout layout(int KS, int NP, int64_t m, int n) {
   Layout L;
@@ -374,7 +411,8 @@ static Layout layout(int KS, int NP, int64_t m, int n) {
   L.frags_bytes = (size_t)chunks * chunk_bytes(KS, NP);
   L.cmax_off = L.frags_bytes;
   L.count_off = L.cmax_off + 256;
-  L.list_off = L.count_off + 256;
+  L.mu_off = L.count_off + 256;
+  L.list_off = L.mu_off + 1024;
   L.total = L.list_off + (size_t)m * 4;
   return L;
 }
@@ -389,10 +427,13 @@ static int run(const float* A, const float* B, float* vals, int64_t* inds, int d
   int* list = reinterpret_cast<int*>(ws + L.list_off);
   const int units = (n + 31) / 32;
   const int units_padded = (units + kUnitsPerChunk - 1) / kUnitsPerChunk * kUnitsPerChunk;
-  int rc = check_hip(hipMemsetAsync(ws + L.cmax_off, 0, 512, st), "coarse_assign memset");
+  float* mu = reinterpret_cast<float*>(ws + L.mu_off);
+  int rc = check_hip(hipMemsetAsync(ws + L.cmax_off, 0, 512 + 1024, st), "coarse_assign memset");
   if (rc) return rc;
+  hipLaunchKernelGGL(assign_mean_kernel, dim3(d), dim3(256), 0, st, B, mu, n, euclid);
+  TPQ_LAUNCH_CHECK("assign_mean_kernel");
   // padding units: rows beyond n get -3e38 norms and zero pieces from the kernel itself
-  hipLaunchKernelGGL((assign_prep_kernel<KS, NP>), dim3(units_padded), dim3(64), 0, st, B, frags, cmax, d, n,
+  hipLaunchKernelGGL((assign_prep_kernel<KS, NP>), dim3(units_padded), dim3(64), 0, st, B, frags, cmax, mu, d, n,
                      euclid);
   TPQ_LAUNCH_CHECK("assign_prep_kernel");
   const size_t lds = 2 * chunk_bytes(KS, NP);
@@ -406,8 +447,9 @@ static int run(const float* A, const float* B, float* vals, int64_t* inds, int d
   // dropped products: NP = 2: c2 a2 + r_c a + c r_a <= 3 x 2^-16 |a_k c_k| (1 % slack for the second-order
   // terms); NP = 3: c2 a3 + c3 a2 + c3 a3 <= 2^-23 |a_k c_k|
   const float eps_prod = NP == 2 ? 3.03f / 65536.0f : 1.01f / 8388608.0f;
-  FastArgs fa{A, frags, cmax, inds, vals, list, count, d, m, units_padded, euclid,
-              eps_prod + (float)(terms + 8) / 8388608.0f};
+  // (+ 8: the shift by mu rounds both operands once, 2^-23 (|a - mu| + |c - mu|)^2, and slack)
+  FastArgs fa{A, frags, cmax, mu, inds, vals, list, count, d, m, units_padded, euclid,
+              eps_prod + (float)(terms + 8) / 8388608.0f, (float)(d + 4) / 16777216.0f};
   const int per_block = kWaves * 32 * CT;
   hipLaunchKernelGGL(kernel, dim3((m + per_block - 1) / per_block), dim3(kWaves * 64), lds, st, fa);
   TPQ_LAUNCH_CHECK("assign_fast_kernel");
