@@ -17,7 +17,8 @@
 //      whole sweep and streams ALL centroid units through a double-buffered LDS ring filled by
 //      global_load_lds (LDS-DMA: no staging registers); per 16 dimensions and 32 x 32 tile the
 //      products c2 a1, c1 a2, c1 a1 (NP = 2) go through v_mfma_f32_32x32x16_bf16; the epilogue keeps
-//      the best AND the second-best fast value per point (5 VALU per value);
+//      the best AND the second-best fast value per point (4 VALU per value: compare, index select,
+//      median-of-three, max);
 //      delta = 1.25 [(eps_prod + (16 KS + 13) 2^-23) (|a - mu| + |c - mu|max)^2 + (d + 4) 2^-24 (|a| + |c|max)^2]
 //      (mu = mean centroid: distances are translation-invariant) covers the dropped products
 //      (c2 a2, r_c a, c r_a: 3 x 2^-16 |a_k c_k| per term at NP = 2), a worst-case (truncating) fp32 accumulation of all
@@ -60,14 +61,13 @@ __device__ __forceinline__ void split3(float x, __bf16& p1, __bf16& p2, __bf16& 
 template <int CL>
 __device__ __forceinline__ void take_top2(float& b1, float& b2, int& bi, float v) {
   static_assert(CL >= 0 && CL <= 64, "inline constant");
-  float t;
+  // b2' = median(b1, b2, v) (b1 >= b2: v >= b1 -> b1, b2 <= v < b1 -> v, v < b2 -> b2); b1' = max
   asm volatile(
-      "v_cmp_ngt_f32 vcc, %4, %0\n\t"
-      "v_cndmask_b32 %2, %5, %2, vcc\n\t"
-      "v_min_f32 %3, %4, %0\n\t"
-      "v_max_f32 %0, %4, %0\n\t"
-      "v_max_f32 %1, %1, %3"
-      : "+v"(b1), "+v"(b2), "+v"(bi), "=&v"(t)
+      "v_cmp_ngt_f32 vcc, %3, %0\n\t"
+      "v_cndmask_b32 %2, %4, %2, vcc\n\t"
+      "v_med3_f32 %1, %0, %1, %3\n\t"
+      "v_max_f32 %0, %3, %0"
+      : "+v"(b1), "+v"(b2), "+v"(bi)
       : "v"(v), "n"(CL)
       : "vcc");
 }
