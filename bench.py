@@ -375,9 +375,12 @@ def secondary_c5(device, stream_peak, iters=3):
     # the Lloyd loop of MultiKMeans.fit assigns with tpq_max_sim_split (exact 3-way bf16 split on the
     # bf16 matrix cores, fp32-level accuracy); predict / encode use the bit-exact fp32-MFMA kernel,
     # timed beside it
-    assign, assign_fp32 = K.MaxSimHip(distance="euclidean", precision="bf16x3"), K.MaxSimHip(distance="euclidean")
+    from torchpq_amd.clustering import MultiKMeans
+    mk = MultiKMeans(n_clusters=k)
+    path = mk._assign_path(l, d, n, k, training=True)
+    assign = lambda a, b, **_: mk.get_labels(a, b, training=True)  # noqa: E731  (what fit() runs)
+    assign_fp32 = K.MaxSimHip(distance="euclidean")
     update = K.ComputeCentroidsHip()
-    assert assign.split_supported(d, n, k)
     _, lab = assign(data, cent, dim=2, mode="tn")
     _, lab32 = assign_fp32(data, cent, dim=2, mode="tn")
     agree = float((lab == lab32).double().mean().item())
@@ -401,10 +404,12 @@ def secondary_c5(device, stream_peak, iters=3):
     byt = 4.0 * l * d * n
     tf = flop / t_assign / 1e9
     tf32 = flop / t_fp32 / 1e9
-    # matrix-pipe work actually issued: per 32 points x 32 centroids x 16 dimensions six piece-product
-    # MFMAs, plus one norm MFMA per 32 x 32 tile: (6 d/16 + 1) / (d/16) bf16 flops per algorithmic flop
+    # matrix-pipe work actually issued per 32 points x 32 centroids x 16 dimensions: three piece products
+    # (select: two-piece split, error-bounded selection + exact re-check) or six (bf16x3 split kernel),
+    # plus one norm MFMA per 32 x 32 tile
     ks = (d + 15) // 16
-    issue_ratio = (6.0 * ks + 1.0) / ks * (16.0 * ks / d)
+    prods = 3.0 if path == "select" else 6.0
+    issue_ratio = (prods * ks + 1.0) / ks * (16.0 * ks / d)
     peak_equiv = MFMA_BF16_PEAK_TFLOPS / issue_ratio
     out.update({
         "assign_ms": round(t_assign, 3), "update_ms": round(t_update, 3),
@@ -413,7 +418,11 @@ def secondary_c5(device, stream_peak, iters=3):
         "assign_labels_equal_to_fp32_kernel": round(agree, 6),
         "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": round(peak_equiv, 1),
                      "unit": "TFLOP/s", "frac": round(tf / peak_equiv, 4), "traffic": None,
-                     "kernel": "max_sim_split_kernel (bf16 MFMA, exact 3-way split, 6 piece products)",
+                     "kernel": ("select_resident_kernel + max_sim_kernel over the re-check lists (bf16 MFMA top-2 "
+                                "selection with an error bound, exact fp32 re-check: the fp32 kernel's labels)"
+                                if path == "select" else
+                                "max_sim_split_kernel (bf16 MFMA, exact 3-way split, 6 piece products)"),
+                     "assign_path": path,
                      "kernel_ms": round(t_assign, 3), "algorithmic_flops_per_launch": flop,
                      "issued_bf16_TFLOPs": round(tf * issue_ratio, 1), "bf16_dense_peak": MFMA_BF16_PEAK_TFLOPS,
                      "peak_note": f"fp32-equivalent: bf16 dense peak / {issue_ratio:.2f} MFMA flops issued per "

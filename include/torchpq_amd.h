@@ -267,6 +267,18 @@ size_t tpq_coarse_assign_count_offset(int d, int64_t m, int n);
 int tpq_coarse_assign(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n,
                       int metric, void* workspace, size_t workspace_bytes, tpq_stream_t stream);
 
+/* a-8 (training path, batched)  the labels of tpq_max_sim, bit for bit, for l codebook-sized problems
+ * replaces the max_sim call of the Lloyd loop, torchpq/clustering/MultiKMeans.py:415-453
+ * A f32 [l][d][m], B f32 [l][d][n], n <= 256, d <= 64 -> inds i64 [l][m] (exact) and, optionally, vals
+ * f32 [l][m] (the selection's fast maxima, ~1e-5 of the scale; exact for re-checked points).
+ * The error-bounded bf16 top-2 selection + exact re-check of tpq_coarse_assign with the centroids
+ * resident in LDS and the points streamed (the PQ-codebook training shape, configs[4]).
+ * workspace: tpq_max_sim_select_workspace_bytes(l, d, m, n) (dominated by the l x m int32 lists). */
+int tpq_max_sim_select_supported(int l, int d, int64_t m, int n);
+size_t tpq_max_sim_select_workspace_bytes(int l, int d, int64_t m, int n);
+int tpq_max_sim_select(const float* A, const float* B, float* vals, int64_t* inds, int l, int d, int64_t m,
+                       int n, int metric, void* workspace, size_t workspace_bytes, tpq_stream_t stream);
+
 /* a-9  k-means update
  * replaces ComputeCentroidsCuda.__call__  torchpq/kernels/ComputeCentroidsCuda.py:43-81
  *          kernel compute_centroids       torchpq/kernels/cuda/compute_centroids.cu:10-86

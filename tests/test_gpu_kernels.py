@@ -772,3 +772,37 @@ def test_coarse_assign_argument_errors(K):
     rc = lib.tpq_coarse_assign(_lib.ptr(A), _lib.ptr(B), None, _lib.ptr(out), 64, 800, 400, _lib.METRIC_NEG_SQ_L2,
                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(DEV))
     assert rc == 0 and int(out.abs().max()) == 0
+
+
+@pytest.mark.parametrize("l,d,m,n,kind", [(3, 64, 3000, 256, "gauss"), (2, 40, 2500, 200, "sift"),
+                                          (1, 17, 5000, 37, "gauss"), (2, 64, 700, 256, "ties"),
+                                          (2, 32, 600, 250, "crowded"), (4, 12, 300, 5, "gauss"),
+                                          (1, 48, 40, 256, "sift")])
+@pytest.mark.parametrize("distance", ["euclidean", "inner"])
+def test_max_sim_select_labels_equal_the_oracle(K, l, d, m, n, kind, distance):
+    """tpq_max_sim_select (batched, centroids resident): the bounded bf16 top-2 selection + exact
+    re-check gives the oracle's labels, bit for bit, for every sub-problem -- ragged shapes, exact
+    ties, points on centroids, single-ulp codebooks; the maxima it returns are within 2e-4."""
+    rng = np.random.default_rng(l * 100 + d * 7 + n)
+    As, Bs = zip(*[_coarse_case(rng, d, m, n, kind) for _ in range(l)])
+    A, B = np.stack(As), np.stack(Bs)
+    assert K.MaxSimSelectHip.supported(l, d, m, n)
+    v, i = K.MaxSimSelectHip(distance=distance)(T(A), T(B))
+    ev, ei = c_oracle.max_sim(A, B, distance, "expanded")
+    assert N(i).dtype == np.int64 and np.array_equal(N(i), ei)
+    scale = np.abs(ev).max() + 1e-6
+    assert np.abs(N(v) - ev).max() <= 2e-4 * max(scale, float((A * A).sum(1).max()))
+
+
+def test_max_sim_select_argument_errors(K):
+    from torchpq_amd import _lib
+    lib = _lib.load()
+    assert not K.MaxSimSelectHip.supported(2, 65, 100, 256)
+    assert not K.MaxSimSelectHip.supported(2, 64, 100, 257)
+    A, B = T(np.zeros((2, 64, 8), np.float32)), T(np.zeros((2, 64, 300), np.float32))
+    v = torch.empty(2, 8, device=DEV)
+    i = torch.empty(2, 8, device=DEV, dtype=torch.int64)
+    ws = torch.empty(1 << 20, device=DEV, dtype=torch.uint8)
+    rc = lib.tpq_max_sim_select(_lib.ptr(A), _lib.ptr(B), _lib.ptr(v), _lib.ptr(i), 2, 64, 8, 300,
+                                _lib.METRIC_NEG_SQ_L2, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(DEV))
+    assert rc == _lib.ERR_UNSUPPORTED and b"max_sim_select" in lib.tpq_last_error()

@@ -155,8 +155,9 @@ def test_fit_random_data_vs_oracle(l, d, n, k, steps, precision):
     data = rng.standard_normal((l, d, n)).astype(np.float32) * 3
     init = data[:, :, rng.choice(n, k, replace=False)].copy()
     mk = MultiKMeans(n_clusters=k, max_iter=steps, tol=0.0, assign_precision=precision)
-    used = mk._assign_kernel(d, n, k, training=True).precision
-    assert used == ("bf16x3" if precision == "bf16x3" and d >= mk.split_min_d else "fp32")
+    used = mk._assign_path(l, d, n, k, training=True)
+    want = "fp32" if precision == "fp32" or d < mk.split_min_d else ("select" if k <= 256 else "bf16x3")
+    assert used == want and mk._assign_path(l, d, n, k, training=False) == "fp32"
     labels = N(mk.fit(T(data), T(init)))
     cen = N(mk.centroids)
     o_cen, o_lab, _ = _oracle_fit(data, init, steps)

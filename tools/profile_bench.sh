@@ -21,7 +21,7 @@ for W in $WORKLOADS; do
     c2) BENCH="python ${ROOT}/bench.py --steps 20 --warmup 3 --no-secondary"; KERNEL="scan_packed_kernel";;
     c3) BENCH="python ${ROOT}/bench.py --secondary-only c3"; KERNEL="scan_packed_kernel";;
     c4) BENCH="python ${ROOT}/bench.py --secondary-only c4"; KERNEL="scan_packed_kernel";;
-    c5) BENCH="python ${ROOT}/bench.py --secondary-only c5"; KERNEL="max_sim_split_kernel";;
+    c5) BENCH="python ${ROOT}/bench.py --secondary-only c5"; KERNEL="select_resident_kernel";;
   esac
   $BENCH > "$OUT/bench.json" 2> "$OUT/bench.err"
   tail -c 600 "$OUT/bench.json"; echo

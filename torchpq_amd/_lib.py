@@ -52,6 +52,9 @@ SIGNATURES = {
     "tpq_max_sim": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tpq_max_sim_split_supported": (_i, [_i, _i64, _i]),
     "tpq_max_sim_split": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tpq_max_sim_select_supported": (_i, [_i, _i, _i64, _i]),
+    "tpq_max_sim_select_workspace_bytes": (_sz, [_i, _i, _i64, _i]),
+    "tpq_max_sim_select": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _vp, _sz, _vp]),
     "tpq_coarse_assign_supported": (_i, [_i, _i64, _i]),
     "tpq_coarse_assign_workspace_bytes": (_sz, [_i, _i64, _i]),
     "tpq_coarse_assign_count_offset": (_sz, [_i, _i64, _i]),

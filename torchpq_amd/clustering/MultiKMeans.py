@@ -1,8 +1,9 @@
 """Batched Lloyd k-means on the GPU (mirrors torchpq/clustering/MultiKMeans.py:13-496).
 
-Assign = tpq_max_sim (fp32 MFMA, bit-exact against the oracle) for predict / encode and, inside
-fit(), tpq_max_sim_split (exact 3-way bf16 split on the bf16 matrix cores, fp32-level accuracy,
-1.8x faster at the PQ-codebook shape) where it applies; update = tpq_compute_centroids; the
+Assign = tpq_max_sim (fp32 MFMA, bit-exact against the oracle) for predict / encode; inside fit()
+the bf16 matrix cores where they apply (`_assign_path`): bounded selection + exact re-check with
+the fp32 kernel's labels (tpq_max_sim_select, tpq_coarse_assign), or the 3-way split kernel
+(tpq_max_sim_split, fp32-level accuracy); update = tpq_compute_centroids; the
 Python below is only the Lloyd driver of the reference (fit :415-453, initialize_centroids :270-289).
 """
 from time import time
@@ -12,7 +13,7 @@ import torch
 
 from .. import metric
 from ..CustomModule import CustomModule
-from ..kernels import CoarseAssignHip, ComputeCentroidsHip, MaxSimHip
+from ..kernels import CoarseAssignHip, ComputeCentroidsHip, MaxSimHip, MaxSimSelectHip
 
 
 class MultiKMeans(CustomModule):
@@ -43,6 +44,7 @@ class MultiKMeans(CustomModule):
         self.assign_precision = assign_precision
         self.max_sim_hip = MaxSimHip(dim=2, distance=distance)
         self.max_sim_split_hip = MaxSimHip(dim=2, distance=distance, precision="bf16x3")
+        self.max_sim_select_hip = MaxSimSelectHip(distance="euclidean" if distance == "euclidean" else "inner")
         self.compute_centroids_hip = ComputeCentroidsHip()
 
     # -- memory helpers of the reference's public surface (:117-139); nothing here chunks by them:
@@ -125,11 +127,24 @@ class MultiKMeans(CustomModule):
     # kernel pads every problem to K = 16 (6 + 1 bf16 MFMAs of 32 cycles against d/2 fp32 MFMAs of 64)
     split_min_d = 12
 
-    def _assign_kernel(self, d, n, k, training):
-        if (training and self.assign_precision == "bf16x3" and d >= self.split_min_d
-                and MaxSimHip.split_supported(d, n, k)):
-            return self.max_sim_split_hip
-        return self.max_sim_hip
+    def _assign_path(self, l, d, n, k, training):
+        """which kernel the assign step runs on:
+        "select"  codebook-sized problems (k <= 256, split_min_d <= d <= 64) inside fit():
+                  tpq_max_sim_select -- bounded bf16 top-2 selection + exact re-check: the fp32
+                  kernel's labels, bit for bit; maxima approximate (used for the inertia only);
+        "coarse"  one problem with many centroids inside fit(): tpq_coarse_assign, same guarantees;
+        "bf16x3"  other shapes with d <= 64 inside fit(): tpq_max_sim_split (fp32-level accuracy,
+                  near-ties may resolve differently);
+        "fp32"    everything else, and always outside fit(): the bit-exact kernel."""
+        if not training or self.assign_precision != "bf16x3":
+            return "fp32"
+        if k <= 256 and d >= self.split_min_d and MaxSimSelectHip.supported(l, d, n, k):
+            return "select"
+        if (l == 1 and k >= 64 and n * k * d >= self.coarse_min_work and CoarseAssignHip.supported(d, n, k)):
+            return "coarse"
+        if d >= self.split_min_d and MaxSimHip.split_supported(d, n, k):
+            return "bf16x3"
+        return "fp32"
 
     # a single problem with many centroids (the coarse quantiser's training): the Lloyd loop takes its
     # labels from tpq_coarse_assign -- the fp32 kernel's labels, bit for bit, 3-4x faster; the
@@ -145,12 +160,14 @@ class MultiKMeans(CustomModule):
             centroids = centroids / (centroids.norm(dim=-2, keepdim=True) + 1e-8)
         l, d, n = data.shape
         k = centroids.shape[2]
-        if (training and l == 1 and self.assign_precision == "bf16x3" and k >= 64
-                and n * k * d >= self.coarse_min_work and CoarseAssignHip.supported(d, n, k)):
+        path = self._assign_path(l, d, n, k, training)
+        if path == "select":
+            return self.max_sim_select_hip(data, centroids)
+        if path == "coarse":
             op = CoarseAssignHip(distance="euclidean" if self.distance == "euclidean" else "inner")
             vals, labels = op(data[0], centroids[0], return_vals=True)
             return vals[None], labels[None]
-        kernel = self._assign_kernel(data.shape[1], data.shape[2], centroids.shape[2], training)
+        kernel = self.max_sim_split_hip if path == "bf16x3" else self.max_sim_hip
         return kernel(data, centroids, dim=2, mode="tn")
 
     def compute_centroids(self, data, labels):
@@ -181,6 +198,7 @@ class MultiKMeans(CustomModule):
                 best = (inertia, centroids, labels)
             centroids = None
         self.register_buffer("centroids", best[1])
+        self.max_sim_select_hip.release()  # its l x n int32 lists
         self.print_message(
             f"finished {self.n_redo} redos in {round(time() - tm, 4)} sec, final_inertia: {best[0]}", 1)
         return best[2]

@@ -33,7 +33,7 @@
 #include "common.h"
 
 namespace tpq {
-int launch_max_sim_list(const float* A, const float* B, float* vals, int64_t* inds, int d, int m, int n,
+int launch_max_sim_list(const float* A, const float* B, float* vals, int64_t* inds, int l, int d, int m, int n,
                         int euclid, const int* list, const int* count, hipStream_t st);  // kmeans.hip
 namespace afast {
 
@@ -88,10 +88,13 @@ constexpr int n_products(int NP) { return NP == 2 ? 3 : 6; }
 // (|a - mu| + |c - mu|max)^2 instead of (|a| + |c|max)^2 -- 2-4x smaller on non-negative data such as
 // SIFT -- while the error of the exact chain, which works on the raw data, keeps the raw norms.
 // mu[k] = mean over the centroids of dimension k (one block per dimension); zero for inner product.
+// blockIdx.y = sub-problem: B + y d n, mu + y 256
 __global__ __launch_bounds__(256) void assign_mean_kernel(const float* __restrict__ B, float* __restrict__ mu,
                                                          int n, int euclid) {
   __shared__ float red[256];
   const int k = blockIdx.x;
+  B += (int64_t)blockIdx.y * gridDim.x * n;
+  mu += blockIdx.y * 256;
   float s = 0.f;
   if (euclid)
     for (int c = threadIdx.x; c < n; c += 256) s += B[(int64_t)k * n + c];
@@ -112,6 +115,11 @@ __global__ __launch_bounds__(64) void assign_prep_kernel(const float* __restrict
                                                         int euclid) {
   const int unit = blockIdx.x, lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
   const int c = unit * 32 + l31;
+  // blockIdx.y = sub-problem (tpq_max_sim_select): its own centroids, mean, maxima and fragment block
+  B += (int64_t)blockIdx.y * d * n;
+  mu += blockIdx.y * 256;
+  cmax2_bits += blockIdx.y * 2;
+  frags += (size_t)blockIdx.y * gridDim.x * frags_per_unit(KS, NP) * 64;
   bf16x8* out = frags + (size_t)unit * frags_per_unit(KS, NP) * 64 + lane;
   float s = 0.f, sraw = 0.f;  // |c - mu|^2 of the shifted centroid the fast path uses, and |c|^2
   if (c < n)
@@ -302,14 +310,15 @@ __global__ __launch_bounds__(kWaves * 64, 2) void assign_fast_kernel(FastArgs a)
           });
         });
       });
-      bf16x8 am[2];  // c1 of k-step s for the main pass, one k-step ahead
+      bf16x8 am[3];  // c1 of k-step s for the main pass, two k-steps (2 CT MFMAs) ahead
       am[0] = up[1 * 64];
+      if constexpr (KS > 1) am[1] = up[(1 + 2) * 64];
       static_for<0, KS>([&](auto s_c) {
         constexpr int st = decltype(s_c)::value;
-        if constexpr (st + 1 < KS) am[(st + 1) & 1] = up[(1 + (st + 1) * 2) * 64];
+        if constexpr (st + 2 < KS) am[(st + 2) % 3] = up[(1 + (st + 2) * 2) * 64];
         static_for<0, CT>([&](auto ct_c) {
           constexpr int ct = decltype(ct_c)::value;
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[st & 1], xs[ct][st][0], acc[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[st % 3], xs[ct][st][0], acc[ct], 0, 0, 0);
           slice(std::integral_constant<int, CT * (2 * KS + st) + ct>{});
         });
       });
@@ -399,6 +408,273 @@ __global__ __launch_bounds__(kWaves * 64, 2) void assign_fast_kernel(FastArgs a)
   }
 }
 
+// ---- 2b. the same selection for BATCHED codebook-sized problems (tpq_max_sim_select) -------------
+// PQ codebook training: l sub-problems, n <= 256 centroids each, d <= 64 -- the loop order of
+// kmeans_split.hip: the sub-problem's centroid fragments (72 KiB at d = 64) are brought into LDS ONCE
+// per block by LDS-DMA and every wave walks kSelTiles tiles of 32 points; the raw fragment of tile
+// t+1 is loaded under units 0-3 of tile t and centred + split under units 4-7.  Per 32 x 32 tile:
+// 2 KS correction MFMAs, KS main MFMAs, the -|c|^2 MFMA (13 at d = 64, against 25 in the six-product
+// training kernel and 32 fp32 MFMAs of twice the length in the exact one); top-2 epilogue, bound and
+// list exactly as in assign_fast_kernel, one list per sub-problem.
+struct SelArgs {
+  const float* A;        // [l][d][m]
+  const bf16x8* frags;   // [l][8 units][2 KS + 1][64]
+  const unsigned* cmax2_bits;  // [l][2]
+  const float* mu;       // [l][256]
+  int64_t* inds;         // [l][m]
+  float* vals;           // optional [l][m]
+  int* list;             // [l][m]
+  int* count;            // [l]
+  int d, m, euclid;
+  float eps, eps_exact;
+};
+#ifndef TPQ_SEL_TILES
+#define TPQ_SEL_TILES 32
+#endif
+constexpr int kSelTiles = TPQ_SEL_TILES;
+
+template <int KS>
+__global__ __launch_bounds__(kWaves * 64, 2) void select_resident_kernel(SelArgs a) {
+  constexpr int FPU = 2 * KS + 1;
+  constexpr int NM = 3 * KS + 1;  // MFMAs per unit
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const bf16x8* fr = reinterpret_cast<const bf16x8*>(smem);          // [8][FPU][64]
+  float* mu_s = reinterpret_cast<float*>(smem + 8 * FPU * 1024);     // [16 KS]
+  const int b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int m = a.m, d = a.d;
+  {
+    const char* src = reinterpret_cast<const char*>(a.frags) + (size_t)b * 8 * FPU * 1024;
+    for (int f = wave; f < 8 * FPU; f += kWaves)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(smem + f * 1024), 16, 0, 0);
+    if (threadIdx.x < 16 * KS) mu_s[threadIdx.x] = a.mu[b * 256 + threadIdx.x];
+  }
+  const float* __restrict__ Ab = a.A + (int64_t)b * d * m;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ab), 0, (int)((int64_t)d * m * 4), 0x00020000);
+  auto frag_offset = [&](int t, bool& iv, int& i) -> int {
+    const int tile = blockIdx.x * kSelTiles + t;
+    i = tile * (kWaves * 32) + wave * 32 + l31;
+    iv = (t < kSelTiles) && (i < m);
+    return iv ? (8 * half * m + i) * 4 : 0x7ffffff0;
+  };
+  const int row1 = m * 4, row9 = 9 * m * 4;
+  float xr[KS * 8];
+  bf16x8 xs[KS][2], xsn[KS][2];
+  float a2c = 0.f, a2r = 0.f, a2cn = 0.f, a2rn = 0.f;  // |a - mu|^2, |a|^2 halves: current / next tile
+  bool iv, ivn = false;
+  int i, in_ = 0;
+  __syncthreads();  // fragments (vmcnt(0) of the DMA) and mu_s are in LDS
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  // this lane's 8 centring values of k-step st (two ds_read_b128)
+  auto load_mu = [&](int st, float (&mk)[8]) {
+    const f32x4v lo = *reinterpret_cast<const f32x4v*>(mu_s + 16 * st + 8 * half);
+    const f32x4v hi = *reinterpret_cast<const f32x4v*>(mu_s + 16 * st + 8 * half + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mk[j] = lo[j];
+      mk[4 + j] = hi[j];
+    }
+  };
+  // No predicate here: a lane without a point reads zeros and ends up with -mu in its operand -- its
+  // results are never written; dimensions beyond d read 0 on both sides (mu is 0 there).  (With a
+  // select on validity the compiler branched around every element: 73 exec-mask branches per tile.)
+  auto split_elem = [&](auto s_c, auto j_c, bf16x8 (&dst)[KS][2], float& c2, float& r2, float muv) {
+    constexpr int st = decltype(s_c)::value, j = decltype(j_c)::value;
+    const float x = xr[st * 8 + j];
+    const float xc = x - muv;
+    __bf16 h, mm, lo;
+    split3(xc, h, mm, lo);
+    dst[st][0][j] = h;
+    dst[st][1][j] = mm;
+    c2 = fmaf(xc, xc, c2);
+    r2 = fmaf(x, x, r2);
+  };
+  {
+    int voff = frag_offset(0, iv, i);
+#pragma unroll
+    for (int e = 0; e < KS * 8; ++e) {
+      xr[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, 0, 0));
+      voff += (e & 7) == 7 ? row9 : row1;
+    }
+    static_for<0, KS>([&](auto s_c) {
+      float mk[8];
+      load_mu(decltype(s_c)::value, mk);
+      static_for<0, 8>([&](auto j_c) { split_elem(s_c, j_c, xs, a2c, a2r, mk[decltype(j_c)::value]); });
+    });
+  }
+  f32x16 accA, accB;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accB[r] = -INFINITY;
+  // two independent top-2 chains (even / odd accumulator registers): one chain of 128 dependent
+  // updates per tile left the wave waiting on its own VALU results; merged when the tile is finished
+  float b1[2] = {-INFINITY, -INFINITY}, b2[2] = {-INFINITY, -INFINITY};
+  int bi[2] = {0, 0}, bu[2] = {0, 0};
+  float a2c_prev = 0.f, a2r_prev = 0.f;
+  bool iv_prev = false;
+  int i_prev = 0;
+  const bf16x8* fp = fr + lane;
+  bf16x8 c1k[KS], c2r[3];  // A operands (see `unit`)
+  c1k[0] = fp[1 * 64];
+  c2r[0] = fp[2 * 64];
+  if constexpr (KS > 1) {
+    c1k[1] = fp[3 * 64];
+    c2r[1] = fp[4 * 64];
+  }
+  bf16x8 bones = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (half == 0) {
+    bones[0] = (__bf16)1.0f;
+    bones[1] = (__bf16)1.0f;
+    bones[2] = (__bf16)1.0f;
+  }
+  const float cn = sqrtf(__uint_as_float(a.cmax2_bits[b * 2])), cnr = sqrtf(__uint_as_float(a.cmax2_bits[b * 2 + 1]));
+
+  auto finish_tile = [&](bool fiv, int fi, float c2own, float r2own) {
+    // merge the two chains, then the two half-waves (disjoint centroid rows of the same point)
+    const int ia = bu[0] * 32 + bi[0] + 4 * half, ib = bu[1] * 32 + bi[1] + 4 * half;
+    const bool tb = b1[1] > b1[0] || (b1[1] == b1[0] && ib < ia);
+    int idx = tb ? ib : ia;
+    const float m1 = fmaxf(b1[0], b1[1]);
+    const float m2 = fmaxf(fminf(b1[0], b1[1]), fmaxf(b2[0], b2[1]));
+    const float o1 = __shfl_xor(m1, 32, 64), o2 = __shfl_xor(m2, 32, 64);
+    const int oi = __shfl_xor(idx, 32, 64);
+    const float an2 = c2own + __shfl_xor(c2own, 32, 64), an2raw = r2own + __shfl_xor(r2own, 32, 64);
+    const float B1 = fmaxf(m1, o1);
+    const float B2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
+    if (o1 > m1 || (o1 == m1 && oi < idx)) idx = oi;
+    if (half == 0 && fiv) {
+      const float an = sqrtf(an2), anr = sqrtf(an2raw);
+      const float delta = 1.25f * (a.euclid ? a.eps * (an + cn) * (an + cn) + a.eps_exact * (anr + cnr) * (anr + cnr)
+                                            : (a.eps + a.eps_exact) * anr * cnr);
+      a.inds[(int64_t)b * m + fi] = idx;
+      if (a.vals) a.vals[(int64_t)b * m + fi] = a.euclid ? B1 - an2 : B1;
+      if (!(B1 - B2 > 2.f * delta)) a.list[(int64_t)b * m + atomicAdd(a.count + b, 1)] = fi;
+    }
+  };
+
+  // unit U into `acc`; the 16 values of `fin` (unit uid_fin of the tile, or the last unit of the previous
+  // tile under unit 0) go through the top-2 update between the MFMAs
+  auto unit = [&](auto u_c, f32x16& acc, const f32x16& fin, int& voff_next, const bf16x8 (&xs)[KS][2],
+                  bf16x8 (&xsn)[KS][2], float& c2n, float& r2n) {
+    constexpr int U = decltype(u_c)::value, FU = (U + 7) & 7;
+    const bf16x8* up = fp + U * FPU * 64;
+    const bf16x8* upn = fp + ((U + 1) & 7) * FPU * 64;  // the next unit (unit 0 of the next tile after 7)
+    const float before0 = b1[0], before1 = b1[1];
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16x8 cfrag = up[0];
+    float mk[8];
+    if constexpr (U >= 4 && U - 4 < KS) load_mu(U - 4, mk);
+    auto fill = [&](auto mi_c) {
+      constexpr int mi = decltype(mi_c)::value;
+      if constexpr (mi >= 2) {
+        constexpr int lo = ((mi - 2) * 16) / (NM - 2), hi = ((mi - 1) * 16) / (NM - 2);
+        static_for<lo, hi>([&](auto r_c) {
+          constexpr int r = decltype(r_c)::value;
+          take_top2<(r & 3) + 8 * (r >> 2)>(b1[r & 1], b2[r & 1], bi[r & 1], fin[r]);
+        });
+      }
+      if constexpr (U < 4) {  // next tile's raw fragment: 2 KS loads per unit
+        constexpr int per = 2 * KS;
+        constexpr int l0 = (mi * per) / NM, l1 = ((mi + 1) * per) / NM;
+        static_for<l0, l1>([&](auto e_c) {
+          constexpr int e = U * per + decltype(e_c)::value;
+          xr[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff_next, 0, 0));
+          voff_next += (e & 7) == 7 ? row9 : row1;
+        });
+      }
+      if constexpr (U >= 4 && U - 4 < KS) {  // ... centred and split under units 4..7
+        constexpr int j0 = (mi * 8) / NM, j1 = ((mi + 1) * 8) / NM;
+        static_for<j0, j1>([&](auto j_c) {
+          split_elem(std::integral_constant<int, U - 4>{}, j_c, xsn, c2n, r2n, mk[decltype(j_c)::value]);
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // small products first (see assign_fast_kernel): corrections, main, -|c|^2.  A operands: c1 of
+    // every k-step stays in registers from the correction pass to the main pass (c1k), c2 runs
+    // through a 3-slot ring two k-steps ahead (c2r); the first two k-steps of the NEXT unit are
+    // fetched during this unit's main pass, as their registers fall free.  (One k-step ahead, and
+    // the main pass reloading c1, put an LDS round trip in front of every MFMA of the main pass.)
+    static_for<0, KS>([&](auto s_c) {
+      constexpr int st = decltype(s_c)::value;
+      if constexpr (st + 2 < KS) {
+        c1k[st + 2] = up[(1 + (st + 2) * 2) * 64];
+        c2r[(st + 2) % 3] = up[(2 + (st + 2) * 2) * 64];
+      }
+      if constexpr (st == 0) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2r[0], xs[0][0], zero, 0, 0, 0);
+      } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c2r[st % 3], xs[st][0], acc, 0, 0, 0);
+      }
+      fill(std::integral_constant<int, 2 * st>{});
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1k[st], xs[st][1], acc, 0, 0, 0);
+      fill(std::integral_constant<int, 2 * st + 1>{});
+    });
+    c2r[0] = upn[2 * 64];
+    if constexpr (KS > 1) c2r[1] = upn[(2 + 2) * 64];
+    static_for<0, KS>([&](auto s_c) {
+      constexpr int st = decltype(s_c)::value;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1k[st], xs[st][0], acc, 0, 0, 0);
+      if constexpr (st < 2) c1k[st] = upn[(1 + st * 2) * 64];
+      fill(std::integral_constant<int, 2 * KS + st>{});
+    });
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, acc, 0, 0, 0);
+    fill(std::integral_constant<int, 3 * KS>{});
+    bu[0] = b1[0] > before0 ? FU : bu[0];
+    bu[1] = b1[1] > before1 ? FU : bu[1];
+  };
+  using std::integral_constant;
+
+  bool have_prev = false;
+  auto tile = [&](int t, const bf16x8 (&cur)[KS][2], bf16x8 (&nxt)[KS][2], float c2cur, float r2cur, float& c2nxt,
+                  float& r2nxt) {
+    int voff_next = frag_offset(t + 1, ivn, in_);
+    c2nxt = 0.f;
+    r2nxt = 0.f;
+    unit(integral_constant<int, 0>{}, accA, accB, voff_next, cur, nxt, c2nxt, r2nxt);
+    if (have_prev) finish_tile(iv_prev, i_prev, a2c_prev, a2r_prev);
+    b1[0] = b1[1] = b2[0] = b2[1] = -INFINITY;
+    bi[0] = bi[1] = bu[0] = bu[1] = 0;
+    unit(integral_constant<int, 1>{}, accB, accA, voff_next, cur, nxt, c2nxt, r2nxt);
+    unit(integral_constant<int, 2>{}, accA, accB, voff_next, cur, nxt, c2nxt, r2nxt);
+    unit(integral_constant<int, 3>{}, accB, accA, voff_next, cur, nxt, c2nxt, r2nxt);
+    unit(integral_constant<int, 4>{}, accA, accB, voff_next, cur, nxt, c2nxt, r2nxt);
+    unit(integral_constant<int, 5>{}, accB, accA, voff_next, cur, nxt, c2nxt, r2nxt);
+    unit(integral_constant<int, 6>{}, accA, accB, voff_next, cur, nxt, c2nxt, r2nxt);
+    unit(integral_constant<int, 7>{}, accB, accA, voff_next, cur, nxt, c2nxt, r2nxt);
+    a2c_prev = c2cur;
+    a2r_prev = r2cur;
+    iv_prev = iv;
+    i_prev = i;
+    have_prev = true;
+    iv = ivn;
+    i = in_;
+  };
+#pragma unroll 1
+  for (int t = 0; t < kSelTiles; t += 2) {
+    if ((blockIdx.x * kSelTiles + t) * (kWaves * 32) >= m) break;
+    tile(t, xs, xsn, a2c, a2r, a2cn, a2rn);
+    if (t + 1 >= kSelTiles || (blockIdx.x * kSelTiles + t + 1) * (kWaves * 32) >= m) break;
+    tile(t + 1, xsn, xs, a2cn, a2rn, a2c, a2r);
+  }
+  if (have_prev) {  // the last unit of the last tile (plain code: these reads follow the MFMA directly)
+    const float before0 = b1[0], before1 = b1[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = accB[r];
+      const float t = fminf(v, b1[r & 1]);
+      if (v > b1[r & 1]) bi[r & 1] = (r & 3) + 8 * (r >> 2);
+      b1[r & 1] = fmaxf(v, b1[r & 1]);
+      b2[r & 1] = fmaxf(b2[r & 1], t);
+    }
+    bu[0] = b1[0] > before0 ? 7 : bu[0];
+    bu[1] = b1[1] > before1 ? 7 : bu[1];
+    finish_tile(iv_prev, i_prev, a2c_prev, a2r_prev);
+  }
+}
+
 // ---- 3. exact re-check: max_sim_kernel (kmeans.hip, the bit-exact fp32-MFMA kernel) over the list ----
 struct Layout {
   size_t frags_off, frags_bytes, cmax_off, count_off, mu_off, list_off, total;
@@ -453,13 +729,95 @@ static int run(const float* A, const float* B, float* vals, int64_t* inds, int d
   const int per_block = kWaves * 32 * CT;
   hipLaunchKernelGGL(kernel, dim3((m + per_block - 1) / per_block), dim3(kWaves * 64), lds, st, fa);
   TPQ_LAUNCH_CHECK("assign_fast_kernel");
-  return launch_max_sim_list(A, B, vals, inds, d, m, n, euclid, list, count, st);
+  return launch_max_sim_list(A, B, vals, inds, 1, d, m, n, euclid, list, count, st);
+}
+
+struct SelLayout {
+  size_t frags_bytes, cmax_off, count_off, mu_off, list_off, total;
+};
+static SelLayout sel_layout(int KS, int l, int64_t m) {
+  SelLayout L;
+  L.frags_bytes = (size_t)l * 8 * (2 * KS + 1) * 1024;
+  L.cmax_off = L.frags_bytes;                          // [l][2] u32
+  L.count_off = L.cmax_off + (size_t)l * 8;            // [l] i32
+  L.mu_off = (L.count_off + (size_t)l * 4 + 255) / 256 * 256;  // [l][256] f32
+  L.list_off = L.mu_off + (size_t)l * 1024;            // [l][m] i32
+  L.total = L.list_off + (size_t)l * m * 4;
+  return L;
+}
+
+template <int KS>
+static int run_select(const float* A, const float* B, float* vals, int64_t* inds, int l, int d, int m, int n,
+                      int euclid, char* ws, hipStream_t st) {
+  const SelLayout L = sel_layout(KS, l, m);
+  bf16x8* frags = reinterpret_cast<bf16x8*>(ws);
+  unsigned* cmax = reinterpret_cast<unsigned*>(ws + L.cmax_off);
+  int* count = reinterpret_cast<int*>(ws + L.count_off);
+  float* mu = reinterpret_cast<float*>(ws + L.mu_off);
+  int* list = reinterpret_cast<int*>(ws + L.list_off);
+  int rc = check_hip(hipMemsetAsync(ws + L.cmax_off, 0, L.list_off - L.cmax_off, st), "max_sim_select memset");
+  if (rc) return rc;
+  hipLaunchKernelGGL(assign_mean_kernel, dim3(d, l), dim3(256), 0, st, B, mu, n, euclid);
+  TPQ_LAUNCH_CHECK("assign_mean_kernel");
+  hipLaunchKernelGGL((assign_prep_kernel<KS, 2>), dim3(8, l), dim3(64), 0, st, B, frags, cmax, mu, d, n, euclid);
+  TPQ_LAUNCH_CHECK("assign_prep_kernel");
+  const size_t lds = (size_t)8 * (2 * KS + 1) * 1024 + 16 * KS * 4;
+  auto kernel = select_resident_kernel<KS>;
+  rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                 "select_resident_kernel attr");
+  if (rc) return rc;
+  const int terms = KS * 16 + 2 + 3;
+  SelArgs sa{A, frags, cmax, mu, inds, vals, list, count, d, m, euclid,
+             3.03f / 65536.0f + (float)(terms + 8) / 8388608.0f, (float)(d + 4) / 16777216.0f};
+  const int per_block = kWaves * 32 * kSelTiles;
+  hipLaunchKernelGGL(kernel, dim3((m + per_block - 1) / per_block, l), dim3(kWaves * 64), lds, st, sa);
+  TPQ_LAUNCH_CHECK("select_resident_kernel");
+  return launch_max_sim_list(A, B, vals, inds, l, d, m, n, euclid, list, count, st);
 }
 
 }  // namespace afast
 }  // namespace tpq
 
 using namespace tpq;
+
+static int sel_ks(int d) { return d <= 16 ? 1 : (d <= 32 ? 2 : (d <= 48 ? 3 : 4)); }
+
+extern "C" int tpq_max_sim_select_supported(int l, int d, int64_t m, int n) {
+  return (l >= 1 && l <= 65535 && d >= 1 && d <= 64 && n >= 1 && n <= 256 && m >= 0 && m < (1LL << 31) &&
+          (int64_t)sel_ks(d) * 16 * m * 4 <= 0x7fffffffLL)
+             ? 1
+             : 0;
+}
+
+extern "C" size_t tpq_max_sim_select_workspace_bytes(int l, int d, int64_t m, int n) {
+  if (!tpq_max_sim_select_supported(l, d, m, n)) return 0;
+  return afast::sel_layout(sel_ks(d), l, m).total;
+}
+
+extern "C" int tpq_max_sim_select(const float* A, const float* B, float* vals, int64_t* inds, int l, int d,
+                                  int64_t m, int n, int metric, void* workspace, size_t workspace_bytes,
+                                  tpq_stream_t stream) {
+  TPQ_REQUIRE(A && B && inds, "max_sim_select: null pointer");
+  TPQ_REQUIRE(metric == TPQ_METRIC_NEG_SQ_L2 || metric == TPQ_METRIC_INNER, "max_sim_select: bad metric %d", metric);
+  if (!tpq_max_sim_select_supported(l, d, m, n)) {
+    set_error("max_sim_select: shape l=%d d=%d m=%lld n=%d not supported (d <= 64, n <= 256); use tpq_max_sim", l, d,
+              (long long)m, n);
+    return TPQ_ERR_UNSUPPORTED;
+  }
+  if (m == 0) return TPQ_OK;
+  const size_t need = tpq_max_sim_select_workspace_bytes(l, d, m, n);
+  TPQ_REQUIRE(workspace && workspace_bytes >= need, "max_sim_select: workspace of %zu bytes needed", need);
+  const int euclid = metric == TPQ_METRIC_NEG_SQ_L2 ? 1 : 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  switch (sel_ks(d)) {
+    case 1: return afast::run_select<1>(A, B, vals, inds, l, d, (int)m, n, euclid, ws, st);
+    case 2: return afast::run_select<2>(A, B, vals, inds, l, d, (int)m, n, euclid, ws, st);
+    case 3: return afast::run_select<3>(A, B, vals, inds, l, d, (int)m, n, euclid, ws, st);
+    default: return afast::run_select<4>(A, B, vals, inds, l, d, (int)m, n, euclid, ws, st);
+  }
+}
 
 #ifndef TPQ_AF_NP
 #define TPQ_AF_NP 2

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
   const int pos = blockIdx.x * 128 + wave * 32 + l31;  // this lane's point (position in the list)
   int m_eff = m;
   if (list) {
-    m_eff = *count;
+    list += (int64_t)b * m;  // one list per sub-problem
+    m_eff = count[b];
     m_eff = m_eff < m ? m_eff : m;
     if ((int)blockIdx.x * 128 >= m_eff) return;  // block-uniform
   }
@@ -246,15 +247,16 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
   }
 }
 
-// the exact kernel over a device-side list of points (one problem): see tpq_coarse_assign
-int launch_max_sim_list(const float* A, const float* B, float* vals, int64_t* inds, int d, int m, int n,
+// the exact kernel over device-side lists of points (list [l][m], count [l]): see tpq_coarse_assign /
+// tpq_max_sim_select
+int launch_max_sim_list(const float* A, const float* B, float* vals, int64_t* inds, int l, int d, int m, int n,
                         int euclid, const int* list, const int* count, hipStream_t st) {
   const size_t ms_lds = (size_t)(2 * kMsSlab + kMsCent) * sizeof(float);
   int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(max_sim_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ms_lds),
                      "max_sim_kernel attr");
   if (rc) return rc;
-  hipLaunchKernelGGL(max_sim_kernel, dim3((m + 127) / 128, 1), dim3(256), ms_lds, st, A, B, vals, inds, d,
+  hipLaunchKernelGGL(max_sim_kernel, dim3((m + 127) / 128, l), dim3(256), ms_lds, st, A, B, vals, inds, d,
                      m, n, euclid, list, count);
   TPQ_LAUNCH_CHECK("max_sim_kernel (list)");
   return TPQ_OK;

@@ -564,6 +564,46 @@ class CoarseAssignHip:
         return int(ws[off:off + 4].view(torch.int32).item())
 
 
+class MaxSimSelectHip:
+    """(vals, labels) for l codebook-sized problems (n <= 256 centroids, d <= 64): A [l, d, m], B [l, d, n].
+    Labels are MaxSimHip's (fp32), bit for bit; vals are the selection's fast maxima, exact only for
+    re-checked points (tpq_max_sim_select: bounded bf16 top-2 selection + exact re-check)."""
+
+    def __init__(self, distance="euclidean", **_):
+        assert distance in ("euclidean", "inner", "cosine")
+        self.distance = distance
+        self._ws = None
+
+    @staticmethod
+    def supported(l, d, m, n):
+        return bool(load().tpq_max_sim_select_supported(int(l), int(d), int(m), int(n)))
+
+    def __call__(self, A, B):
+        assert A.dim() == 3 and B.dim() == 3 and A.shape[:2] == B.shape[:2]
+        assert A.dtype == B.dtype == torch.float32
+        A = A.contiguous()
+        B = B.contiguous()
+        require_gpu(A, B)
+        l, d, m = A.shape
+        n = B.shape[2]
+        lib = load()
+        vals = torch.empty(l, m, device=A.device, dtype=torch.float32)
+        inds = torch.empty(l, m, device=A.device, dtype=torch.int64)
+        ws_bytes = lib.tpq_max_sim_select_workspace_bytes(l, d, m, n)
+        if self._ws is None or self._ws.numel() < ws_bytes or self._ws.device != A.device:
+            self._ws = None
+            self._ws = torch.empty(max(ws_bytes, 1), device=A.device, dtype=torch.uint8)
+        metric = _lib.METRIC_NEG_SQ_L2 if self.distance == "euclidean" else _lib.METRIC_INNER
+        with torch.cuda.device(A.device):
+            check(lib.tpq_max_sim_select(ptr(A), ptr(B), ptr(vals), ptr(inds), l, d, m, n, metric,
+                                         ptr(self._ws), ws_bytes, stream_ptr(A.device)), "tpq_max_sim_select")
+        return vals, inds
+
+    def release(self):
+        """drop the cached workspace (l x m int32 lists)"""
+        self._ws = None
+
+
 class ComputeCentroidsHip:
     """K-means update (kernels/ComputeCentroidsCuda.py:43-81): data [l, d, n], labels [l, n]
     -> centroids [l, d, k]; empty clusters -> 0."""
