@@ -72,6 +72,25 @@ __device__ __forceinline__ void take_top2(float& b1, float& b2, int& bi, float v
       : "vcc");
 }
 
+// two values, two INDEPENDENT chains, one block (separate asm statements get a wait state between them)
+template <int CL0, int CL1>
+__device__ __forceinline__ void take_top2_pair(float& p1, float& p2, int& pi, float& q1, float& q2, int& qi,
+                                               float v0, float v1) {
+  static_assert(CL0 >= 0 && CL0 <= 64 && CL1 >= 0 && CL1 <= 64, "inline constants");
+  asm volatile(
+      "v_cmp_ngt_f32 vcc, %6, %0\n\t"
+      "v_cndmask_b32 %2, %8, %2, vcc\n\t"
+      "v_cmp_ngt_f32 vcc, %7, %3\n\t"
+      "v_cndmask_b32 %5, %9, %5, vcc\n\t"
+      "v_med3_f32 %1, %0, %1, %6\n\t"
+      "v_med3_f32 %4, %3, %4, %7\n\t"
+      "v_max_f32 %0, %6, %0\n\t"
+      "v_max_f32 %3, %7, %3"
+      : "+v"(p1), "+v"(p2), "+v"(pi), "+v"(q1), "+v"(q2), "+v"(qi)
+      : "v"(v0), "v"(v1), "n"(CL0), "n"(CL1)
+      : "vcc");
+}
+
 constexpr int kUnitsPerChunk = 4;  // 128 centroids per LDS buffer
 constexpr int kWaves = 8;
 constexpr int frags_per_unit(int KS, int NP) { return KS * NP + 1; }  // + the -|c|^2 fragment
@@ -489,8 +508,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void select_resident_kernel(SelArgs
     split3(xc, h, mm, lo);
     dst[st][0][j] = h;
     dst[st][1][j] = mm;
-    c2 = fmaf(xc, xc, c2);
-    r2 = fmaf(x, x, r2);
+    // (asm: left to the compiler the two norm chains are packed into v_pk_fma_f32 with a v_mov per
+    // operand pair -- 76 moves per tile)
+    asm("v_fmac_f32 %0, %1, %1" : "+v"(c2) : "v"(xc));
+    asm("v_fmac_f32 %0, %1, %1" : "+v"(r2) : "v"(x));
   };
   {
     int voff = frag_offset(0, iv, i);
@@ -570,9 +591,15 @@ __global__ __launch_bounds__(kWaves * 64, 2) void select_resident_kernel(SelArgs
       constexpr int mi = decltype(mi_c)::value;
       if constexpr (mi >= 2) {
         constexpr int lo = ((mi - 2) * 16) / (NM - 2), hi = ((mi - 1) * 16) / (NM - 2);
+        // values lo..hi-1: even registers feed chain 0, odd ones chain 1; adjacent pairs in one block
         static_for<lo, hi>([&](auto r_c) {
           constexpr int r = decltype(r_c)::value;
-          take_top2<(r & 3) + 8 * (r >> 2)>(b1[r & 1], b2[r & 1], bi[r & 1], fin[r]);
+          if constexpr ((r & 1) == 0 && r + 1 < hi) {
+            take_top2_pair<(r & 3) + 8 * (r >> 2), ((r + 1) & 3) + 8 * ((r + 1) >> 2)>(
+                b1[0], b2[0], bi[0], b1[1], b2[1], bi[1], fin[r], fin[r + 1]);
+          } else if constexpr ((r & 1) == 0 || r == lo) {
+            take_top2<(r & 3) + 8 * (r >> 2)>(b1[r & 1], b2[r & 1], bi[r & 1], fin[r]);
+          }
         });
       }
       if constexpr (U < 4) {  // next tile's raw fragment: 2 KS loads per unit
