@@ -645,8 +645,8 @@ def main():
         "roofline": roofline,
     }
     if rank == 0:
-        out["train_s"] = round(t_train, 2)
-        out["add_s"] = round(t_add, 2)
+        out["train_s"] = round(t_train, 3)
+        out["add_s"] = round(t_add, 3)
         if base is not None:
             # recall@k = the true nearest neighbour (exact L2 on the raw vectors) is in the top-k:
             # the reference benchmark's definition, on a 1000-query sample

@@ -105,3 +105,36 @@ def test_bench_launch_command_and_defaults():
     a = bench.parse_args(["--workload", "c4", "--gpus", "8"])
     assert (a.n_base, a.n_cells, a.n_probe) == (100_000_000, 16384, 64)
     assert len(bench.source_fingerprint()) == 16
+
+
+def test_assign_path_policy_and_host_side_shape_functions():
+    """which kernel the Lloyd loop's assign runs on (MultiKMeans._assign_path) and the pure host
+    functions behind it (no GPU needed: *_supported / *_workspace_bytes only inspect shapes)"""
+    from torchpq_amd import _lib
+    from torchpq_amd.clustering import MultiKMeans
+    lib = _lib.load()
+    mk = MultiKMeans(n_clusters=256)
+    # codebook-sized problems inside fit(): exact-label selection kernel; outside fit(): fp32
+    assert mk._assign_path(64, 64, 1_000_000, 256, training=True) == "select"
+    assert mk._assign_path(64, 64, 1_000_000, 256, training=False) == "fp32"
+    assert mk._assign_path(64, 2, 100_000, 256, training=True) == "fp32"       # SIFT's d_sub = 2
+    assert mk._assign_path(120, 8, 100_000, 256, training=True) == "fp32"      # GIST's d_sub = 8
+    # one problem, many centroids: coarse assign; batched with > 256 centroids: split kernel
+    assert mk._assign_path(1, 128, 1_000_000, 16384, training=True) == "coarse"
+    assert mk._assign_path(1, 960, 500_000, 1024, training=True) == "fp32"     # d > 128
+    assert mk._assign_path(4, 64, 100_000, 512, training=True) == "bf16x3"
+    assert MultiKMeans(n_clusters=256, assign_precision="fp32")._assign_path(64, 64, 10 ** 6, 256, True) == "fp32"
+    # shape functions
+    assert lib.tpq_max_sim_select_supported(64, 64, 1_000_000, 256) == 1
+    assert lib.tpq_max_sim_select_supported(64, 65, 1000, 256) == 0
+    assert lib.tpq_max_sim_select_supported(64, 64, 1000, 257) == 0
+    ws = lib.tpq_max_sim_select_workspace_bytes(64, 64, 1_000_000, 256)
+    assert 64 * 1_000_000 * 4 <= ws <= 64 * 1_000_000 * 4 + (8 << 20)         # the lists dominate
+    assert lib.tpq_coarse_assign_supported(128, 1 << 20, 16384) == 1
+    assert lib.tpq_coarse_assign_supported(129, 1000, 16) == 0
+    assert lib.tpq_coarse_assign_supported(128, 1 << 23, 16) == 0              # padded slice >= 2 GiB
+    ws = lib.tpq_coarse_assign_workspace_bytes(128, 1 << 20, 16384)
+    off = lib.tpq_coarse_assign_count_offset(128, 1 << 20, 16384)
+    frag_bytes = (16384 // 128) * 4 * 17 * 1024                                # 128 chunks x 4 units x 17 KiB
+    assert off == frag_bytes + 256 and ws >= frag_bytes + (1 << 20) * 4
+    assert lib.tpq_max_sim_split_supported(64, 1_000_000, 256) == 1 and lib.tpq_max_sim_split_supported(65, 10, 4) == 0
