@@ -1,5 +1,7 @@
-// Bit-exact coarse assign (labels only) at bf16-matrix-core speed: error-bounded selection on a
-// split-bf16 MFMA kernel + exact re-check of the ambiguous points.
+// Bit-exact assign (labels) at bf16-matrix-core speed: error-bounded selection on a split-bf16 MFMA
+// kernel + exact re-check of the ambiguous points.  Two entry points: tpq_coarse_assign (one problem,
+// many centroids, points resident: the coarse assign of add) and tpq_max_sim_select (batched
+// codebook-sized problems, centroids resident: the PQ codebook training; section 2b below).
 //
 // tpq_coarse_assign returns, for every point, the SAME label tpq_max_sim returns (the arg-max of the
 // oracle's fp32 arithmetic: ascending-k fmaf chains, (2 acc - |a|^2) - |c|^2, ties -> smallest
@@ -9,7 +11,7 @@
 // is 90 % of an add() at 16 384 cells.  The same idea as the list scan: a FAST value f
 // with a rigorous bound |f - g| <= delta on its distance from the real-number value g selects, the
 // exact arithmetic decides only where the selection cannot:
-//   1. assign_prep_kernel: the centroids, doubled (exact), split into NP bf16 pieces (NP = 2:
+//   1. assign_mean_kernel + assign_prep_kernel: the centroids, centred on their mean, doubled (exact), split into NP bf16 pieces (NP = 2:
 //      c = c1 + c2 + r, |r| <= 2^-16 |c|: a bf16 piece carries 8 significant bits, unit roundoff
 //      2^-8) and laid out in MFMA-fragment order, 32 centroids per unit,
 //      plus -|c|^2 as an exact 3-piece fragment and max |c|^2;
@@ -19,12 +21,14 @@
 //      products c2 a1, c1 a2, c1 a1 (NP = 2) go through v_mfma_f32_32x32x16_bf16; the epilogue keeps
 //      the best AND the second-best fast value per point (4 VALU per value: compare, index select,
 //      median-of-three, max);
-//      delta = 1.25 [(eps_prod + (16 KS + 13) 2^-23) (|a - mu| + |c - mu|max)^2 + (d + 4) 2^-24 (|a| + |c|max)^2]
-//      (mu = mean centroid: distances are translation-invariant) covers the dropped products
-//      (c2 a2, r_c a, c r_a: 3 x 2^-16 |a_k c_k| per term at NP = 2), a worst-case (truncating) fp32 accumulation of all
-//      MFMA terms (small products first: see the kernel), and the rounding of the exact chain itself.  A point whose two best fast values
-//      are further apart than 2 delta has its label decided: any other centroid is worse in
-//      the exact arithmetic too.  The rest (a few per cent at d = 128) are appended to a list;
+//      delta = 1.25 [(eps_prod + (16 KS + 13) 2^-23) (|a - mu| + |c - mu|max)^2
+//                    + (d + 4) 2^-24 (|a| + |c|max)^2]
+//      (mu = mean centroid: distances are translation-invariant) covers the dropped products (c2 a2,
+//      r_c a, c r_a: 3 x 2^-16 |a_k c_k| per term), a worst-case (truncating, any order) fp32
+//      accumulation of all MFMA terms (small products first: see the kernel), the rounding of the
+//      shift by mu and -- on the raw norms -- the rounding of the exact chain itself.  A point whose two
+//      best fast values are further apart than 2 delta has its label decided: any other centroid is
+//      worse in the exact arithmetic too.  The rest (1-3 % at d = 128) are appended to a list;
 //   3. the bit-exact fp32-MFMA kernel (max_sim_kernel, kmeans.hip) over the listed points only: it
 //      reads the list and its length from device memory (no host round trip; the grid covers the
 //      worst case and surplus blocks leave at once).
