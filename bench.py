@@ -222,14 +222,19 @@ def hbm_roofline(algo_bytes, kernel_ms, kernel, stream_peak=None, **extra):
 
 
 def source_fingerprint():
-    """sha1 over the kernel sources: a committed PMC summary is attached to the bench line only
-    when it was taken from exactly this code"""
+    """sha1 over the kernel sources with comments and whitespace removed: a committed PMC summary is
+    attached to the bench line only when it was taken from exactly this code (editing a comment
+    does not orphan the profiles)"""
+    import re
     h = hashlib.sha1()
     src = os.path.join(ROOT, "torchpq_amd", "csrc")
     for f in sorted(os.listdir(src)):
         if f.endswith((".h", ".hip", ".cpp")):
+            text = open(os.path.join(src, f), encoding="utf-8", errors="replace").read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", "", text)
             h.update(f.encode())
-            h.update(open(os.path.join(src, f), "rb").read())
+            h.update(re.sub(r"\s+", "", text).encode())
     return h.hexdigest()[:16]
 
 
