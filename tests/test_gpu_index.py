@@ -576,3 +576,29 @@ def test_add_uses_the_fast_coarse_assign_and_cells_stay_exact(monkeypatch):
     cells = N(idx.get_cell_by_address(adr))
     _, cells_or = c_oracle.max_sim(base[None], N(idx.vq_codec.codebook)[None], "euclidean", "expanded")
     assert np.array_equal(cells, cells_or[0]) and np.array_equal(cells, slow)
+
+
+def test_pq_encode_of_wide_subvectors_uses_the_selection_kernel_and_stays_exact(monkeypatch):
+    """d_subvector = 16 (e.g. 768-d embeddings at m = 48): PQCodec.encode takes tpq_max_sim_select and
+    returns the oracle's codes, bit for bit -- the same bytes the fp32 kernel path produces"""
+    from torchpq_amd import kernels as K
+    from torchpq_amd.codec import PQCodec
+    rng = np.random.default_rng(5)
+    d, m, n = 128, 8, 20000
+    x = (rng.standard_normal((d, n)) * 3).astype(np.float32)
+    np.random.seed(3)
+    pq = PQCodec(d_vector=d, n_subvectors=m, n_clusters=256)
+    pq.kmeans.max_iter = 3
+    pq.train(T(x))
+    calls = []
+    orig = K.MaxSimSelectHip.__call__
+    monkeypatch.setattr(K.MaxSimSelectHip, "__call__", lambda self, A, B: (calls.append(A.shape), orig(self, A, B))[1])
+    monkeypatch.setattr(PQCodec, "select_min_work", 1 << 60)
+    slow = N(pq.encode(T(x)))
+    assert not calls
+    monkeypatch.setattr(PQCodec, "select_min_work", 0)
+    fast = N(pq.encode(T(x)))
+    assert calls == [(m, d // m, n)]
+    cb = N(pq.codebook)
+    _, want = c_oracle.max_sim(x.reshape(m, d // m, n), cb, "euclidean", "expanded")
+    assert fast.dtype == np.uint8 and np.array_equal(fast, want.astype(np.uint8)) and np.array_equal(fast, slow)

@@ -46,8 +46,20 @@ class PQCodec(BaseCodec):
         d_vector, n_data = x.shape
         assert d_vector == self.d_vector
         x = x.reshape(self.n_subvectors, self.d_subvector, n_data)
-        _, labels = self.kmeans.get_labels(x, self.codebook)
+        # wide sub-vectors (d_subvector >= 12: 768-d embeddings at m = 64, ...): the bounded selection
+        # + exact re-check of tpq_max_sim_select -- the fp32 kernel's labels, bit for bit, ~2x faster;
+        # narrow ones (SIFT's 2, GIST's 8) stay on the fp32 MFMA, whose K = 2 wastes nothing
+        km = self.kmeans
+        if (self.distance in ("euclidean", "inner") and self.d_subvector >= km.split_min_d
+                and n_data * 256 * self.d_vector >= self.select_min_work
+                and km.max_sim_select_hip.supported(self.n_subvectors, self.d_subvector, n_data, 256)):
+            _, labels = km.max_sim_select_hip(x.contiguous(), self.codebook)
+            km.max_sim_select_hip.release()
+        else:
+            _, labels = km.get_labels(x, self.codebook)
         return labels.byte()
+
+    select_min_work = 1 << 27  # multiply-adds below which the extra launches do not pay
 
     def decode(self, code):
         """codes [n_subvectors, n_data] uint8 -> [d_vector, n_data] f32"""
