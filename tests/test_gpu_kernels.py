@@ -806,3 +806,24 @@ def test_max_sim_select_argument_errors(K):
     rc = lib.tpq_max_sim_select(_lib.ptr(A), _lib.ptr(B), _lib.ptr(v), _lib.ptr(i), 2, 64, 8, 300,
                                 _lib.METRIC_NEG_SQ_L2, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(DEV))
     assert rc == _lib.ERR_UNSUPPORTED and b"max_sim_select" in lib.tpq_last_error()
+
+
+def test_selection_kernels_degenerate_shapes(K):
+    """one point, one centroid, no point: tpq_coarse_assign / tpq_max_sim_select behave like the exact kernel"""
+    rng = np.random.default_rng(0)
+    for d, m, n in ((128, 1, 1), (5, 1, 300), (64, 513, 1), (16, 0, 7)):
+        A = rng.standard_normal((d, m)).astype(np.float32)
+        B = rng.standard_normal((d, n)).astype(np.float32)
+        got = N(K.CoarseAssignHip()(T(A), T(B)))
+        assert got.shape == (m,)
+        if m:
+            _, want = c_oracle.max_sim(A[None], B[None], "euclidean", "expanded")
+            assert np.array_equal(got, want[0])
+    for l, d, m, n in ((1, 64, 1, 1), (3, 20, 1, 256), (2, 48, 300, 1), (2, 32, 0, 9)):
+        A = rng.standard_normal((l, d, m)).astype(np.float32)
+        B = rng.standard_normal((l, d, n)).astype(np.float32)
+        v, i = K.MaxSimSelectHip()(T(A), T(B))
+        assert tuple(i.shape) == (l, m) and tuple(v.shape) == (l, m)
+        if m:
+            _, want = c_oracle.max_sim(A, B, "euclidean", "expanded")
+            assert np.array_equal(N(i), want)

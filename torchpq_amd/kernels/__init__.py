@@ -548,6 +548,9 @@ class CoarseAssignHip:
         n = B.shape[1]
         lib = load()
         inds = torch.empty(m, device=A.device, dtype=torch.int64)
+        if m == 0:  # (empty tensors have null data pointers)
+            self._last = None
+            return (torch.empty(0, device=A.device), inds) if return_vals else inds
         ws_bytes = lib.tpq_coarse_assign_workspace_bytes(d, m, n)
         ws = torch.empty(max(ws_bytes, 1), device=A.device, dtype=torch.uint8)
         metric = _lib.METRIC_NEG_SQ_L2 if self.distance == "euclidean" else _lib.METRIC_INNER
@@ -560,6 +563,8 @@ class CoarseAssignHip:
 
     def last_rechecked(self):
         """diagnostics (synchronises): points of the last call that went to the exact re-check"""
+        if self._last is None:
+            return 0
         ws, off = self._last
         return int(ws[off:off + 4].view(torch.int32).item())
 
@@ -589,6 +594,8 @@ class MaxSimSelectHip:
         lib = load()
         vals = torch.empty(l, m, device=A.device, dtype=torch.float32)
         inds = torch.empty(l, m, device=A.device, dtype=torch.int64)
+        if m == 0:
+            return vals, inds
         ws_bytes = lib.tpq_max_sim_select_workspace_bytes(l, d, m, n)
         if self._ws is None or self._ws.numel() < ws_bytes or self._ws.device != A.device:
             self._ws = None
