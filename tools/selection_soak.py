@@ -1,0 +1,79 @@
+#!/usr/bin/env python
+"""Randomised soak of the two selection kernels: labels must equal the bit-exact fp32 kernel's on
+every case.  Shapes and data kinds are drawn at random (Gaussian, SIFT-like integers, heavy-tailed,
+tight clusters, large common offset, tiny and huge magnitudes, duplicated centroids)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from torchpq_amd import kernels as K  # noqa: E402
+
+KINDS = ("gauss", "sift", "heavy", "tight", "offset", "tiny", "huge", "dups")
+
+
+def make(rng, kind, d, m, n, dev):
+    if kind == "sift":
+        A = rng.integers(0, 256, (d, m)).astype(np.float32)
+    elif kind == "heavy":
+        A = (rng.standard_t(2.5, (d, m)) * 5).astype(np.float32)
+    elif kind == "tight":
+        c = rng.standard_normal((d, 8)) * 50
+        A = (c[:, rng.integers(0, 8, m)] + rng.standard_normal((d, m)) * 0.01).astype(np.float32)
+    elif kind == "offset":
+        A = (1000.0 + rng.standard_normal((d, m))).astype(np.float32)
+    elif kind == "tiny":
+        A = (rng.standard_normal((d, m)) * 1e-18).astype(np.float32)
+    elif kind == "huge":
+        A = (rng.standard_normal((d, m)) * 1e14).astype(np.float32)
+    else:
+        A = (rng.standard_normal((d, m)) * 7).astype(np.float32)
+    B = A[:, rng.integers(0, m, n)].copy()
+    if kind != "dups":
+        B = B + (np.abs(A).mean() * 0.05 * rng.standard_normal((d, n))).astype(np.float32)
+    return torch.from_numpy(np.ascontiguousarray(A)).to(dev), torch.from_numpy(np.ascontiguousarray(B)).to(dev)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    dev = "cuda:0"
+    bad, log = [], {"coarse": 0, "select": 0, "rechecked_share_max": 0.0}
+    for c in range(a.cases):
+        kind = KINDS[c % len(KINDS)]
+        d = int(rng.integers(1, 129))
+        m = int(rng.integers(1, 20000))
+        n = int(rng.integers(1, 3000))
+        dist = "euclidean" if rng.random() < 0.75 else "inner"
+        A, B = make(rng, kind, d, m, n, dev)
+        op = K.CoarseAssignHip(distance=dist)
+        got = op(A, B)
+        want = K.MaxSimHip(distance=dist)(A, B, dim=1)[1]
+        log["coarse"] += 1
+        log["rechecked_share_max"] = max(log["rechecked_share_max"], op.last_rechecked() / m)
+        if not torch.equal(got, want):
+            bad.append(("coarse", kind, d, m, n, dist, int((got != want).sum())))
+        l = int(rng.integers(1, 5))
+        d2 = int(rng.integers(1, 65))
+        n2 = int(rng.integers(1, 257))
+        As, Bs = zip(*[make(rng, kind, d2, m, n2, dev) for _ in range(l)])
+        A3, B3 = torch.stack(As).contiguous(), torch.stack(Bs).contiguous()
+        got = K.MaxSimSelectHip(distance=dist)(A3, B3)[1]
+        want = K.MaxSimHip(distance=dist)(A3, B3, dim=2)[1]
+        log["select"] += 1
+        if not torch.equal(got, want):
+            bad.append(("select", kind, l, d2, m, n2, dist, int((got != want).sum())))
+    log["mismatching_cases"] = bad
+    print(json.dumps(log))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
