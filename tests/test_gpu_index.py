@@ -602,3 +602,21 @@ def test_pq_encode_of_wide_subvectors_uses_the_selection_kernel_and_stays_exact(
     cb = N(pq.codebook)
     _, want = c_oracle.max_sim(x.reshape(m, d // m, n), cb, "euclidean", "expanded")
     assert fast.dtype == np.uint8 and np.array_equal(fast, want.astype(np.uint8)) and np.array_equal(fast, slow)
+
+
+@pytest.mark.parametrize("distance", ["inner", "cosine"])
+def test_fast_predict_for_inner_and_cosine_equals_the_fp32_path(distance, monkeypatch):
+    """KMeans.predict through tpq_coarse_assign for the other two metrics: cosine normalises exactly as
+    get_labels does and then takes the inner-product path; labels equal the fp32 kernel's"""
+    from torchpq_amd.clustering import KMeans
+    rng = np.random.default_rng(8)
+    d, n, k = 48, 9000, 200
+    x = T((rng.standard_normal((d, n)) * 2 + 0.5).astype(np.float32))
+    km = KMeans(n_clusters=k, max_iter=3, distance=distance)
+    np.random.seed(2)
+    km.fit(x)
+    monkeypatch.setattr(KMeans, "fast_predict_min_work", 1 << 60)
+    slow = km.predict(x)
+    monkeypatch.setattr(KMeans, "fast_predict_min_work", 0)
+    fast = km.predict(x)
+    assert torch.equal(fast, slow)

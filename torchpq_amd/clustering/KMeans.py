@@ -83,9 +83,13 @@ class KMeans(CustomModule):
         assert self.centroids is not None, "kmeans is not trained"
         d, m = query.shape
         n = self.centroids.shape[1]
-        if (self.distance in ("euclidean", "inner") and m * n * d >= self.fast_predict_min_work
-                and n >= 64 and CoarseAssignHip.supported(d, m, n)):
-            return CoarseAssignHip(distance=self.distance)(query, self.centroids)
+        if m * n * d >= self.fast_predict_min_work and n >= 64 and CoarseAssignHip.supported(d, m, n):
+            centroids = self.centroids
+            if self.distance == "cosine":  # normalised exactly as get_labels does, then inner product
+                query = query / (query.norm(dim=-2, keepdim=True) + 1e-8)
+                centroids = centroids / (centroids.norm(dim=-2, keepdim=True) + 1e-8)
+            op = CoarseAssignHip(distance="euclidean" if self.distance == "euclidean" else "inner")
+            return op(query, centroids)
         return self.get_labels(query, self.centroids)[1]
 
     def topk(self, query, k=128):
