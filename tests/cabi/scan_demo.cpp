@@ -6,7 +6,8 @@
 // Builds a small inverted-list index on the host (reference layout, ragged cells with slack),
 // calls tpq_ivfpq_scan_topk and -- after tpq_ivfpq_pack_codes -- tpq_ivfpq_scan_topk_packed through
 // include/torchpq_amd.h, and checks both against a scalar restatement of the reference kernel's
-// arithmetic (sum_j LUT[j][code_j] in ascending j, ivfpq_topk.cu:662-679; ties by ascending address).
+// arithmetic (sum_j LUT[j][code_j] in ascending j, ivfpq_topk.cu:662-679; ties by ascending address);
+// then tpq_coarse_assign against a scalar restatement of the fp32 assign arithmetic.
 // Test infrastructure (run by tests/test_gpu_cabi_demo.py); exit code 0 = bit-exact.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -149,6 +150,62 @@ int main() {
                                      nullptr, nullptr, n_slots, nq, n_probe, /*m=*/6, k, 1, d_ws, 0, stream);
   printf("bad m -> rc=%d (%s)\n", rc, tpq_last_error());
   failures += rc == 0;
+  // ---- tpq_coarse_assign: the labels of the fp32 arithmetic (ascending-k fmaf chains, (2 acc - |a|^2)
+  // - |c|^2, ties -> smallest index: oracle_max_sim mode "expanded"), from the bounded bf16 selection
+  // + exact re-check; centroids include exact duplicates and near-duplicates
+  {
+    const int d = 96, np = 3000, nc = 700;
+    std::vector<float> A((size_t)d * np), B((size_t)d * nc);
+    for (auto& v : A) v = (float)((int)(rnd() % 2001) - 1000) / 64.0f;
+    for (int c = 0; c < nc; ++c)
+      for (int kk = 0; kk < d; ++kk) {
+        const int src = (c % 3 == 0) ? (c / 3) % np : (int)(rnd() % np);  // every third one copies a point
+        B[(size_t)kk * nc + c] = A[(size_t)kk * np + src] + ((c % 3 == 0) ? 0.f : (float)((int)(rnd() % 201) - 100) / 512.0f);
+      }
+    for (int kk = 0; kk < d; ++kk) B[(size_t)kk * nc + 5] = B[(size_t)kk * nc + 0];  // an exact duplicate
+    std::vector<int64_t> want(np);
+    std::vector<float> b2(nc);
+    for (int c = 0; c < nc; ++c) {
+      float sq = 0.f;
+      for (int kk = 0; kk < d; ++kk) sq = fmaf(B[(size_t)kk * nc + c], B[(size_t)kk * nc + c], sq);
+      b2[c] = sq;
+    }
+    for (int i = 0; i < np; ++i) {
+      float a2 = 0.f;
+      for (int kk = 0; kk < d; ++kk) a2 = fmaf(A[(size_t)kk * np + i], A[(size_t)kk * np + i], a2);
+      float best = -INFINITY;
+      int64_t bi = 0;
+      for (int c = 0; c < nc; ++c) {
+        float acc = 0.f;
+        for (int kk = 0; kk < d; ++kk) acc = fmaf(A[(size_t)kk * np + i], B[(size_t)kk * nc + c], acc);
+        acc = 2.f * acc;
+        acc = acc - a2;
+        acc = acc - b2[c];
+        if (acc > best) {
+          best = acc;
+          bi = c;
+        }
+      }
+      want[i] = bi;
+    }
+    float* dA = to_device(A);
+    float* dB = to_device(B);
+    int64_t* d_lab = nullptr;
+    void* d_cws = nullptr;
+    if (!dA || !dB) return 2;
+    HIP_OK(hipMalloc(&d_lab, (size_t)np * sizeof(int64_t)));
+    const size_t cws = tpq_coarse_assign_workspace_bytes(d, np, nc);
+    HIP_OK(hipMalloc(&d_cws, cws + 16));
+    TPQ_OK_(tpq_coarse_assign(dA, dB, nullptr, d_lab, d, np, nc, TPQ_METRIC_NEG_SQ_L2, d_cws, cws, stream));
+    std::vector<int64_t> lab(np);
+    HIP_OK(hipMemcpyAsync(lab.data(), d_lab, lab.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    int bad = 0;
+    for (int i = 0; i < np; ++i) bad += lab[i] != want[i];
+    printf("coarse assign, %d points x %d centroids x %d: %s (%d mismatches)\n", np, nc, d,
+           bad ? "FAIL" : "labels bit-exact", bad);
+    failures += bad != 0;
+  }
   printf("tpq_version %d\n", tpq_version());
   return failures ? 1 : 0;
 }

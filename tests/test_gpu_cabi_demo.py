@@ -18,5 +18,5 @@ def test_cabi_scan_demo_is_bit_exact():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count("bit-exact") == 4
+    assert out.stdout.count("bit-exact") == 5 and "labels bit-exact" in out.stdout
     assert "bad m -> rc=-1" in out.stdout
