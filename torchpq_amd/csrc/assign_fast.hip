@@ -280,6 +280,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void assign_fast_kernel(FastArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) accB[ct][r] = -INFINITY;
 
+  bf16x8 ar[2][NP], am[3];  // A-operand rings (see `unit`)
   constexpr int NM = CT * (1 + KS * NPR);  // MFMAs per unit
   // unit U of the chunk in `base`; `fin` = accumulators of the unit before it (uid_fin), whose values
   // go through the top-2 update between this unit's MFMAs
@@ -289,10 +290,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void assign_fast_kernel(FastArgs a)
     float before[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) before[ct] = b1[ct];
-    bf16x8 ar[2][NP];
+    // A operands of the correction pass: a two-slot ring one k-step ahead that lives across the units
+    // of a chunk (unit U + 1's first k-step is fetched during unit U's main pass); only unit 0 of a
+    // chunk -- whose buffer is known to have landed only after the chunk barrier -- starts cold
     const bf16x8 cfrag = up[0];
+    if constexpr (U == 0 || NP != 2) {
 #pragma unroll
-    for (int q = 0; q < NP; ++q) ar[0][q] = up[(1 + q) * 64];
+      for (int q = 0; q < NP; ++q) ar[0][q] = up[(1 + q) * 64];
+    }
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // epilogue slice after MFMA number mi (of NM): CT * 16 values spread over gaps [CT, NM)
     auto slice = [&](auto mi_c) {
@@ -320,6 +325,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void assign_fast_kernel(FastArgs a)
 #pragma unroll
           for (int q = 0; q < 2; ++q) ar[(st + 1) & 1][q] = up[(1 + (st + 1) * 2 + q) * 64];
         }
+        // c1 of the first two k-steps for the main pass (am: 3 slots, two k-steps ahead)
+        if constexpr (st == KS - 2) am[0] = up[1 * 64];
+        if constexpr (st == KS - 1) am[1] = up[(1 + 2) * 64];
         static_for<0, 2>([&](auto t_c) {
           constexpr int t = decltype(t_c)::value;  // t = 0: (c2, a1); t = 1: (c1, a2)
           static_for<0, CT>([&](auto ct_c) {
@@ -333,12 +341,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void assign_fast_kernel(FastArgs a)
           });
         });
       });
-      bf16x8 am[3];  // c1 of k-step s for the main pass, two k-steps (2 CT MFMAs) ahead
-      am[0] = up[1 * 64];
-      if constexpr (KS > 1) am[1] = up[(1 + 2) * 64];
       static_for<0, KS>([&](auto s_c) {
         constexpr int st = decltype(s_c)::value;
         if constexpr (st + 2 < KS) am[(st + 2) % 3] = up[(1 + (st + 2) * 2) * 64];
+        if constexpr (st == 0 && U + 1 < kUnitsPerChunk) {  // the next unit's first correction operands
+          ar[0][0] = up[FPU * 64 + 1 * 64];
+          ar[0][1] = up[FPU * 64 + 2 * 64];
+        }
         static_for<0, CT>([&](auto ct_c) {
           constexpr int ct = decltype(ct_c)::value;
           acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[st % 3], xs[ct][st][0], acc[ct], 0, 0, 0);
