@@ -730,6 +730,7 @@ def _coarse_case(rng, d, m, n, kind):
 @pytest.mark.parametrize("d,m,n,kind", [(128, 3000, 1024, "sift"), (128, 1111, 300, "gauss"),
                                         (100, 2000, 129, "gauss"), (17, 5000, 64, "sift"),
                                         (64, 700, 2049, "ties"), (128, 600, 500, "crowded"),
+                                        (64, 40000, 300, "crowded"),  # more re-checked points than the compact copy holds
                                         (33, 513, 31, "ties"), (96, 40, 4000, "gauss"),
                                         (1, 300, 5, "gauss")])
 @pytest.mark.parametrize("distance", ["euclidean", "inner"])

@@ -38,7 +38,8 @@
 
 namespace tpq {
 int launch_max_sim_list(const float* A, const float* B, float* vals, int64_t* inds, int l, int d, int m, int n,
-                        int euclid, const int* list, const int* count, hipStream_t st);  // kmeans.hip
+                        int euclid, const int* list, const int* count, unsigned long long* keys, float* Ac, int cap,
+                        hipStream_t st);  // kmeans.hip
 namespace afast {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -717,9 +718,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void select_resident_kernel(SelArgs
 
 // ---- 3. exact re-check: max_sim_kernel (kmeans.hip, the bit-exact fp32-MFMA kernel) over the list ----
 struct Layout {
-  size_t frags_off, frags_bytes, cmax_off, count_off, mu_off, list_off, total;
+  size_t frags_off, frags_bytes, cmax_off, count_off, mu_off, list_off, keys_off, ac_off, total;
+  int cap;
 };
-static Layout layout(int KS, int NP, int64_t m, int n) {
+static Layout layout(int KS, int NP, int64_t m, int n, int d = 0) {
   Layout L;
   const int64_t units = (n + 31) / 32;
   const int64_t chunks = (units + kUnitsPerChunk - 1) / kUnitsPerChunk;
@@ -729,14 +731,19 @@ static Layout layout(int KS, int NP, int64_t m, int n) {
   L.count_off = L.cmax_off + 256;
   L.mu_off = L.count_off + 256;
   L.list_off = L.mu_off + 1024;
-  L.total = L.list_off + (size_t)m * 4;
+  L.keys_off = (L.list_off + (size_t)m * 4 + 255) / 256 * 256;  // [m] u64: the split re-check's (value, index) keys
+  // compact copy of the re-checked points' columns: a quarter of the points (at least 8192) -- the
+  // re-check share is a few per cent; more than that overflows into the gathering launch
+  L.cap = (int)(m < 8192 ? m : (m / 4 > 8192 ? m / 4 : 8192));
+  L.ac_off = (L.keys_off + (size_t)m * 8 + 255) / 256 * 256;
+  L.total = L.ac_off + (size_t)L.cap * d * 4;
   return L;
 }
 
 template <int KS, int NP, int CT>
 static int run(const float* A, const float* B, float* vals, int64_t* inds, int d, int m, int n, int euclid, char* ws,
                hipStream_t st) {
-  const Layout L = layout(KS, NP, m, n);
+  const Layout L = layout(KS, NP, m, n, d);
   bf16x8* frags = reinterpret_cast<bf16x8*>(ws + L.frags_off);
   unsigned* cmax = reinterpret_cast<unsigned*>(ws + L.cmax_off);
   int* count = reinterpret_cast<int*>(ws + L.count_off);
@@ -769,7 +776,11 @@ static int run(const float* A, const float* B, float* vals, int64_t* inds, int d
   const int per_block = kWaves * 32 * CT;
   hipLaunchKernelGGL(kernel, dim3((m + per_block - 1) / per_block), dim3(kWaves * 64), lds, st, fa);
   TPQ_LAUNCH_CHECK("assign_fast_kernel");
-  return launch_max_sim_list(A, B, vals, inds, 1, d, m, n, euclid, list, count, st);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws + L.keys_off);
+  rc = check_hip(hipMemsetAsync(keys, 0, (size_t)m * 8, st), "coarse_assign keys memset");
+  if (rc) return rc;
+  return launch_max_sim_list(A, B, vals, inds, 1, d, m, n, euclid, list, count, keys,
+                             reinterpret_cast<float*>(ws + L.ac_off), L.cap, st);
 }
 
 struct SelLayout {
@@ -813,7 +824,7 @@ static int run_select(const float* A, const float* B, float* vals, int64_t* inds
   const int per_block = kWaves * 32 * kSelTiles;
   hipLaunchKernelGGL(kernel, dim3((m + per_block - 1) / per_block, l), dim3(kWaves * 64), lds, st, sa);
   TPQ_LAUNCH_CHECK("select_resident_kernel");
-  return launch_max_sim_list(A, B, vals, inds, l, d, m, n, euclid, list, count, st);
+  return launch_max_sim_list(A, B, vals, inds, l, d, m, n, euclid, list, count, nullptr, nullptr, 0, st);
 }
 
 }  // namespace afast
@@ -877,7 +888,7 @@ extern "C" int tpq_coarse_assign_supported(int d, int64_t m, int n) {
 
 extern "C" size_t tpq_coarse_assign_workspace_bytes(int d, int64_t m, int n) {
   if (!tpq_coarse_assign_supported(d, m, n)) return 0;
-  return afast::layout(af_ks(d), TPQ_AF_NP, m, n).total;
+  return afast::layout(af_ks(d), TPQ_AF_NP, m, n, d).total;
 }
 
 // diagnostics: byte offset, inside the workspace, of the int32 number of points the last call sent

@@ -63,23 +63,34 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
                                                          int64_t* __restrict__ inds, int d, int m,
                                                          int n, int euclidean,
                                                          const int* __restrict__ list,
-                                                         const int* __restrict__ count) {
+                                                         const int* __restrict__ count,
+                                                         unsigned long long* __restrict__ keys,
+                                                         const float* __restrict__ Ac, int cap, int pos0) {
   // list != nullptr (tpq_coarse_assign's exact re-check): the points are columns list[0 .. *count)
   // of A, results go to inds[list[p]], vals may be null; the grid covers the worst case and blocks
-  // beyond *count leave at once.
+  // beyond *count leave at once.  keys != nullptr (one problem, many centroids, few points): the
+  // CENTROIDS are split over gridDim.y blocks per point tile -- a few hundred listed points would
+  // otherwise occupy a few hundred long-running blocks, one per CU -- and every split folds its
+  // (value, index) into keys[point] with a 64-bit atomicMax (order-preserving value bits, then
+  // ~index: ties go to the smaller index); max_sim_list_decode_kernel writes the results.
+  // Ac != nullptr: list positions [0, min(*count, cap)) read their point from the compact copy
+  // Ac [d][cap] (gather_columns_kernel) -- coalesced; gathering the listed columns of A inside the
+  // slab loop (64 cache lines per load instruction, once per centroid chunk) was what the re-check
+  // spent its time on.  A second launch (Ac == nullptr, pos0 = cap) gathers for the overflow, if any.
   extern __shared__ __attribute__((aligned(16))) float ms_smem[];
   float* cs = ms_smem;                  // [2][kMsKC][kMsCent]
   float* b2s = ms_smem + 2 * kMsSlab;   // [kMsCent]
-  const int b = blockIdx.y;
+  const int b = keys ? 0 : blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l31 = lane & 31, half = lane >> 5;
-  const int pos = blockIdx.x * 128 + wave * 32 + l31;  // this lane's point (position in the list)
+  const int pos = pos0 + blockIdx.x * 128 + wave * 32 + l31;  // this lane's point (position in the list)
   int m_eff = m;
   if (list) {
     list += (int64_t)b * m;  // one list per sub-problem
     m_eff = count[b];
     m_eff = m_eff < m ? m_eff : m;
-    if ((int)blockIdx.x * 128 >= m_eff) return;  // block-uniform
+    if (Ac) m_eff = m_eff < cap ? m_eff : cap;
+    if (pos0 + (int)blockIdx.x * 128 >= m_eff) return;  // block-uniform
   }
   const bool iv = pos < m_eff;
   const int i = list ? (iv ? list[pos] : 0) : pos;  // column of A / slot of the outputs
@@ -89,10 +100,11 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
   // for each of the 24 loads of a slab: 48 address registers, the kernel sat at its 256-VGPR cap
   // with two registers left for the MFMA A operands, and every pair of MFMAs waited for its own
   // LDS round trip -- ds_read2, s_waitcnt lgkmcnt(0), 2 MFMAs, repeat: 80-86 TF/s.)
-  const float* __restrict__ Ab = A + (int64_t)b * d * m;  // uniform
+  const float* __restrict__ Ab = Ac ? Ac : A + (int64_t)b * d * m;  // uniform
   const float* __restrict__ Bb = B + (int64_t)b * d * n;  // uniform
-  const uint32_t xoff = iv ? (uint32_t)i : 0u;            // this lane's column of A (a valid one)
-  auto a_row = [&](int k) -> const float* { return Ab + (int64_t)(k < d ? k : d - 1) * m; };
+  const int a_cols = Ac ? cap : m;
+  const uint32_t xoff = iv ? (uint32_t)(Ac ? pos : i) : 0u;  // this lane's column of A (a valid one)
+  auto a_row = [&](int k) -> const float* { return Ab + (int64_t)(k < d ? k : d - 1) * a_cols; };
   auto b_row = [&](int k) -> const float* { return Bb + (int64_t)(k < d ? k : d - 1) * n; };
 
   // |a|^2, one ascending-k fma chain per point; 16 loads in flight per step (a plain loop waits
@@ -117,8 +129,15 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
   int besti = 0;
   const int n_slabs = (d + kMsKC - 1) / kMsKC;
 
-  for (int c0 = 0; c0 < n; c0 += kMsCent) {
-    const int nc = (n - c0) < kMsCent ? (n - c0) : kMsCent;
+  int c_lo = 0, c_hi = n;
+  if (keys) {  // this block's share of the centroid chunks
+    const int chunks = (n + kMsCent - 1) / kMsCent;
+    c_lo = (int)(((int64_t)chunks * blockIdx.y) / gridDim.y) * kMsCent;
+    c_hi = (int)(((int64_t)chunks * (blockIdx.y + 1)) / gridDim.y) * kMsCent;
+    c_hi = c_hi < n ? c_hi : n;
+  }
+  for (int c0 = c_lo; c0 < c_hi; c0 += kMsCent) {
+    const int nc = (c_hi - c0) < kMsCent ? (c_hi - c0) : kMsCent;
     const int nt = (nc + 31) >> 5;
     const bool cv = (int)threadIdx.x < nc;  // this thread's centroid column of the chunk exists
     const uint32_t coff = (uint32_t)c0 + (cv ? threadIdx.x : 0u);
@@ -242,22 +261,81 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
     besti = oi;
   }
   if (half == 0 && iv) {
-    if (vals) vals[(int64_t)b * m + i] = best;
-    inds[(int64_t)b * m + i] = besti;
+    if (keys) {
+      if (c_lo < c_hi) {
+        const unsigned fb = __float_as_uint(best);
+        const unsigned ordered = (fb & 0x80000000u) ? ~fb : (fb | 0x80000000u);
+        atomicMax(keys + i, ((unsigned long long)ordered << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)besti));
+      }
+    } else {
+      if (vals) vals[(int64_t)b * m + i] = best;
+      inds[(int64_t)b * m + i] = besti;
+    }
   }
+}
+
+// Ac[k][p] = A[k][list[p]] for p < min(*count, cap): grid (ceil(cap / 256), d)
+__global__ __launch_bounds__(256) void gather_columns_kernel(const float* __restrict__ A,
+                                                            const int* __restrict__ list,
+                                                            const int* __restrict__ count,
+                                                            float* __restrict__ Ac, int m, int cap) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int cnt = *count < cap ? *count : cap;
+  if (p >= cnt) return;
+  Ac[(int64_t)blockIdx.y * cap + p] = A[(int64_t)blockIdx.y * m + list[p]];
+}
+
+__global__ __launch_bounds__(256) void max_sim_list_decode_kernel(const int* __restrict__ list,
+                                                                 const int* __restrict__ count,
+                                                                 const unsigned long long* __restrict__ keys,
+                                                                 float* __restrict__ vals,
+                                                                 int64_t* __restrict__ inds, int m) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int cnt = *count < m ? *count : m;
+  if (p >= cnt) return;
+  const int i = list[p];
+  const unsigned long long key = keys[i];
+  const unsigned ordered = (unsigned)(key >> 32);
+  const unsigned fb = (ordered & 0x80000000u) ? (ordered & 0x7FFFFFFFu) : ~ordered;
+  inds[i] = (int64_t)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+  if (vals) vals[i] = __uint_as_float(fb);
 }
 
 // the exact kernel over device-side lists of points (list [l][m], count [l]): see tpq_coarse_assign /
 // tpq_max_sim_select
 int launch_max_sim_list(const float* A, const float* B, float* vals, int64_t* inds, int l, int d, int m, int n,
-                        int euclid, const int* list, const int* count, hipStream_t st) {
+                        int euclid, const int* list, const int* count, unsigned long long* keys, float* Ac, int cap,
+                        hipStream_t st) {
   const size_t ms_lds = (size_t)(2 * kMsSlab + kMsCent) * sizeof(float);
   int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(max_sim_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ms_lds),
                      "max_sim_kernel attr");
   if (rc) return rc;
+  if (keys && l == 1) {
+    // one problem: keys [m] u64 (zeroed by the caller) + compact copy Ac [d][cap]; the centroid
+    // chunks are split up to 8 ways
+    const int chunks = (n + kMsCent - 1) / kMsCent;
+    const int splits = chunks < 8 ? chunks : 8;
+    cap = cap < m ? cap : m;
+    hipLaunchKernelGGL(gather_columns_kernel, dim3((cap + 255) / 256, d), dim3(256), 0, st, A, list, count, Ac, m,
+                       cap);
+    TPQ_LAUNCH_CHECK("gather_columns_kernel");
+    hipLaunchKernelGGL(max_sim_kernel, dim3((cap + 127) / 128, splits), dim3(256), ms_lds, st, A, B, vals, inds, d,
+                       m, n, euclid, list, count, keys, static_cast<const float*>(Ac), cap, 0);
+    TPQ_LAUNCH_CHECK("max_sim_kernel (list, compact)");
+    if (cap < m) {  // more listed points than the compact copy holds: gather for the rest
+      hipLaunchKernelGGL(max_sim_kernel, dim3((m - cap + 127) / 128, splits), dim3(256), ms_lds, st, A, B, vals,
+                         inds, d, m, n, euclid, list, count, keys, static_cast<const float*>(nullptr), 0, cap);
+      TPQ_LAUNCH_CHECK("max_sim_kernel (list, overflow)");
+    }
+    hipLaunchKernelGGL(max_sim_list_decode_kernel, dim3((m + 255) / 256), dim3(256), 0, st, list, count, keys,
+                       vals, inds, m);
+    TPQ_LAUNCH_CHECK("max_sim_list_decode_kernel");
+    return TPQ_OK;
+  }
   hipLaunchKernelGGL(max_sim_kernel, dim3((m + 127) / 128, l), dim3(256), ms_lds, st, A, B, vals, inds, d,
-                     m, n, euclid, list, count);
+                     m, n, euclid, list, count, static_cast<unsigned long long*>(nullptr),
+                     static_cast<const float*>(nullptr), 0, 0);
   TPQ_LAUNCH_CHECK("max_sim_kernel (list)");
   return TPQ_OK;
 }
@@ -887,7 +965,8 @@ extern "C" int tpq_max_sim(const float* A, const float* B, float* vals, int64_t*
   if (rc_attr) return rc_attr;
   hipLaunchKernelGGL(max_sim_kernel, dim3((m + 127) / 128, l), dim3(256), ms_lds, st, A, B, vals,
                      inds, d, m, n, euclid, static_cast<const int*>(nullptr),
-                     static_cast<const int*>(nullptr));
+                     static_cast<const int*>(nullptr), static_cast<unsigned long long*>(nullptr),
+                     static_cast<const float*>(nullptr), 0, 0);
   TPQ_LAUNCH_CHECK("max_sim_kernel");
   return TPQ_OK;
 }
