@@ -531,6 +531,7 @@ class CoarseAssignHip:
     def __init__(self, distance="euclidean", **_):
         assert distance in ("euclidean", "inner", "cosine")
         self.distance = distance
+        self._last = None
 
     @staticmethod
     def supported(d, m, n):
