@@ -16,6 +16,10 @@ collective.
 
 `--gpus N` with N > 1 launches its own N ranks (torch.distributed.run, one per GPU, RCCL) when
 not already running under a launcher; under the driver's torchrun command it is one of the ranks.
+`--scaling weak|strong` picks the mode `value` is quoted in (weak, the default: --nq queries per
+rank; strong: ONE batch of --nq queries split over the ranks); at N > 1 the other mode is timed
+as well and reported under `other_scaling`, with the per-rank ms_per_step spread and the bytes of
+the one index broadcast.
 
 At N=1 a time-boxed secondary pass (<= ~60 s) puts the other BASELINE.json configs on the record
 under the key "secondary" of the same JSON line, each with its own roofline:
@@ -35,8 +39,21 @@ import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
+
+def rccl_env(env=os.environ):
+    """What RCCL needs on this driver, set on EVERY entry path -- under the driver's own
+    `torch.distributed.run ... bench.py --gpus N` as well as under self_launch -- and before the
+    first HIP call (i.e. before torch is imported): the host driver only supports dmabuf IPC;
+    without it RCCL's intra-node transport fails with `hipIpcGetMemHandle: invalid argument`."""
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    return env
+
+
+rccl_env()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -44,7 +61,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix-core peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix-core peak (MI355X_MICROARCH.md; not the 2:1-sparsity figure)
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 
 # ---------------------------------------------------------------------------------------------
@@ -255,10 +272,14 @@ def attach_traffic(roofline, name):
             roofline["traffic"] = round(pj["hbm_side_read_bytes_corrected"])
             roofline["traffic_source"] = (f"profiles/{PROFILE_TAG}_{name}.json (rocprofv3 --pmc "
                                           "FETCH_SIZE x2 x1KiB, same command, same sources)")
+            roofline["traffic_measured_in_this_run"] = False
         elif abs(pj["algorithmic_bytes_per_launch"] - algo) <= 0.02 * algo:
             roofline["traffic"] = round(pj["hbm_side_read_bytes_corrected"])
             roofline["traffic_source"] = (f"profiles/{PROFILE_TAG}_{name}.json (rocprofv3 --pmc "
                                           "FETCH_SIZE x2 x1KiB, same command, same sources)")
+            # replayed from the builder's committed counter pass (another run, possibly another box
+            # of the pool): PMC counters cannot be collected from inside the timed run
+            roofline["traffic_measured_in_this_run"] = False
     except Exception as e:  # a malformed summary must not break the bench line
         roofline["traffic_note"] = f"unreadable profile: {e}"
 
@@ -490,8 +511,7 @@ def launch_command(n, argv, port=None):
 
 
 def self_launch(args):
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env = rccl_env(dict(os.environ))
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
     return subprocess.call(launch_command(args.gpus, sys.argv[1:]), env=env)
 
@@ -504,7 +524,13 @@ def parse_args(argv=None):
     ap.add_argument("--workload", choices=["c2", "c4"], default="c2",
                     help="c2 = SIFT1M shape (BASELINE.json configs[1], the headline); "
                          "c4 = 100 M vectors, n_cells=16384, n_probe=64 (configs[3])")
-    ap.add_argument("--nq", type=int, default=10000)
+    ap.add_argument("--nq", type=int, default=10000,
+                    help="queries per rank (weak scaling) / in the whole batch (strong scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="the mode `value` is quoted in: weak = every rank searches its own --nq "
+                         "queries; strong = ONE batch of --nq queries split over the ranks "
+                         "(shard_queries).  At N > 1 the other mode is timed too and reported "
+                         "under the key `other_scaling` of the same line")
     ap.add_argument("--n-base", type=int, default=None)
     ap.add_argument("--n-train", type=int, default=100000)
     ap.add_argument("--d", type=int, default=128)
@@ -592,7 +618,7 @@ def main():
     if rank != 0:
         idx = IVFPQIndex(d_vector=args.d, n_subvectors=args.m, n_cells=args.n_cells, initial_size=1,
                          device=str(device))
-    t_bcast = 0.0
+    t_bcast, bcast_bytes = 0.0, 0
     if world > 1:
         torch.cuda.synchronize()
         dist.barrier()
@@ -601,32 +627,58 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         t_bcast = time.time() - t0
+        bcast_bytes = int(getattr(idx, "replicated_bytes", 0))
     idx.n_probe = args.n_probe
     idx.use_smart_probing = False
     idx.use_packed_layout = args.layout == "packed"
 
-    # every rank searches its own query set (weak scaling): same distribution, rank-specific seed
-    if args.workload == "c4":
-        qg = torch.Generator(device=device)
-        qg.manual_seed(4321 + rank)
-        queries = torch.randn(args.d, args.nq, generator=qg, device=device)
-    elif real is not None:
-        queries, gt_nn = real[2], real[3]
-    else:
-        queries = synth.sample(args.nq, seed=4321 + rank)
+    # weak scaling: every rank searches its own --nq queries (same distribution, rank-specific
+    # seed); strong scaling: ONE batch of --nq queries (rank 0's), split over the ranks
+    def make_queries(mode):
+        seed_rank = rank if mode == "weak" else 0
+        if args.workload == "c4":
+            qg = torch.Generator(device=device)
+            qg.manual_seed(4321 + seed_rank)
+            q = torch.randn(args.d, args.nq, generator=qg, device=device)
+        elif real is not None:
+            q = real[2]
+        else:
+            q = synth.sample(args.nq, seed=4321 + seed_rank)
+        return q if mode == "weak" or world == 1 else tpd.shard_queries(q, rank, world)
 
-    dt, scan_ms, n_batches, vals, ids = time_search(idx, queries, args.k, args.steps, args.warmup,
-                                                    dist if world > 1 else None)
-    if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def timed(mode):
+        """K timed steps in `mode`: (max-over-ranks seconds, per-rank seconds, scan ms, results, queries)"""
+        q = make_queries(mode)
+        dt_, scan_ms_, _, v_, i_ = time_search(idx, q, args.k, args.steps, args.warmup,
+                                               dist if world > 1 else None)
+        per_rank = [dt_]
+        if world > 1:
+            t = torch.tensor([dt_], device=device, dtype=torch.float64)
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            per_rank = [float(x.item()) for x in allt]
+        return max(per_rank), per_rank, scan_ms_, v_, i_, q
+
+    def mode_summary(mode, dt_, per_rank):
+        total_q = args.nq * (world if mode == "weak" else 1)
+        return {"scaling": mode, "value": round(total_q * args.steps / dt_, 1), "unit": "queries/s",
+                "queries_per_step_all_ranks": total_q, "ms_per_step": round(dt_ / args.steps * 1e3, 4),
+                "ms_per_step_rank_min": round(min(per_rank) / args.steps * 1e3, 4),
+                "ms_per_step_rank_max": round(max(per_rank) / args.steps * 1e3, 4)}
+
+    other = None
+    if world > 1:  # the mode `value` is NOT quoted in, first: the headline region runs last
+        om = "strong" if args.scaling == "weak" else "weak"
+        odt, oper, _, _, _, _ = timed(om)
+        other = mode_summary(om, odt, oper)
+    dt, per_rank_dt, scan_ms, vals, ids, queries = timed(args.scaling)
+    headline = mode_summary(args.scaling, dt, per_rank_dt)
 
     # ---- roofline of the dominant kernel (the list scan) --------------------------------------
     algo_bytes = scanned_bytes(idx, queries, args.m)  # uint8 codes only: the irreducible read
     kernel = "scan_packed_kernel" if args.layout == "packed" else "scan_ref_kernel"
     roofline = hbm_roofline(
-        algo_bytes, scan_ms, kernel, stream_peak, bytes_per_query=round(algo_bytes / args.nq, 1),
+        algo_bytes, scan_ms, kernel, stream_peak, bytes_per_query=round(algo_bytes / queries.shape[1], 1),
         cell_imbalance=round(float((idx._cell_size.double() ** 2).sum().item()) * args.n_cells
                              / float(idx._cell_size.sum().item()) ** 2, 3))
     if args.layout == "packed" and args.workload == "c2":
@@ -635,32 +687,36 @@ def main():
     shape = "SIFT1M" if real is not None else ("SIFT1M-like" if args.workload == "c2" else "synthetic")
     out = {
         "metric": "queries/sec + recall@100, SIFT1M IVFPQ d=128 m=64 nprobe=32",
-        "value": round(args.nq * args.steps * world / dt, 1), "unit": "queries/s",
+        "value": headline["value"], "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "ms_per_step": headline["ms_per_step"], "higher_is_better": True,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
         "data": data_label,
         "config": {"workload": f"{shape} d={args.d} n={args.n_base} IVFPQ n_cells={args.n_cells} "
                                f"m={args.m} nprobe={args.n_probe} k={args.k} on 1xMI355X per rank",
-                   "n_query_per_rank": args.nq, "code_layout": args.layout,
+                   "n_query_per_rank": int(queries.shape[1]), "code_layout": args.layout,
                    "codes": "u8 (8-bit PQ)", "arithmetic": "f32 LUT entries, f32 sums, exact ids",
                    "use_smart_probing": False, "parallelism": f"query-sharded x{world}, replicated index",
                    "collective_backend": backend, "world_size_seen": world,
-                   "index_broadcast_s": round(t_bcast, 3)},
+                   "index_broadcast_s": round(t_bcast, 3), "index_broadcast_bytes": bcast_bytes,
+                   "ms_per_step_rank_min": headline["ms_per_step_rank_min"],
+                   "ms_per_step_rank_max": headline["ms_per_step_rank_max"]},
         "roofline": roofline,
     }
+    if other is not None:
+        out["other_scaling"] = other
     if rank == 0:
         out["train_s"] = round(t_train, 3)
         out["add_s"] = round(t_add, 3)
         if base is not None:
             # recall@k = the true nearest neighbour (exact L2 on the raw vectors) is in the top-k:
             # the reference benchmark's definition, on a 1000-query sample
-            ns = min(1000, args.nq)
+            ns = min(1000, queries.shape[1])
             nn = gt_nn[:ns] if gt_nn is not None else exact_nn(queries[:, :ns], base)
             out["recall_gt@%d" % args.k] = round(float((ids[:ns] == nn[:, None]).any(dim=1).float().mean().item()), 4)
             out["recall_gt@1"] = round(float((ids[:ns, 0] == nn).float().mean().item()), 4)
         if not args.no_cpu_baseline and world == 1 and args.workload == "c2":  # rank 0 at N=1 only
-            cb, cpu_ids = cpu_baseline(idx, queries, args.k, min(args.cpu_sample, args.nq))
+            cb, cpu_ids = cpu_baseline(idx, queries, args.k, min(args.cpu_sample, queries.shape[1]))
             out["cpu_baseline"] = cb
             gpu_ids = ids[:cpu_ids.shape[0]].cpu().numpy()
             inter = [len(np.intersect1d(gpu_ids[q], cpu_ids[q])) for q in range(cpu_ids.shape[0])]

@@ -90,3 +90,28 @@ def test_bench_gpus2_self_launches_under_the_one_device_hook():
     assert rec["config"]["collective_backend"] == "gloo"
     assert rec["value"] > 0 and rec["scaling"] == "weak" and rec["steps"] == 2
     assert "cpu_baseline" not in rec and "secondary" not in rec
+    # weak: 512 queries per rank; the strong-scaling leg (ONE 512-query batch split 256 + 256) rides
+    # on the same line, with the per-rank spread and the broadcast volume
+    cfg = rec["config"]
+    assert cfg["n_query_per_rank"] == 512 and cfg["index_broadcast_bytes"] > 60000 * 64
+    assert 0 < cfg["ms_per_step_rank_min"] <= cfg["ms_per_step_rank_max"] == rec["ms_per_step"]
+    other = rec["other_scaling"]
+    assert other["scaling"] == "strong" and other["queries_per_step_all_ranks"] == 512 and other["value"] > 0
+
+
+def test_bench_gpus2_strong_scaling_is_the_headline_when_asked():
+    env = dict(os.environ, TPQ_BENCH_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+         "--scaling", "strong", "--nq", "511", "--n-base", "60000", "--n-train", "20000", "--n-cells", "64",
+         "--n-probe", "8"],
+        env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["scaling"] == "strong" and rec["n_gpus"] == 2
+    assert rec["config"]["n_query_per_rank"] == 256          # rank 0's share of 511 (256 + 255)
+    assert rec["other_scaling"]["scaling"] == "weak"
+    assert rec["other_scaling"]["queries_per_step_all_ranks"] == 2 * 511
+    assert abs(rec["value"] - 511 * 2 / (rec["ms_per_step"] * 2e-3)) / rec["value"] < 0.01

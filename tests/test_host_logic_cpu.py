@@ -105,6 +105,53 @@ def test_bench_launch_command_and_defaults():
     a = bench.parse_args(["--workload", "c4", "--gpus", "8"])
     assert (a.n_base, a.n_cells, a.n_probe) == (100_000_000, 16384, 64)
     assert len(bench.source_fingerprint()) == 16
+    assert a.scaling == "weak" and bench.parse_args(["--scaling", "strong"]).scaling == "strong"
+
+
+def test_bench_sets_the_rccl_environment_on_both_entry_paths():
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC, which RCCL needs on this driver) must
+    be in place before the first HIP call under the DRIVER's `torch.distributed.run ... bench.py`
+    (WORLD_SIZE already set: main() never goes through self_launch) as well as under self_launch."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    probe = (
+        "import os, sys, importlib.util\n"
+        "os.environ.pop('HSA_ENABLE_IPC_MODE_LEGACY', None)\n"
+        "spec = importlib.util.spec_from_file_location('bench_mod', sys.argv[1])\n"
+        "assert 'torch' not in sys.modules\n"
+        "b = importlib.util.module_from_spec(spec)\n"
+        "import builtins\n"
+        "orig = builtins.__import__\n"
+        "seen = {}\n"
+        "def hook(name, *a, **k):\n"
+        "    if name == 'torch' and 'at_torch_import' not in seen:\n"
+        "        seen['at_torch_import'] = os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')\n"
+        "    return orig(name, *a, **k)\n"
+        "builtins.__import__ = hook\n"
+        "spec.loader.exec_module(b)\n"
+        "builtins.__import__ = orig\n"
+        "print('AT_IMPORT', seen.get('at_torch_import'))\n"
+        "print('AFTER', os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'), os.environ.get('MASTER_ADDR'))\n"
+        "env = b.rccl_env({})\n"
+        "print('CHILD', env['HSA_ENABLE_IPC_MODE_LEGACY'], env['MASTER_ADDR'])\n")
+    # the driver's entry path: a rank of torch.distributed.run (WORLD_SIZE set), env var absent
+    env = dict(os.environ, WORLD_SIZE="8", RANK="3", LOCAL_RANK="3")
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+    env.pop("MASTER_ADDR", None)
+    out = subprocess.run([sys.executable, "-c", probe, os.path.join(ROOT, "bench.py")], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert "AT_IMPORT 0" in out.stdout, out.stdout      # set before torch (hence HIP) is imported
+    assert "AFTER 0 127.0.0.1" in out.stdout, out.stdout
+    assert "CHILD 0 127.0.0.1" in out.stdout, out.stdout  # what self_launch hands its ranks
+    # an explicit setting by the operator is respected
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "1"
+    out = subprocess.run([sys.executable, "-c", probe.replace(
+        "os.environ.pop('HSA_ENABLE_IPC_MODE_LEGACY', None)\n", ""), os.path.join(ROOT, "bench.py")],
+        env=env, capture_output=True, text=True, timeout=300)
+    assert "AFTER 1" in out.stdout, out.stdout + out.stderr[-500:]
 
 
 def test_assign_path_policy_and_host_side_shape_functions():

@@ -59,6 +59,8 @@ def replicate_index(index, src=0, group=None):
     configuration ~7.3 GB, per-link bound on xGMI -- tens of ms, paid once at load)."""
     sd = index.state_dict() if dist.get_rank(group) == src else {}
     sd = broadcast_state(sd, src=src, device=index.device, group=group)
+    # bytes that crossed the links, for the record (bench.py `index_broadcast_bytes`)
+    index.replicated_bytes = int(sum(v.numel() * v.element_size() for v in sd.values()))
     extra = [None]
     if dist.get_rank(group) == src:
         extra[0] = {"n_probe": index.n_probe, "use_smart_probing": index.use_smart_probing,
