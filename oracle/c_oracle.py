@@ -34,6 +34,7 @@ def lib():
         _lib.oracle_scan_topk_residual.restype = C.c_int64
         _lib.oracle_adc_lut.restype = None
         _lib.oracle_max_sim.restype = None
+        _lib.oracle_coarse_sims.restype = None
     return _lib
 
 
@@ -128,3 +129,18 @@ def max_sim(A, B, distance="euclidean", numerics="direct", n_threads=None):
     lib().oracle_max_sim(_p(A), _p(B), _p(vals), _p(inds), C.c_int(l), C.c_int(d), C.c_int(m),
                          C.c_int(n), C.c_int(_MODES[(distance, numerics)]), C.c_int(nt))
     return vals, inds
+
+
+def coarse_sims(x, centroids, n_threads=None):
+    """sims [nq, n_cells] of the coarse step in the fp32-MFMA kernels' arithmetic (bit-exact check of
+    tpq_ivfpq_coarse_probe); x [d, nq], centroids [d, n_cells]"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    centroids = np.ascontiguousarray(centroids, dtype=np.float32)
+    d, nq = x.shape
+    assert centroids.shape[0] == d
+    n_cells = centroids.shape[1]
+    sims = np.empty((nq, n_cells), np.float32)
+    nt = n_threads or os.cpu_count() or 1
+    lib().oracle_coarse_sims(_p(x), _p(centroids), _p(sims), C.c_int(d), C.c_int(nq), C.c_int(n_cells),
+                             C.c_int(nt))
+    return sims

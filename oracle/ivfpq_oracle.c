@@ -256,3 +256,32 @@ void oracle_max_sim(const float *A, const float *B, float *vals, int64_t *inds, 
     free(b2);
   }
 }
+
+/* Coarse step, euclidean (torchpq/metric.py:75-98 as the index calls it, index/IVFPQIndex.py:485-494):
+ * sims[q][c] = (2 dot - |x_q|^2) - |C_c|^2 with dot, |x|^2, |C|^2 ascending-k fmaf chains from 0 --
+ * the arithmetic of the fp32-MFMA coarse kernels (an MFMA is an ascending-k fma chain), so the
+ * device sims can be checked bit for bit.
+ * x f32 [d][nq], C f32 [d][n_cells] -> sims f32 [nq][n_cells] */
+void oracle_coarse_sims(const float *x, const float *C, float *sims, int d, int nq, int n_cells,
+                        int n_threads) {
+  float *c2 = (float *)malloc(sizeof(float) * (size_t)n_cells);
+  for (int c = 0; c < n_cells; c++) {
+    float s = 0.f;
+    for (int k = 0; k < d; k++) s = fmaf(C[(int64_t)k * n_cells + c], C[(int64_t)k * n_cells + c], s);
+    c2[c] = s;
+  }
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+  for (int q = 0; q < nq; q++) {
+    float q2 = 0.f;
+    for (int k = 0; k < d; k++) q2 = fmaf(x[(int64_t)k * nq + q], x[(int64_t)k * nq + q], q2);
+    for (int c = 0; c < n_cells; c++) {
+      float acc = 0.f;
+      for (int k = 0; k < d; k++) acc = fmaf(C[(int64_t)k * n_cells + c], x[(int64_t)k * nq + q], acc);
+      float v = 2.f * acc;
+      v = v - q2;
+      v = v - c2[c];
+      sims[(int64_t)q * n_cells + c] = v;
+    }
+  }
+  free(c2);
+}

@@ -346,3 +346,35 @@ def test_cosine_index_against_reference(fx_cosine):
             sl = sl[is_empty[sl] == 0]
             exact = np.sort(fx["ref_dot_decode"][q][sl])[::-1][:k]
             np.testing.assert_allclose(v[q][:exact.size], exact, rtol=1e-4, atol=1e-5)
+
+
+def test_label_disagreement_between_direct_and_expanded_numerics_is_measured():
+    """the reference CUDA kernel accumulates fmaf(-(a-b), (a-b), acc)
+    (max_sim.cu:78-98, oracle numerics="direct"); the MFMA kernels -- and therefore every cell /
+    code that add() stores -- use 2ab - a^2 - b^2 on ascending-k chains (numerics="expanded").  The
+    two disagree only where two centroids are within a few ulps of the same distance; this test puts
+    a NUMBER on it (INTEGRATION.md 4 quotes the 200 000-point run) and bounds it."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(0)
+    d, n, k = 128, 40000, 512
+    cen = np.abs(rng.standard_normal((d, 64))) * 40
+    sift = np.clip(np.round(np.abs(cen[:, rng.integers(0, 64, n)] + rng.standard_normal((d, n)) * 25)), 0, 218)
+    gist = np.clip(rng.random((d, n)) * 0.6 + rng.standard_normal((d, n)) * 0.1, 0, 1)
+    gauss = rng.standard_normal((d, n)) * 3
+    rates = {}
+    for name, A in (("sift", sift), ("gist", gist), ("gauss", gauss)):
+        A = A.astype(np.float32)
+        B = A[:, rng.permutation(n)[:k]] + (rng.random((d, k)) * 0.5 if name == "sift"
+                                            else rng.standard_normal((d, k)) * 0.01).astype(np.float32)
+        v0, i0 = c_oracle.max_sim(A[None], B[None], "euclidean", "direct")
+        v1, i1 = c_oracle.max_sim(A[None], B[None], "euclidean", "expanded")
+        rates[name] = float((i0 != i1).mean())
+        # the maxima agree to fp32 accuracy of the scale |a|^2 + |b|^2 ...
+        assert np.abs(v0 - v1).max() <= 2e-5 * np.abs(v0).max()
+        # ... and where the labels differ the two candidates are a near-tie under BOTH numerics
+        for p in np.nonzero(i0[0] != i1[0])[0]:
+            da = -((A[:, p].astype(np.float64) - B[:, i0[0, p]]) ** 2).sum()
+            db = -((A[:, p].astype(np.float64) - B[:, i1[0, p]]) ** 2).sum()
+            assert abs(da - db) <= 1e-5 * abs(da)
+    print("label disagreement direct vs expanded:", rates)
+    assert max(rates.values()) <= 1e-3

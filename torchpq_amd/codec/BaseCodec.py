@@ -5,6 +5,7 @@ buffer ``_is_trained`` next to the k-means child module, so trained indexes inte
 import torch
 
 from ..CustomModule import CustomModule
+from ..util import tensor_version
 
 
 class BaseCodec(CustomModule):
@@ -22,7 +23,7 @@ class BaseCodec(CustomModule):
         # (in-place writes -- `_is_trained.fill_()`, `.data = ...`, a stock load_state_dict
         # copying into the buffer -- bump the tensor's version counter or replace its storage)
         t = self._is_trained
-        key = (t._version, t.data_ptr())
+        key = (tensor_version(t), t.data_ptr())  # inference tensors carry no version counter
         cached = self.__dict__.get("_trained_seen")
         if cached is None or cached[0] is not t or cached[1] != key:
             cached = (t, key, bool(t))

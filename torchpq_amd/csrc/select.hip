@@ -454,21 +454,25 @@ __global__ __launch_bounds__(256) void coarse_sims_small_kernel(const float* __r
     if (bt + 1 < n_batches) load_batch((bt + 1) * kCsKB);
 #pragma unroll
     for (int kk = 0; kk < kCsKB / 2; ++kk) {
-      const float a = As[buf][2 * kk + half][wq + l31];
-      a2 = fmaf(a, a, a2);
+      // both k rows of the step in every lane: the norms are ONE ascending-k fmaf chain, the same
+      // arithmetic as coarse_sims_kernel (and oracle_coarse_sims) -- a sim does not depend on
+      // which of the kernels the batch size selects.  (Even / odd partial chains added at the end
+      // differed from it in the last bit.)
+      const float a0 = As[buf][2 * kk][wq + l31], a1 = As[buf][2 * kk + 1][wq + l31];
+      a2 = fmaf(a0, a0, a2);
+      a2 = fmaf(a1, a1, a2);
+      const float a = half ? a1 : a0;
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
-        const float b = Bs[buf][2 * kk + half][wc + 32 * t + l31];
-        b2[t] = fmaf(b, b, b2[t]);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        const float b0 = Bs[buf][2 * kk][wc + 32 * t + l31], b1 = Bs[buf][2 * kk + 1][wc + 32 * t + l31];
+        b2[t] = fmaf(b0, b0, b2[t]);
+        b2[t] = fmaf(b1, b1, b2[t]);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, half ? b1 : b0, acc[t], 0, 0, 0);
       }
     }
     if (bt + 1 < n_batches) store_batch(buf ^ 1);
     __syncthreads();
   }
-  a2 += __shfl_xor(a2, 32, 64);
-#pragma unroll
-  for (int t = 0; t < CT; ++t) b2[t] += __shfl_xor(b2[t], 32, 64);
   if (wave < 2 && half == 0) q2s[32 * wave + l31] = a2;
   __syncthreads();
 #pragma unroll

@@ -8,6 +8,8 @@ through its wrappers.)
 """
 import torch
 
+from ..util import tensor_version
+
 
 class GraphedSearch:
     """``g = index.graphed_search(n_query, k); values, ids = g(x)``.
@@ -42,7 +44,7 @@ class GraphedSearch:
     def _snapshot(cls, index):
         knobs = tuple(getattr(index, name) for name in cls.KNOBS)
         bufs = cls._buffers(index)
-        ident = tuple((name, None if t is None else (t.data_ptr(), tuple(t.shape), t._version))
+        ident = tuple((name, None if t is None else (t.data_ptr(), tuple(t.shape), tensor_version(t)))
                       for name, t in bufs.items())
         return knobs, ident, bufs
 

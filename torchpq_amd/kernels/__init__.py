@@ -44,6 +44,7 @@ class IVFPQTopkHip:
         # measurement hook (bench.py): when a list, every call appends a (start, stop) pair of
         # timing events recorded on the launch stream around the scan kernel(s)
         self.record_events = None
+        self.last_n_split = None
 
     def _n_split(self, n_query, device, slots_hint=None):
         """Workgroups per query so that small batches still fill the chip (256 CUs x 2).
@@ -104,6 +105,7 @@ class IVFPQTopkHip:
         lib = load()
         if n_split is None:
             n_split = self._n_split(n_query, device, slots_hint)
+        self.last_n_split = n_split  # diagnostics / tests: workgroups per query of the last call
         ws_bytes = lib.tpq_ivfpq_scan_workspace_bytes(n_query, k, n_split, self.m)
         ws = torch.empty(max(ws_bytes, 1), device=device, dtype=torch.uint8) if ws_bytes else None
         ev = None
@@ -161,6 +163,7 @@ class IVFPQTopkHip:
         lib = load()
         if n_split is None:
             n_split = self._n_split(n_query, device, slots_hint)
+        self.last_n_split = n_split  # diagnostics / tests: workgroups per query of the last call
         ws_bytes = lib.tpq_ivfpq_scan_workspace_bytes(n_query, k, n_split, self.m)
         ws = torch.empty(max(ws_bytes, 1), device=device, dtype=torch.uint8)
         metric = _lib.METRIC_NEG_SQ_L2 if distance == "euclidean" else _lib.METRIC_INNER
@@ -265,6 +268,7 @@ class IVFPQTopkHip:
         lib = load()
         if n_split is None:
             n_split = self._n_split(n_query, device, slots_hint)
+        self.last_n_split = n_split  # diagnostics / tests: workgroups per query of the last call
         ws_bytes = lib.tpq_ivfpq_scan_workspace_bytes(n_query, k, n_split, self.m)
         ws = torch.empty(max(ws_bytes, 1), device=device, dtype=torch.uint8)
         ev = None

@@ -32,6 +32,16 @@ def check_device(tensor, *device):
     return tensor.device in wanted
 
 
+def tensor_version(t):
+    """In-place-write counter of `t`, or None where PyTorch keeps none: tensors created under
+    torch.inference_mode() raise on `._version` ("Inference tensors do not track version counter").
+    Callers that cache on (identity, data_ptr, version) then fall back to identity + data_ptr --
+    inference tensors cannot be written in place outside inference mode anyway."""
+    if t is None:
+        return None
+    return None if t.is_inference() else t._version
+
+
 def normalize(x, dim=0):
     return x / (x.norm(dim=dim, keepdim=True) + 1e-9)
 
