@@ -140,6 +140,7 @@ def build_index(args, device, base, train):
     t0 = time.time()
     for b in range(0, n_base, 1 << 18):
         idx.add(base[:, b:b + (1 << 18)].contiguous())
+    idx.release_spare()  # the idle growth arena (as large as the index)
     torch.cuda.synchronize()
     return idx, t_train, time.time() - t0
 
@@ -358,6 +359,7 @@ def secondary_c3(device, stream_peak, steps=10):
     t0 = time.time()
     for b in range(0, n, 1 << 17):
         idx.add(sample(min(1 << 17, n - b)))
+    idx.release_spare()
     torch.cuda.synchronize()
     t_add = time.time() - t0
     idx.n_probe, idx.use_smart_probing = n_probe, False

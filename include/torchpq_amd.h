@@ -283,7 +283,12 @@ int tpq_max_sim_select(const float* A, const float* B, float* vals, int64_t* ind
  * replaces ComputeCentroidsCuda.__call__  torchpq/kernels/ComputeCentroidsCuda.py:43-81
  *          kernel compute_centroids       torchpq/kernels/cuda/compute_centroids.cu:10-86
  * data f32 [l][d][n], labels i64 [l][n] -> centroids f32 [l][d][k]; empty cluster -> 0.
- * workspace: tpq_compute_centroids_workspace_bytes(l, d, k) (zeroed by the call). */
+ * workspace: tpq_compute_centroids_workspace_bytes(l, d, k) (zeroed by the call).
+ * Non-finite data (documented divergence): for k <= 256, d >= 32 the sums run as one-hot x data on
+ * the bf16 matrix cores, where a NaN / Inf coordinate reaches every cluster of its 16-point group
+ * through 0 * x (up to 256 centroids turn NaN in that dimension); the scalar kernels used for the
+ * other shapes, and the reference, confine it to the point's own cluster.  Finite inputs are
+ * unaffected; callers that may hold NaN / Inf must sanitise the data first. */
 size_t tpq_compute_centroids_workspace_bytes(int l, int d, int k);
 int tpq_compute_centroids(const float* data, const int64_t* labels, float* centroids, int l, int d,
                           int64_t n, int k, void* workspace, size_t workspace_bytes,

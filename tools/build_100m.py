@@ -67,6 +67,7 @@ def build(n_total=100_000_000, chunk=1 << 20, d=128, m=64, n_cells=16384, n_trai
         cells_all[b:b + cnt] = idx.get_cell_by_address(adr).to(cells_all.dtype)
         if verbose and ci % 10 == 0:
             print(f"chunk {ci}: {cnt} vectors, add {1e3 * (t2 - t1):.1f} ms, capacity {idx.capacity}", flush=True)
+    idx.release_spare()  # the idle growth arena: as large as the index
     t.update({"generate_s": t_gen, "add_s": t_add, "chunks": (n_total + chunk - 1) // chunk,
               "chunks_that_grew_the_storage": grows, "n": n_total, "capacity": idx.capacity,
               "vectors_per_s": n_total / t_add})

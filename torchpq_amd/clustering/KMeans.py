@@ -83,7 +83,9 @@ class KMeans(CustomModule):
         assert self.centroids is not None, "kmeans is not trained"
         d, m = query.shape
         n = self.centroids.shape[1]
-        if m * n * d >= self.fast_predict_min_work and n >= 64 and CoarseAssignHip.supported(d, m, n):
+        # assign_precision="fp32" opts out of every selection kernel: tpq_max_sim everywhere
+        if (self._multi.assign_precision != "fp32" and m * n * d >= self.fast_predict_min_work and n >= 64
+                and CoarseAssignHip.supported(d, m, n)):
             centroids = self.centroids
             if self.distance == "cosine":  # normalised exactly as get_labels does, then inner product
                 query = query / (query.norm(dim=-2, keepdim=True) + 1e-8)

@@ -38,9 +38,12 @@ class MultiKMeans(CustomModule):
         self.distance = distance
         self.init_mode = init_mode
         self.register_buffer("centroids", None)
-        # arithmetic of the assign step INSIDE fit(): "bf16x3" = tpq_max_sim_split where it applies
-        # (split_min_d <= d <= 64), "fp32" = the bit-exact kernel everywhere.  predict() / get_labels()
-        # / kmeans++ always use the bit-exact kernel.
+        # "bf16x3" (default): the assign step may run on the bf16 matrix cores -- inside fit() per
+        # `_assign_path`; in KMeans.predict / PQCodec.encode only through the selection kernels,
+        # whose labels equal the fp32 kernel's bit for bit (error-bounded selection + exact
+        # re-check).  "fp32" = tpq_max_sim, the bit-exact fp32-MFMA kernel, EVERYWHERE: fit(),
+        # KMeans.predict (the coarse assign of IVFPQIndex.add) and PQCodec.encode.
+        # MultiKMeans.predict() / get_labels() / kmeans++ always use the fp32 kernel.
         self.assign_precision = assign_precision
         self.max_sim_hip = MaxSimHip(dim=2, distance=distance)
         self.max_sim_split_hip = MaxSimHip(dim=2, distance=distance, precision="bf16x3")

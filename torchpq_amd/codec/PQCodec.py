@@ -50,7 +50,9 @@ class PQCodec(BaseCodec):
         # + exact re-check of tpq_max_sim_select -- the fp32 kernel's labels, bit for bit, ~2x faster;
         # narrow ones (SIFT's 2, GIST's 8) stay on the fp32 MFMA, whose K = 2 wastes nothing
         km = self.kmeans
-        if (self.distance in ("euclidean", "inner") and self.d_subvector >= km.split_min_d
+        # (kmeans.assign_precision = "fp32" opts out: tpq_max_sim everywhere)
+        if (km.assign_precision != "fp32" and self.distance in ("euclidean", "inner")
+                and self.d_subvector >= km.split_min_d
                 and n_data * 256 * self.d_vector >= self.select_min_work
                 and km.max_sim_select_hip.supported(self.n_subvectors, self.d_subvector, n_data, 256)):
             _, labels = km.max_sim_select_hip(x.contiguous(), self.codebook)

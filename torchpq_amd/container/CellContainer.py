@@ -207,7 +207,12 @@ class CellContainer(BaseContainer):
 
     def release_spare(self):
         """Free the arena side that holds no live buffer (the destination of the next growth).
-        Worth calling after a bulk build: the spare is as large as the index."""
+        Call it after a bulk build (bench.py, tools/build_100m.py do): the spare is as large as
+        the index -- containers above `arena_min_bytes` otherwise keep up to ~3x their size
+        resident (two arenas of 1.5x the request).
+        Growth INVALIDATES earlier references to `_storage` / `_address2id` / `_is_empty` (and
+        tensors of a `state_dict(keep_vars=True)`): the arena side they point into is reused two
+        growths later.  `state_dict()` hands out copies and is safe."""
         for pair in self._arena.values():
             pair[1 - self._arena_side] = None
 
@@ -274,7 +279,8 @@ class CellContainer(BaseContainer):
 
     def _compact(self):
         """Pack the live slots of every cell to the front of its range (stable), so that
-        [start, start+size) holds no tombstone.  Capacities and starts are unchanged."""
+        [start, start+size) holds no tombstone.  Capacities and starts are unchanged.
+        Returns the old -> new address map [capacity] (-1 for slots that were empty)."""
         dev = self._storage.device
         cap = self.capacity
         pos = torch.arange(cap, device=dev)
@@ -304,6 +310,9 @@ class CellContainer(BaseContainer):
         self._packed_valid = False
         self._codes_version += 1
         self._drop_inverse_id_mapping()
+        new_of_old = torch.full((cap,), -1, device=dev, dtype=torch.long)
+        new_of_old[src] = dst
+        return new_of_old
 
     def _apply(self, fn, *args, **kwargs):
         """.to() / .cuda(): the derived scan-layout copy is not a registered buffer -- drop it
@@ -340,9 +349,10 @@ class CellContainer(BaseContainer):
         if self._has_holes:
             # a foreign state_dict left tombstones inside some [start, start+size): the dense
             # bookkeeping below needs every cell packed first (addresses change; ids do not)
-            ids_to_remove = self._address2id[address]
-            self._compact()
-            address = self.get_address_by_id(ids_to_remove)
+            # (remapped through the compaction's own old -> new map: going through the ids would
+            # mis-resolve duplicate ids -- get_address_by_id returns one address per id -- and cost
+            # O(n_ids x capacity) without the inverse table)
+            address = self._compact()[address]
         cells = self.get_cell_by_address(address)
         ucells, counts = cells.unique(return_counts=True)
         old_end = (self._cell_start + self._cell_size)[ucells]
