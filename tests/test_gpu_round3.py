@@ -273,3 +273,75 @@ def test_train_add_search_under_inference_mode():
     assert torch.equal(v1, v2) and torch.equal(i1, i2)
     assert gs.stale_reason() is None
     assert float((i2[:, 0].cpu() == torch.arange(50)).float().mean()) > 0.8
+
+
+# ---------------------------------------------------------------------------------------------
+# ADVICE r2 lows
+# ---------------------------------------------------------------------------------------------
+def test_remove_by_address_on_holes_with_duplicate_ids(fx_tomb):
+    """remove(address=...) on a container with tombstones inside cells AND duplicate ids: the
+    addresses are carried through the compaction by its own old -> new map, not through the ids
+    (get_address_by_id resolves a duplicated id to ONE address: the wrong slot, or fewer slots,
+    were removed before)."""
+    from torchpq_amd.index import IVFPQIndex
+    fx = fx_tomb
+    idx = IVFPQIndex(d_vector=int(fx["d"]), n_subvectors=int(fx["m"]), n_cells=int(fx["n_cells"]), device=DEV)
+    idx.load_state_dict({k[3:]: torch.from_numpy(v.copy()) for k, v in fx.items() if k.startswith("sd.")})
+    assert idx._has_holes
+    a2i = N(idx._address2id)
+    live = np.nonzero(a2i >= 0)[0]
+    # make every live slot share its id with another one (ids 0..n/2-1, each twice)
+    dup = np.arange(live.shape[0]) // 2
+    idx._address2id[T(live)] = T(dup.astype(np.int64))
+    idx._drop_inverse_id_mapping()
+    codes = N(idx._storage).transpose(1, 0, 2).reshape(a2i.shape[0], -1)   # [slot][m]
+    victims = live[3::5]                                                   # one of each pair, mostly
+    keep = np.setdiff1d(live, victims)
+    want = sorted((int(dup[np.searchsorted(live, a)]), codes[a].tobytes()) for a in keep)
+    idx.remove(address=T(victims.astype(np.int64)))
+    assert not idx._has_holes and idx.n_items == keep.shape[0]
+    a2i2 = N(idx._address2id)
+    codes2 = N(idx._storage).transpose(1, 0, 2).reshape(a2i2.shape[0], -1)
+    got = sorted((int(a2i2[a]), codes2[a].tobytes()) for a in np.nonzero(a2i2 >= 0)[0])
+    assert got == want                       # exactly the survivors, each with its own code
+    st, sz = N(idx._cell_start), N(idx._cell_size)
+    ie = N(idx._is_empty)
+    for c in range(idx.n_cells):
+        assert np.all(ie[st[c]:st[c] + sz[c]] == 0)
+
+
+def test_assign_precision_fp32_opts_out_of_the_selection_kernels(monkeypatch):
+    """assign_precision="fp32": KMeans.predict (the coarse assign of add) and PQCodec.encode call
+    tpq_max_sim only; the default routes the same shapes through the selection kernels -- with the
+    same labels."""
+    import torchpq_amd.kernels as K
+    from torchpq_amd.clustering import KMeans
+    from torchpq_amd.codec import PQCodec
+    calls = []
+    for cls in (K.CoarseAssignHip, K.MaxSimSelectHip):
+        orig = cls.__call__
+        monkeypatch.setattr(cls, "__call__", (lambda o: lambda self, *a, **kw: (calls.append(type(self).__name__),
+                                                                                 o(self, *a, **kw))[1])(orig))
+    g = torch.Generator(device=DEV)
+    g.manual_seed(11)
+    x = torch.randn(64, 300_000, generator=g, device=DEV)
+    cent = x[:, :1024].contiguous()
+    labels = {}
+    for prec in ("bf16x3", "fp32"):
+        km = KMeans(n_clusters=1024, assign_precision=prec)
+        km.register_buffer("centroids", cent)
+        calls.clear()
+        labels[prec] = km.predict(x)
+        assert ("CoarseAssignHip" in calls) == (prec == "bf16x3"), (prec, calls)
+    assert torch.equal(labels["bf16x3"], labels["fp32"])
+    codes = {}
+    np.random.seed(0)
+    for prec in ("bf16x3", "fp32"):
+        pq = PQCodec(d_vector=64, n_subvectors=4).to(DEV)          # d_sub = 16 >= split_min_d
+        pq.kmeans.assign_precision = prec
+        pq.kmeans.register_buffer("centroids", x[:, :256].reshape(4, 16, 256).contiguous())
+        pq._trained(True)
+        calls.clear()
+        codes[prec] = pq.encode(x)
+        assert ("MaxSimSelectHip" in calls) == (prec == "bf16x3"), (prec, calls)
+    assert torch.equal(codes["bf16x3"], codes["fp32"])

@@ -8,4 +8,4 @@ from . import clustering, codec, container, fn, index, kernels, metric, util  # 
 from .CustomModule import CustomModule  # noqa: F401
 from ._lib import TorchPQAmdError, load as load_library  # noqa: F401
 
-__version__ = "0.2.0"
+from ._version import __version__  # noqa: F401,E402
