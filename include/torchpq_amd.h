@@ -279,6 +279,35 @@ size_t tpq_max_sim_select_workspace_bytes(int l, int d, int64_t m, int n);
 int tpq_max_sim_select(const float* A, const float* B, float* vals, int64_t* inds, int l, int d, int64_t m,
                        int n, int metric, void* workspace, size_t workspace_bytes, tpq_stream_t stream);
 
+/* a-8 + a-9 on PREPARED data: one Lloyd iteration of the PQ-codebook training shape
+ * replaces, per iteration, the get_labels -> compute_centroids pair of the reference's driver
+ *          torchpq/clustering/MultiKMeans.py:415-453 (max_sim_tn, kernels/cuda/max_sim.cu:182-309;
+ *          compute_centroids, kernels/cuda/compute_centroids.cu:10-86)
+ * tpq_lloyd_prepare (once per fit: the data never changes, only the centroids do):
+ *   data f32 [l][d][m], centroids0 f32 [l][d][n] (the initial centroids; their mean is the centring
+ *   vector) -> `prepared`: every point centred, scaled by a power of two per sub-problem and split
+ *   into two fp16 pieces in MFMA-fragment order (4 bytes per element, as the fp32 original), plus
+ *   |a'|^2, |x|^2 per point, the centring vector, the scale and a not-finite / out-of-range flag per
+ *   sub-problem.  prepared_bytes >= tpq_lloyd_prepared_bytes(l, d, m) (~ the size of data).
+ * tpq_lloyd_step: centroids f32 [l][d][n] -> inds i64 [l][m] = the labels of tpq_max_sim, BIT FOR BIT
+ *   (error-bounded top-2 selection on the fp16 matrix cores + exact fp32 re-check of the ambiguous
+ *   points on `data`), vals (optional) f32 [l][m] = the maxima (fast values, ~1e-6 of the scale; exact
+ *   for re-checked points), new_centroids (optional) f32 [l][d][n] = tpq_compute_centroids of those
+ *   labels (empty cluster -> 0).  A sub-problem whose data or centroids are not finite / leave the
+ *   fp16 range is handled entirely by the exact path (same results, slower).
+ * Shapes: d <= 64, n <= 256, slices below 2 GiB (tpq_lloyd_supported); euclidean only. */
+int tpq_lloyd_supported(int l, int d, int64_t m, int n);
+size_t tpq_lloyd_prepared_bytes(int l, int d, int64_t m);
+int tpq_lloyd_prepare(const float* data, const float* centroids0, void* prepared, size_t prepared_bytes,
+                      int l, int d, int64_t m, int n, tpq_stream_t stream);
+size_t tpq_lloyd_step_workspace_bytes(int l, int d, int64_t m, int n);
+/* diagnostics: byte offset inside the workspace of the int32 [l] counts of points left undecided by
+ * level 1 (the one-product coarse pass) / level 2 (the three-product pass; = re-checked exactly) */
+size_t tpq_lloyd_step_count_offset(int l, int d, int64_t m, int n, int level);
+int tpq_lloyd_step(const float* data, const void* prepared, const float* centroids, float* new_centroids,
+                   float* vals, int64_t* inds, int l, int d, int64_t m, int n, void* workspace,
+                   size_t workspace_bytes, tpq_stream_t stream);
+
 /* a-9  k-means update
  * replaces ComputeCentroidsCuda.__call__  torchpq/kernels/ComputeCentroidsCuda.py:43-81
  *          kernel compute_centroids       torchpq/kernels/cuda/compute_centroids.cu:10-86

@@ -55,6 +55,12 @@ SIGNATURES = {
     "tpq_max_sim_select_supported": (_i, [_i, _i, _i64, _i]),
     "tpq_max_sim_select_workspace_bytes": (_sz, [_i, _i, _i64, _i]),
     "tpq_max_sim_select": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _vp, _sz, _vp]),
+    "tpq_lloyd_supported": (_i, [_i, _i, _i64, _i]),
+    "tpq_lloyd_prepared_bytes": (_sz, [_i, _i, _i64]),
+    "tpq_lloyd_prepare": (_i, [_vp, _vp, _vp, _sz, _i, _i, _i64, _i, _vp]),
+    "tpq_lloyd_step_workspace_bytes": (_sz, [_i, _i, _i64, _i]),
+    "tpq_lloyd_step_count_offset": (_sz, [_i, _i, _i64, _i, _i]),
+    "tpq_lloyd_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _sz, _vp]),
     "tpq_coarse_assign_supported": (_i, [_i, _i64, _i]),
     "tpq_coarse_assign_workspace_bytes": (_sz, [_i, _i64, _i]),
     "tpq_coarse_assign_count_offset": (_sz, [_i, _i64, _i]),

@@ -23,7 +23,7 @@ for m in 4 8 12 16 20 24 28 32 40 48 56 64 96 120 128; do  # = TPQ_PACKED_M_LIST
     pids+=($!)
   fi
 done
-for src in api.cpp scan.hip pack.hip select.hip lut.hip kmeans.hip kmeans_split.hip assign_fast.hip container.hip ubench.hip; do
+for src in api.cpp scan.hip pack.hip select.hip lut.hip kmeans.hip kmeans_split.hip assign_fast.hip lloyd.hip container.hip ubench.hip; do
   obj="${HERE}/build/${src%.*}.o"
   if stale "$obj" "${HERE}/${src}"; then
     ( "$HIPCC" "${FLAGS[@]}" -x hip -c "${HERE}/${src}" -o "$obj" ${EXTRA_FLAGS:-} ) &

@@ -1,0 +1,949 @@
+// One Lloyd iteration of MultiKMeans.fit on PREPARED data (tpq_lloyd_prepare / tpq_lloyd_step):
+// the PQ-codebook training shape -- l sub-problems, n <= 256 centroids, d <= 64 (configs[4]).
+// Replaces, per iteration, the pair  get_labels -> compute_centroids  of the reference's driver
+// (torchpq/clustering/MultiKMeans.py:415-453: max_sim_tn torchpq/kernels/cuda/max_sim.cu:182-309 +
+// compute_centroids torchpq/kernels/cuda/compute_centroids.cu:10-86).
+//
+// What "prepared" buys.  The data of a fit() never changes, only the centroids do,
+// yet tpq_max_sim_select re-reads the fp32 points every iteration and spends a third of its
+// instructions centring and splitting them.  tpq_lloyd_prepare does it ONCE per fit:
+//   a' = s (x - mu)          mu = mean of the initial centroids (distances are translation-
+//                            invariant; any fixed shift works), s = the power of two that puts
+//                            max |x - mu| of the sub-problem in [2^13, 2^14)
+//   a' = h + m + rho         h = fp16(a'), m = fp16(a' - h):  |rho| <= 2^-22 |a'| + eta
+// and stores (h, m) in MFMA-fragment order -- tile of 32 points x k-step x piece x lane x 16 B, 4 bytes
+// per element, exactly the bytes of the fp32 original -- plus |a'|^2 and |x|^2 per point.  A tile's
+// B operands are then eight 16-byte loads per lane, no VALU work at all.
+// fp16 pieces instead of the bf16 pieces of assign_fast.hip: two fp16 pieces carry 22 significant
+// bits (two bf16: 16), so the dropped products shrink from 3 x 2^-16 to 3 x 2^-22 and the bound of the
+// selection by ~4x -- a quarter of the points go to the exact re-check -- and h + m is precise
+// enough (2^-22 relative: two ulps of fp32) to feed the centroid UPDATE from the same bytes.  The
+// price is fp16's range: hence the per-sub-problem scale, the overflow / non-finite flags (a
+// flagged sub-problem sends every point to the exact path) and eta below.
+//
+// Selection (same scheme as assign_fast.hip section 2b, re-derived for fp16; all in scaled-centred
+// units): per 32 x 32 tile  f = sum_k (C2 a1 + C1 a2 + C1 a1) - N  on v_mfma_f32_32x32x16_f16 (C = 2 c'
+// split the same way; small products first) and one bf16 MFMA for N = fl |c'|^2 (three exact bf16
+// pieces against ones);  g = 2 a'.c' - |c'|^2 is what the real-number distance orders by.
+//   |f - g| <= [3.03 2^-22 + (16 KS + 13) 2^-23 + (d + 1) 2^-24] (|a'| + |c'|max)^2      dropped
+//              products, worst-case fp32 accumulation of all MFMA terms, the norm chain
+//            + 2^-22 (|a'| + |c'|max)^2                          rounding of x - mu, c - mu
+//            + eta sqrt(d) (2 |c'|max + |a'|),  eta = 2^-13     fp16 subnormals, flushed or not
+//            + s^2 (d + 4) 2^-24 (|x| + |c|max)^2                the exact fp32 chain's own rounding
+// delta = 1.25 x that.  A point whose two best fast values differ by more than 2 delta has its
+// label decided -- the arg-max of tpq_max_sim, bit for bit; the others are listed and re-evaluated
+// by the exact fp32-MFMA kernel (launch_max_sim_list, kmeans.hip) on the raw data.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace tpq {
+int launch_max_sim_list(const float* A, const float* B, float* vals, int64_t* inds, int l, int d, int m, int n,
+                        int euclid, const int* list, const int* count, unsigned long long* keys, float* Ac, int cap,
+                        hipStream_t st);  // kmeans.hip
+namespace lloyd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I0 < I1) {
+    f(std::integral_constant<int, I0>{});
+    static_for<I0 + 1, I1>(f);
+  }
+}
+
+constexpr int kWaves = 8;
+#ifndef TPQ_LL_TILES
+#define TPQ_LL_TILES 32
+#endif
+constexpr int kTiles = TPQ_LL_TILES;  // 32-point tiles per wave and block
+
+static int ks_of(int d) { return (d + 15) / 16; }
+
+// ---- prepared block --------------------------------------------------------------------------
+struct PrepLayout {
+  int KS;
+  int64_t T;  // 32-point tiles per sub-problem
+  size_t hi_off, mid_off, norms_off, mu_off, scale_off, flag_off, maxbits_off, total;
+};
+static PrepLayout prep_layout(int l, int d, int64_t m) {
+  PrepLayout L;
+  L.KS = ks_of(d);
+  L.T = (m + 31) / 32;
+  // hi and mid pieces in separate arrays [l][T][KS][64] x 16 B: the coarse pass streams the hi pieces only
+  L.hi_off = 0;
+  L.mid_off = (size_t)l * L.T * L.KS * 1024;
+  L.norms_off = 2 * L.mid_off;
+  L.mu_off = L.norms_off + (size_t)l * L.T * 32 * 8;       // [l][T * 32] float2
+  L.scale_off = L.mu_off + (size_t)l * 64 * 4;             // [l][64] f32
+  L.flag_off = L.scale_off + (size_t)l * 4;                // [l] f32
+  L.maxbits_off = L.flag_off + (size_t)l * 4;              // [l] i32
+  L.total = (L.maxbits_off + (size_t)l * 4 + 255) / 256 * 256;
+  return L;
+}
+
+// mu[b][k] = mean over the n initial centroids of dimension k (zero beyond d)
+__global__ __launch_bounds__(256) void mu_kernel(const float* __restrict__ B, float* __restrict__ mu, int d, int n) {
+  __shared__ float red[256];
+  const int k = blockIdx.x, b = blockIdx.y;
+  const float* row = B + ((int64_t)b * d + k) * n;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < n; c += 256) s += row[c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float v = red[0] / (float)n;
+    mu[b * 64 + k] = (v == v && fabsf(v) <= 3.0e38f) ? v : 0.f;  // a non-finite mean: no centring (flagged below)
+  }
+}
+
+// max |x - mu| per sub-problem (bits of a non-negative float: integer order == value order) and a
+// flag for any non-finite element.  grid (chunks, d, l)
+__global__ __launch_bounds__(256) void maxabs_kernel(const float* __restrict__ A, const float* __restrict__ mu,
+                                                    unsigned* __restrict__ maxbits, int* __restrict__ flag, int d,
+                                                    int64_t m) {
+  const int k = blockIdx.y, b = blockIdx.z;
+  const float* row = A + ((int64_t)b * d + k) * m;
+  const float mk = mu[b * 64 + k];
+  float mx = 0.f;
+  int bad = 0;
+  const int64_t per = (m + gridDim.x - 1) / gridDim.x;
+  const int64_t i0 = (int64_t)blockIdx.x * per, i1 = (i0 + per) < m ? (i0 + per) : m;
+  if ((m & 3) == 0 && (per & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0) {
+    for (int64_t i = i0 + (int64_t)threadIdx.x * 4; i < i1; i += 1024) {
+      const float4 x = *reinterpret_cast<const float4*>(row + i);
+      const float v0 = fabsf(x.x - mk), v1 = fabsf(x.y - mk), v2 = fabsf(x.z - mk), v3 = fabsf(x.w - mk);
+      bad |= !(v0 <= 3.0e38f) | !(v1 <= 3.0e38f) | !(v2 <= 3.0e38f) | !(v3 <= 3.0e38f);
+      mx = fmaxf(fmaxf(mx, fmaxf(v0, v1)), fmaxf(v2, v3));
+    }
+  } else {
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+      const float v = fabsf(row[i] - mk);
+      bad |= !(v <= 3.0e38f);
+      mx = fmaxf(mx, v);
+    }
+  }
+  __shared__ float red[256];
+  __shared__ int redb[256];
+  red[threadIdx.x] = mx;
+  redb[threadIdx.x] = bad;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + w]);
+      redb[threadIdx.x] |= redb[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (red[0] > 0.f) atomicMax(maxbits + b, __float_as_uint(red[0]));
+    if (redb[0]) atomicOr(flag + b, 1);
+  }
+}
+
+// s[b] = 2^(13 - floor(log2 max)): max |x - mu| s in [2^13, 2^14)
+__global__ void scale_kernel(const unsigned* __restrict__ maxbits, int* __restrict__ flag, float* __restrict__ scale,
+                             int l) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= l) return;
+  const float mx = __uint_as_float(maxbits[b]);
+  float s = 1.f;
+  if (flag[b] || !(mx <= 3.0e38f)) {
+    flag[b] = 1;
+  } else if (mx > 0.f) {
+    int e = ilogbf(mx);
+    int se = 13 - e;
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    s = ldexpf(1.f, se);
+    if (!(mx * s < 16384.f)) flag[b] = 1;  // (a clamped exponent on astronomically large data)
+  }
+  scale[b] = s;
+}
+
+// pieces + norms.  grid (ceil(T / 4), l), 4 waves; wave -> tile of 32 points, lane (point l31, half)
+// holds dimensions 16 st + 8 half + j of its point: the B operand of v_mfma_f32_32x32x16_f16.
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ A, const float* __restrict__ mu,
+                                                   const float* __restrict__ scale, u32x4* __restrict__ hi,
+                                                   u32x4* __restrict__ mid, float2* __restrict__ norms, int d,
+                                                   int64_t m, int64_t T, int KS) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+  const int b = blockIdx.y;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  if (tile >= T) return;
+  const int64_t i = tile * 32 + l31;
+  const bool iv = i < m;
+  const float* Ab = A + (int64_t)b * d * m + (iv ? i : 0);
+  const float s = scale[b];
+  const int64_t fo = ((int64_t)b * T + tile) * KS * 64 + lane;
+  float n2c = 0.f, n2r = 0.f;
+  for (int st = 0; st < KS; ++st) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * st + 8 * half + j;
+      x[j] = (iv && k < d) ? Ab[(int64_t)k * m] : 0.f;
+    }
+    f16x8 h, mm;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * st + 8 * half + j;
+      const float a = (iv && k < d) ? (x[j] - mu[b * 64 + k]) * s : 0.f;
+      const _Float16 hh = (_Float16)a;
+      const float r = a - (float)hh;
+      h[j] = hh;
+      mm[j] = (_Float16)r;
+      n2c = fmaf(a, a, n2c);
+      n2r = fmaf(x[j], x[j], n2r);
+    }
+    hi[fo + st * 64] = __builtin_bit_cast(u32x4, h);
+    mid[fo + st * 64] = __builtin_bit_cast(u32x4, mm);
+  }
+  n2c += __shfl_xor(n2c, 32, 64);
+  n2r += __shfl_xor(n2r, 32, 64);
+  if (half == 0) norms[(int64_t)b * T * 32 + tile * 32 + l31] = make_float2(n2c, n2r);
+}
+
+// ---- per iteration: centroid fragments -----------------------------------------------------------
+// grid (8 units, l), 64 lanes: lane (row = centroid l31 of the unit, k-group half).
+// frags [l][8][2 KS + 1][64] x 16 B: fragment 0 = -N (N = fl |c'|^2) as three exact bf16 pieces at
+// k = 0, 1, 2 (rows beyond n: -3e38, never first or second); fragments 1 + 2 st + q = piece q of
+// C = 2 c' = 2 s (c - mu), k-step st, fp16.
+__device__ __forceinline__ void split3_bf16(float x, __bf16& p1, __bf16& p2, __bf16& p3) {
+  p1 = (__bf16)x;
+  const float r1 = x - (float)p1;
+  p2 = (__bf16)r1;
+  const float r2 = r1 - (float)p2;
+  p3 = (__bf16)r2;
+}
+
+__global__ __launch_bounds__(64) void cprep_kernel(const float* __restrict__ B, const float* __restrict__ mu,
+                                                  const float* __restrict__ scale, u32x4* __restrict__ frags,
+                                                  unsigned* __restrict__ cmax2_bits, int* __restrict__ cflag, int d,
+                                                  int n, int KS) {
+  const int unit = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+  const int c = unit * 32 + l31;
+  const int FPU = 2 * KS + 1;
+  const float* Bb = B + (int64_t)b * d * n;
+  const float s = scale[b];
+  u32x4* out = frags + ((int64_t)b * 8 + unit) * FPU * 64 + lane;
+  float N = 0.f, sraw = 0.f;
+  if (c < n)
+    for (int k = 0; k < d; ++k) {
+      const float y = Bb[(int64_t)k * n + c];
+      const float cc = (y - mu[b * 64 + k]) * s;
+      N = fmaf(cc, cc, N);
+      sraw = fmaf(y, y, sraw);
+    }
+  int bad = 0;
+  {
+    bf16x8 f = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (half == 0) {
+      __bf16 p1, p2, p3;
+      split3_bf16(c < n ? -N : -3.0e38f, p1, p2, p3);
+      f[0] = p1;
+      f[1] = p2;
+      f[2] = p3;
+    }
+    out[0] = __builtin_bit_cast(u32x4, f);
+  }
+  if (c < n) {
+    bad |= !(N <= 3.0e38f) | !(sraw <= 3.0e38f);
+    if (half == 0 && !bad) {
+      atomicMax(cmax2_bits + b * 2, __float_as_uint(N));
+      atomicMax(cmax2_bits + b * 2 + 1, __float_as_uint(sraw));
+    }
+  }
+  for (int st = 0; st < KS; ++st) {
+    f16x8 h, mm;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * st + 8 * half + j;
+      const float C = (k < d && c < n) ? 2.f * ((Bb[(int64_t)k * n + c] - mu[b * 64 + k]) * s) : 0.f;
+      bad |= !(fabsf(C) <= 65000.f);  // beyond fp16's range (or NaN): the whole sub-problem goes exact
+      const _Float16 hh = (_Float16)C;
+      const float r = C - (float)hh;
+      h[j] = hh;
+      mm[j] = (_Float16)r;
+    }
+    out[(1 + 2 * st) * 64] = __builtin_bit_cast(u32x4, h);
+    out[(2 + 2 * st) * 64] = __builtin_bit_cast(u32x4, mm);
+  }
+  if (bad) atomicOr(cflag + b, 1);
+}
+
+// ---- top-2 of fast values (assign_fast.hip) -----------------------------------------------------
+template <int CL>
+__device__ __forceinline__ void take_top2(float& b1, float& b2, int& bi, float v) {
+  static_assert(CL >= 0 && CL <= 64, "inline constant");
+  asm volatile(
+      "v_cmp_ngt_f32 vcc, %3, %0\n\t"
+      "v_cndmask_b32 %2, %4, %2, vcc\n\t"
+      "v_med3_f32 %1, %0, %1, %3\n\t"
+      "v_max_f32 %0, %3, %0"
+      : "+v"(b1), "+v"(b2), "+v"(bi)
+      : "v"(v), "n"(CL)
+      : "vcc");
+}
+template <int CL0, int CL1>
+__device__ __forceinline__ void take_top2_pair(float& p1, float& p2, int& pi, float& q1, float& q2, int& qi,
+                                               float v0, float v1) {
+  static_assert(CL0 >= 0 && CL0 <= 64 && CL1 >= 0 && CL1 <= 64, "inline constants");
+  asm volatile(
+      "v_cmp_ngt_f32 vcc, %6, %0\n\t"
+      "v_cndmask_b32 %2, %8, %2, vcc\n\t"
+      "v_cmp_ngt_f32 vcc, %7, %3\n\t"
+      "v_cndmask_b32 %5, %9, %5, vcc\n\t"
+      "v_med3_f32 %1, %0, %1, %6\n\t"
+      "v_med3_f32 %4, %3, %4, %7\n\t"
+      "v_max_f32 %0, %6, %0\n\t"
+      "v_max_f32 %3, %7, %3"
+      : "+v"(p1), "+v"(p2), "+v"(pi), "+v"(q1), "+v"(q2), "+v"(qi)
+      : "v"(v0), "v"(v1), "n"(CL0), "n"(CL1)
+      : "vcc");
+}
+
+// Key epilogue: the accumulator register number r (0..15: which of the lane's 16 centroid rows of
+// the unit) replaces the value's low 4 mantissa bits, so the running best carries its own index
+// and no compare / select is needed: per PAIR of values  t = med3(b1, k0, k1); b1 = max3(b1, k0, k1);
+// b2 = max(b2, t)  (the second best of {b1 >= b2, k0, k1} is max(med3(b1, k0, k1), b2)).  5 VALU per
+// two values against 8; the 2^-19 |v| the keys are off by is part of the bound (StepArgs::eps).
+template <int R0>
+__device__ __forceinline__ void take_keys_quad(float& p1, float& p2, float& q1, float& q2, float v0, float v1,
+                                               float v2, float v3) {
+  static_assert(R0 >= 0 && R0 + 3 <= 15, "inline constants");
+  float k0, k1, k2, k3, t0, t1;
+  asm volatile(
+      "v_and_or_b32 %4, %10, -16, %14\n\t"
+      "v_and_or_b32 %5, %11, -16, %15\n\t"
+      "v_and_or_b32 %6, %12, -16, %16\n\t"
+      "v_and_or_b32 %7, %13, -16, %17\n\t"
+      "v_med3_f32 %8, %0, %4, %5\n\t"
+      "v_med3_f32 %9, %2, %6, %7\n\t"
+      "v_max3_f32 %0, %0, %4, %5\n\t"
+      "v_max3_f32 %2, %2, %6, %7\n\t"
+      "v_max_f32 %1, %1, %8\n\t"
+      "v_max_f32 %3, %3, %9"
+      : "+v"(p1), "+v"(p2), "+v"(q1), "+v"(q2), "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3), "=&v"(t0), "=&v"(t1)
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "n"(R0), "n"(R0 + 1), "n"(R0 + 2), "n"(R0 + 3));
+}
+
+template <int R0>
+__device__ __forceinline__ void take_keys_pair(float& p1, float& p2, float v0, float v1) {
+  static_assert(R0 >= 0 && R0 + 1 <= 15, "inline constants");
+  float k0, k1, t0;
+  asm volatile(
+      "v_and_or_b32 %2, %5, -16, %7\n\t"
+      "v_and_or_b32 %3, %6, -16, %8\n\t"
+      "v_med3_f32 %4, %0, %2, %3\n\t"
+      "v_max3_f32 %0, %0, %2, %3\n\t"
+      "v_max_f32 %1, %1, %4"
+      : "+v"(p1), "+v"(p2), "=&v"(k0), "=&v"(k1), "=&v"(t0)
+      : "v"(v0), "v"(v1), "n"(R0), "n"(R0 + 1));
+}
+
+// ---- the cascade on prepared pieces ------------------------------------------------------------------
+// Level 1 (coarse_kernel): ONE product per k-step -- f0 = sum_k Ch ah - N on the hi pieces only (half the
+// bytes, 5 MFMAs per 32 x 32 tile instead of 13).  |f0 - g| carries the dropped pieces,
+//   (2^-11 + 2^-23) (|a'| + |c'|max)^2      (|a - ah| <= 2^-11 |a|, |C - Ch| <= 2^-11 |C|, 2 |c'||a'| <= (.)^2 / 2)
+// in place of 3.03 2^-22 (.)^2: the bound is ~36x wider and 5-13 % of the points stay undecided.
+// Level 2 (refine_kernel): those points, gathered through the level-1 list, with all three products
+// (the bound of the header comment): 0.2-0.7 % stay undecided.
+// Level 3: the exact fp32 kernel over the level-2 list (launch_max_sim_list, kmeans.hip).
+// Every level decides a point only when its two best fast values are further apart than twice its
+// own rigorous bound, so the labels are tpq_max_sim's whatever the split between the levels.
+struct StepArgs {
+  const u32x4* hi;             // [l][T][KS][64]
+  const u32x4* mid;            // [l][T][KS][64]
+  const float2* norms;         // [l][T * 32]: (|a'|^2, |x|^2)
+  const u32x4* frags;          // [l][8][2 KS + 1][64]
+  const unsigned* cmax2_bits;  // [l][2]: max N, max |c|^2
+  const float* scale;          // [l]
+  const int* flag;             // [l] data not finite / out of range (prepare)
+  const int* cflag;            // [l] centroids out of fp16 range (this iteration)
+  int64_t* inds;               // [l][m]
+  float* vals;                 // optional [l][m]
+  const int* list_in;          // level 2: [l][m] points to refine, count_in [l]
+  const int* count_in;
+  int* list;                   // [l][m] points this level leaves undecided
+  int* count;                  // [l]
+  int m;
+  int64_t T;
+  float eps, eps_exact, eta;   // eps: this level's fast-path bound, relative to (|a'| + |c'|max)^2; eta times sqrt(d)
+};
+
+// label, value and -- unless the two best fast values are more than 2 delta apart -- a list entry.
+// Called by all lanes of the wave.  The list is staged in LDS (one LDS atomic per wave) and flushed
+// once per block (flush_list): a RETURNING global atomic per tile put a memory round trip -- and,
+// vmcnt being in order, the wait for every load issued before it -- into each tile of level 1,
+// where 92 % of the tiles hold an undecided point (19 ms instead of 2).
+constexpr int kBlockPoints = kWaves * kTiles * 32;  // points a block decides = capacity of its staged list
+struct BlockList {
+  int n;
+  int base;
+  int item[kBlockPoints];
+};
+__device__ __forceinline__ void emit(const StepArgs& a, BlockList* bl, int b, int lane, bool valid, int64_t fi, int idx,
+                                     float B1, float B2, float2 n2, float s, float cn, float cnr, float inv_s2,
+                                     bool exact_all) {
+  // (v_sqrt_f32: 1 ulp; the norms only scale the bound, whose 1.25 covers it)
+  const float an = __builtin_amdgcn_sqrtf(n2.x), anr = __builtin_amdgcn_sqrtf(n2.y) * s;
+  const float t1 = an + cn, t2 = anr + cnr * s;
+  float delta = 1.25f * (a.eps * t1 * t1 + a.eta * (2.f * cn + an) + a.eps_exact * t2 * t2);
+  if (exact_all) delta = INFINITY;
+  if (valid) {
+    a.inds[(int64_t)b * a.m + fi] = idx;
+    if (a.vals) a.vals[(int64_t)b * a.m + fi] = (B1 - n2.x) * inv_s2;
+  }
+  const bool listed = valid && !(B1 - B2 > 2.f * delta);
+  const unsigned long long mk = __ballot(listed);
+  if (mk) {
+    const int leader = __ffsll((long long)mk) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&bl->n, __popcll(mk));  // LDS
+    base = __shfl(base, leader, 64);
+    if (listed) bl->item[base + __popcll(mk & ((1ull << lane) - 1ull))] = (int)fi;
+  }
+}
+// end of the block: reserve [base, base + n) of the sub-problem's list with one global atomic, copy
+__device__ __forceinline__ void flush_list(const StepArgs& a, BlockList* bl, int b) {
+  __syncthreads();
+  if (threadIdx.x == 0) bl->base = bl->n ? atomicAdd(a.count + b, bl->n) : 0;
+  __syncthreads();
+  const int n = bl->n, base = bl->base;
+  for (int i = threadIdx.x; i < n; i += kWaves * 64) a.list[(int64_t)b * a.m + base + i] = bl->item[i];
+}
+
+// ---- level 1 -----------------------------------------------------------------------------------------
+// A wave owns WIDE tiles of 64 points (two MFMA column tiles sharing every A operand: at one A
+// operand per MFMA the centroid fragments alone would take the whole LDS bandwidth -- 1 KiB per
+// 32-cycle MFMA per SIMD = 128 B/clk/CU); the two accumulators of a k-step are independent, so no
+// MFMA waits for the one before it.  LDS holds -N and the hi pieces of the centroids only (40 KiB).
+constexpr int kWide = kTiles / 2;  // wide tiles per wave and block
+
+template <int KS>
+__global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
+  constexpr int FPU = 2 * KS + 1;  // fragments per unit in global memory
+  constexpr int FL = KS + 1;       // ... in LDS
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int m = a.m;
+  BlockList* bl = reinterpret_cast<BlockList*>(smem + 8 * FL * 1024);
+  if (threadIdx.x == 0) bl->n = 0;
+  {
+    const char* src = reinterpret_cast<const char*>(a.frags) + (size_t)b * 8 * FPU * 1024;
+    for (int f = wave; f < 8 * FL; f += kWaves) {
+      const int unit = f / FL, j = f % FL;
+      const int sf = unit * FPU + (j ? 2 * j - 1 : 0);  // -N, then the hi piece of k-step j - 1
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + sf * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(smem + f * 1024), 16, 0, 0);
+    }
+  }
+  const int64_t slice = a.T * KS * 1024;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(a.hi) + (size_t)b * slice), 0, (int)slice, 0x00020000);
+  const float2* __restrict__ nrm = a.norms + (int64_t)b * a.T * 32;
+  auto wide_of = [&](int t) -> int64_t { return ((int64_t)blockIdx.x * kWide + t) * kWaves + wave; };
+  auto frag_voff = [&](int t) -> int {
+    const int64_t wt = wide_of(t);
+    return (t < kWide && 2 * wt < a.T) ? (int)(2 * wt * KS * 1024) + lane * 16 : 0x7ffffff0;
+  };
+  f16x8 xs[2][KS], xsn[2][KS];
+  float2 n2cur[2], n2nxt[2];
+  // fragment e of the wide tile: column tile e / KS, k-step e % KS (the second tile follows the first)
+  auto load_frag = [&](int voff, auto e_c, f16x8 (&dst)[2][KS]) {
+    constexpr int e = decltype(e_c)::value;
+    dst[e / KS][e % KS] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, e * 1024, 0));
+  };
+  auto load_norm = [&](int t, int ct) -> float2 {
+    const int64_t tile = 2 * wide_of(t) + ct;  // (clamped: a tile beyond the range reads tile 0's norms; never used)
+    return nrm[((t < kWide && tile < a.T) ? tile : 0) * 32 + l31];
+  };
+  {
+    const int voff = frag_voff(0);
+    static_for<0, 2 * KS>([&](auto e_c) { load_frag(voff, e_c, xs); });
+    n2cur[0] = load_norm(0, 0);
+    n2cur[1] = load_norm(0, 1);
+  }
+  n2nxt[0] = n2nxt[1] = make_float2(0.f, 0.f);
+  __syncthreads();  // fragments (vmcnt(0) of the DMA) are in LDS
+  const u32x4* fp = reinterpret_cast<const u32x4*>(smem) + lane;
+  auto ldsf = [&](const u32x4* p) -> f16x8 { return __builtin_bit_cast(f16x8, *p); };
+
+  // ONE accumulator per column tile: a unit is its 2 KS + 2 MFMAs (the two tiles alternating, so no MFMA
+  // waits for the one before it), then the top-2 update of its 2 x 16 values; the SIMD's other wave has
+  // its MFMA phase meanwhile.  (Two accumulator sets, updating unit U - 1 between the MFMAs of unit U,
+  // put the kernel at 256 VGPRs + 53 spilled around the per-tile epilogue -- and a scratch reload
+  // waits, vmcnt being in order, for the piece loads issued before it.)
+  f32x16 acc[2];
+  // one top-2 chain per column tile: the two tiles' updates alternate, so a chain's three dependent
+  // instructions always have the other chain's between them
+  float b1[2] = {-INFINITY, -INFINITY}, b2[2] = {-INFINITY, -INFINITY};
+  int bu[2] = {0, 0};
+  f16x8 c1k[KS];
+#pragma unroll
+  for (int st = 0; st < KS; ++st) c1k[st] = ldsf(fp + (1 + st) * 64);
+  bf16x8 bones = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (half == 0) {
+    bones[0] = (__bf16)1.0f;
+    bones[1] = (__bf16)1.0f;
+    bones[2] = (__bf16)1.0f;
+  }
+  const float s = a.scale[b];
+  const float cn = sqrtf(__uint_as_float(a.cmax2_bits[b * 2])), cnr = sqrtf(__uint_as_float(a.cmax2_bits[b * 2 + 1]));
+  const bool exact_all = (a.flag[b] | a.cflag[b]) != 0;
+  const float inv_s2 = (1.f / s) * (1.f / s);
+
+  auto finish = [&](int ct, int64_t tile, float2 n2) {
+    const int r0 = __float_as_int(b1[ct]) & 15;
+    int idx = bu[ct] * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * half;
+    const float m1 = b1[ct], m2 = b2[ct];
+    const float o1 = __shfl_xor(m1, 32, 64), o2 = __shfl_xor(m2, 32, 64);
+    const int oi = __shfl_xor(idx, 32, 64);
+    const float B1 = fmaxf(m1, o1);
+    const float B2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
+    if (o1 > m1 || (o1 == m1 && oi < idx)) idx = oi;
+    const int64_t fi = tile * 32 + l31;
+    emit(a, bl, b, lane, half == 0 && fi < m, fi, idx, B1, B2, n2, s, cn, cnr, inv_s2, exact_all);
+  };
+
+  auto unit = [&](auto u_c, int voff_next, const f16x8 (&xs)[2][KS], f16x8 (&xsn)[2][KS]) {
+    constexpr int U = decltype(u_c)::value;
+    const u32x4* up = fp + U * FL * 64;
+    const u32x4* upn = fp + ((U + 1) & 7) * FL * 64;  // the next unit (unit 0 of the next tile after 7)
+    const float before0 = b1[0], before1 = b1[1];
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16x8 cfrag = __builtin_bit_cast(bf16x8, up[0]);
+    if constexpr (U < 4) {  // the next wide tile's hi pieces: 2 KS 16-byte loads over units 0..3
+      constexpr int l0 = (U * 2 * KS) / 4, l1 = ((U + 1) * 2 * KS) / 4;
+      static_for<l0, l1>([&](auto e_c) { load_frag(voff_next, e_c, xsn); });
+    }
+    static_for<0, KS>([&](auto s_c) {
+      constexpr int st = decltype(s_c)::value;
+      if constexpr (st == 0) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[0], xs[0][0], zero, 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[0], xs[1][0], zero, 0, 0, 0);
+      } else {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[st], xs[0][st], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[st], xs[1][st], acc[1], 0, 0, 0);
+      }
+      c1k[st] = ldsf(upn + (1 + st) * 64);  // this k-step's A operand of the NEXT unit
+    });
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, acc[1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, 16>([&](auto q_c) {  // 16 register pairs, the two column tiles in turn
+      constexpr int q = decltype(q_c)::value, ct = q & 1, pq = q >> 1;
+      take_keys_pair<2 * pq>(b1[ct], b2[ct], acc[ct][2 * pq], acc[ct][2 * pq + 1]);
+    });
+    bu[0] = b1[0] > before0 ? U : bu[0];
+    bu[1] = b1[1] > before1 ? U : bu[1];
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using std::integral_constant;
+
+  auto tile = [&](int t, const f16x8 (&cur)[2][KS], f16x8 (&nxt)[2][KS]) {
+    const int voff_next = frag_voff(t + 1);
+    n2nxt[0] = load_norm(t + 1, 0);
+    n2nxt[1] = load_norm(t + 1, 1);
+    b1[0] = b1[1] = b2[0] = b2[1] = -INFINITY;
+    bu[0] = bu[1] = 0;
+    unit(integral_constant<int, 0>{}, voff_next, cur, nxt);
+    unit(integral_constant<int, 1>{}, voff_next, cur, nxt);
+    unit(integral_constant<int, 2>{}, voff_next, cur, nxt);
+    unit(integral_constant<int, 3>{}, voff_next, cur, nxt);
+    unit(integral_constant<int, 4>{}, voff_next, cur, nxt);
+    unit(integral_constant<int, 5>{}, voff_next, cur, nxt);
+    unit(integral_constant<int, 6>{}, voff_next, cur, nxt);
+    unit(integral_constant<int, 7>{}, voff_next, cur, nxt);
+    const int64_t wt = wide_of(t);
+    finish(0, 2 * wt, n2cur[0]);
+    finish(1, 2 * wt + 1, n2cur[1]);
+    n2cur[0] = n2nxt[0];
+    n2cur[1] = n2nxt[1];
+  };
+#pragma unroll 1
+  for (int t = 0; t < kWide; t += 2) {
+    if (2 * ((int64_t)blockIdx.x * kWide + t) * kWaves >= a.T) break;
+    tile(t, xs, xsn);
+    if (t + 1 >= kWide || 2 * ((int64_t)blockIdx.x * kWide + t + 1) * kWaves >= a.T) break;
+    tile(t + 1, xsn, xs);
+  }
+  flush_list(a, bl, b);
+}
+
+// ---- level 2 -----------------------------------------------------------------------------------------
+// The three-product selection (assign_fast.hip section 2b's loop order, fp16 pieces) over the points of
+// the level-1 list: a tile is 32 LISTED points, their pieces gathered from the fragment arrays (16
+// chunks of 16 B per point).  The grid covers the worst case (every point listed); blocks beyond the
+// list leave at once.
+template <int KS>
+__global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
+  constexpr int FPU = 2 * KS + 1;
+  constexpr int NM = 3 * KS + 1;  // MFMAs per unit
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.y;
+  const int m = a.m;
+  int cnt = a.count_in[b];
+  cnt = cnt < m ? cnt : m;
+  if ((int64_t)blockIdx.x * kTiles * kWaves * 32 >= cnt) return;  // block-uniform
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l31 = lane & 31, half = lane >> 5;
+  BlockList* bl = reinterpret_cast<BlockList*>(smem + 8 * FPU * 1024);
+  if (threadIdx.x == 0) bl->n = 0;
+  {
+    const char* src = reinterpret_cast<const char*>(a.frags) + (size_t)b * 8 * FPU * 1024;
+    for (int f = wave; f < 8 * FPU; f += kWaves)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(smem + f * 1024), 16, 0, 0);
+  }
+  const int64_t slice = a.T * KS * 1024;
+  const __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(a.hi) + (size_t)b * slice), 0, (int)slice, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_mid = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(a.mid) + (size_t)b * slice), 0, (int)slice, 0x00020000);
+  const float2* __restrict__ nrm = a.norms + (int64_t)b * a.T * 32;
+  const int* __restrict__ lst = a.list_in + (int64_t)b * m;
+  // tile t of this wave = positions [32 tile, 32 tile + 32) of the list
+  auto point_of = [&](int t) -> int {
+    const int64_t pos = (((int64_t)blockIdx.x * kTiles + t) * kWaves + wave) * 32 + l31;
+    return (t < kTiles && pos < cnt) ? lst[pos] : -1;
+  };
+  auto voff_of = [&](int p) -> int {
+    return p >= 0 ? (p >> 5) * (KS * 1024) + ((p & 31) + 32 * half) * 16 : 0x7ffffff0;
+  };
+  f16x8 xs[KS][2], xsn[KS][2];
+  auto load_frag = [&](int voff, auto e_c, f16x8 (&dst)[KS][2]) {
+    constexpr int e = decltype(e_c)::value, st = e >> 1;
+    dst[st][e & 1] = __builtin_bit_cast(
+        f16x8, __builtin_amdgcn_raw_buffer_load_b128((e & 1) ? rs_mid : rs_hi, voff, st * 1024, 0));
+  };
+  auto load_norm = [&](int p) -> float2 { return nrm[p >= 0 ? p : 0]; };  // (clamped, never used when p < 0)
+  int p_cur = point_of(0), p_nxt = point_of(1), p_nx2 = -1, p_prev = -1;
+  float2 n2cur = load_norm(p_cur), n2nxt = make_float2(0.f, 0.f), n2prev = make_float2(0.f, 0.f);
+  {
+    const int voff = voff_of(p_cur);
+    static_for<0, 2 * KS>([&](auto e_c) { load_frag(voff, e_c, xs); });
+  }
+  __syncthreads();  // fragments (vmcnt(0) of the DMA) are in LDS
+  const u32x4* fp = reinterpret_cast<const u32x4*>(smem) + lane;
+  auto ldsf = [&](const u32x4* p) -> f16x8 { return __builtin_bit_cast(f16x8, *p); };
+
+  f32x16 accA, accB;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accB[r] = -3.0e38f;
+  float b1[2] = {-INFINITY, -INFINITY}, b2[2] = {-INFINITY, -INFINITY};
+  int bu[2] = {0, 0};
+  f16x8 c1k[KS], c2r[3];
+  c1k[0] = ldsf(fp + 1 * 64);
+  c2r[0] = ldsf(fp + 2 * 64);
+  if constexpr (KS > 1) {
+    c1k[1] = ldsf(fp + 3 * 64);
+    c2r[1] = ldsf(fp + 4 * 64);
+  }
+  bf16x8 bones = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (half == 0) {
+    bones[0] = (__bf16)1.0f;
+    bones[1] = (__bf16)1.0f;
+    bones[2] = (__bf16)1.0f;
+  }
+  const float s = a.scale[b];
+  const float cn = sqrtf(__uint_as_float(a.cmax2_bits[b * 2])), cnr = sqrtf(__uint_as_float(a.cmax2_bits[b * 2 + 1]));
+  const bool exact_all = (a.flag[b] | a.cflag[b]) != 0;
+  const float inv_s2 = (1.f / s) * (1.f / s);
+
+  auto finish_tile = [&](int p, float2 n2) {
+    const int r0 = __float_as_int(b1[0]) & 15, r1 = __float_as_int(b1[1]) & 15;
+    const int ia = bu[0] * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * half;
+    const int ib = bu[1] * 32 + (r1 & 3) + 8 * (r1 >> 2) + 4 * half;
+    const bool tb = b1[1] > b1[0] || (b1[1] == b1[0] && ib < ia);
+    int idx = tb ? ib : ia;
+    const float m1 = fmaxf(b1[0], b1[1]);
+    const float m2 = fmaxf(fminf(b1[0], b1[1]), fmaxf(b2[0], b2[1]));
+    const float o1 = __shfl_xor(m1, 32, 64), o2 = __shfl_xor(m2, 32, 64);
+    const int oi = __shfl_xor(idx, 32, 64);
+    const float B1 = fmaxf(m1, o1);
+    const float B2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
+    if (o1 > m1 || (o1 == m1 && oi < idx)) idx = oi;
+    emit(a, bl, b, lane, half == 0 && p >= 0, p, idx, B1, B2, n2, s, cn, cnr, inv_s2, exact_all);
+  };
+
+  auto unit = [&](auto u_c, f32x16& acc, const f32x16& fin, int voff_next, const f16x8 (&xs)[KS][2],
+                  f16x8 (&xsn)[KS][2]) {
+    constexpr int U = decltype(u_c)::value, FU = (U + 7) & 7;
+    const u32x4* up = fp + U * FPU * 64;
+    const u32x4* upn = fp + ((U + 1) & 7) * FPU * 64;  // the next unit (unit 0 of the next tile after 7)
+    const float before0 = b1[0], before1 = b1[1];
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16x8 cfrag = __builtin_bit_cast(bf16x8, up[0]);
+    auto fill = [&](auto mi_c) {
+      constexpr int mi = decltype(mi_c)::value;
+      if constexpr (mi >= 2) {  // 8 register pairs of the previous unit's values over gaps 2 .. NM - 1
+        constexpr int lo = ((mi - 2) * 16) / (NM - 2), hi = ((mi - 1) * 16) / (NM - 2);
+        static_for<0, 8>([&](auto q_c) {
+          constexpr int q = decltype(q_c)::value;
+          if constexpr (2 * q + 1 >= lo && 2 * q + 1 < hi)
+            take_keys_pair<2 * q>(b1[q & 1], b2[q & 1], fin[2 * q], fin[2 * q + 1]);
+        });
+      }
+      if constexpr (U < 4 && mi == 0) {  // the next tile's pieces: 2 KS gathered 16-byte loads over units 0..3
+        constexpr int l0 = (U * 2 * KS) / 4, l1 = ((U + 1) * 2 * KS) / 4;
+        static_for<l0, l1>([&](auto e_c) { load_frag(voff_next, e_c, xsn); });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // small products first: corrections (C2 a1, C1 a2), main (C1 a1), then -N
+    static_for<0, KS>([&](auto s_c) {
+      constexpr int st = decltype(s_c)::value;
+      if constexpr (st + 2 < KS) {
+        c1k[st + 2] = ldsf(up + (1 + (st + 2) * 2) * 64);
+        c2r[(st + 2) % 3] = ldsf(up + (2 + (st + 2) * 2) * 64);
+      }
+      if constexpr (st == 0) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c2r[0], xs[0][0], zero, 0, 0, 0);
+      } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c2r[st % 3], xs[st][0], acc, 0, 0, 0);
+      }
+      fill(std::integral_constant<int, 2 * st>{});
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[st], xs[st][1], acc, 0, 0, 0);
+      fill(std::integral_constant<int, 2 * st + 1>{});
+    });
+    c2r[0] = ldsf(upn + 2 * 64);
+    if constexpr (KS > 1) c2r[1] = ldsf(upn + (2 + 2) * 64);
+    static_for<0, KS>([&](auto s_c) {
+      constexpr int st = decltype(s_c)::value;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[st], xs[st][0], acc, 0, 0, 0);
+      if constexpr (st < 2) c1k[st] = ldsf(upn + (1 + st * 2) * 64);
+      fill(std::integral_constant<int, 2 * KS + st>{});
+    });
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, acc, 0, 0, 0);
+    fill(std::integral_constant<int, 3 * KS>{});
+    bu[0] = b1[0] > before0 ? FU : bu[0];
+    bu[1] = b1[1] > before1 ? FU : bu[1];
+  };
+  using std::integral_constant;
+
+  bool have_prev = false;
+  auto tile = [&](int t, const f16x8 (&cur)[KS][2], f16x8 (&nxt)[KS][2]) {
+    const int voff_next = voff_of(p_nxt);
+    n2nxt = load_norm(p_nxt);
+    p_nx2 = point_of(t + 2);
+    unit(integral_constant<int, 0>{}, accA, accB, voff_next, cur, nxt);
+    if (have_prev) finish_tile(p_prev, n2prev);
+    b1[0] = b1[1] = b2[0] = b2[1] = -INFINITY;
+    bu[0] = bu[1] = 0;
+    unit(integral_constant<int, 1>{}, accB, accA, voff_next, cur, nxt);
+    unit(integral_constant<int, 2>{}, accA, accB, voff_next, cur, nxt);
+    unit(integral_constant<int, 3>{}, accB, accA, voff_next, cur, nxt);
+    unit(integral_constant<int, 4>{}, accA, accB, voff_next, cur, nxt);
+    unit(integral_constant<int, 5>{}, accB, accA, voff_next, cur, nxt);
+    unit(integral_constant<int, 6>{}, accA, accB, voff_next, cur, nxt);
+    unit(integral_constant<int, 7>{}, accB, accA, voff_next, cur, nxt);
+    p_prev = p_cur;
+    p_cur = p_nxt;
+    p_nxt = p_nx2;
+    n2prev = n2cur;
+    n2cur = n2nxt;
+    have_prev = true;
+  };
+#pragma unroll 1
+  for (int t = 0; t < kTiles; t += 2) {
+    if (((int64_t)blockIdx.x * kTiles + t) * kWaves * 32 >= cnt) break;
+    tile(t, xs, xsn);
+    if (t + 1 >= kTiles || ((int64_t)blockIdx.x * kTiles + t + 1) * kWaves * 32 >= cnt) break;
+    tile(t + 1, xsn, xs);
+  }
+  if (have_prev) {  // the last unit of the last tile
+    const float before0 = b1[0], before1 = b1[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = (r >> 1) & 1;
+      const float v = __int_as_float((__float_as_int(accB[r]) & ~15) | r);
+      const float t = fminf(v, b1[c]);
+      b1[c] = fmaxf(v, b1[c]);
+      b2[c] = fmaxf(b2[c], t);
+    }
+    bu[0] = b1[0] > before0 ? 7 : bu[0];
+    bu[1] = b1[1] > before1 ? 7 : bu[1];
+    finish_tile(p_prev, n2prev);
+  }
+  flush_list(a, bl, b);
+}
+
+// ---- step workspace --------------------------------------------------------------------------------
+struct StepLayout {
+  size_t frags_off, cmax_off, count_off, cflag_off, count2_off, list_off, list2_off, upd_off, total;
+};
+static StepLayout step_layout(int l, int d, int64_t m, int n) {
+  StepLayout L;
+  const int KS = ks_of(d);
+  L.frags_off = 0;
+  L.cmax_off = (size_t)l * 8 * (2 * KS + 1) * 1024;   // [l][2] u32
+  L.count_off = L.cmax_off + (size_t)l * 8;            // [l] i32: left undecided by level 1
+  L.cflag_off = L.count_off + (size_t)l * 4;           // [l] i32
+  L.count2_off = L.cflag_off + (size_t)l * 4;          // [l] i32: left undecided by level 2
+  L.list_off = (L.count2_off + (size_t)l * 4 + 255) / 256 * 256;   // [l][m] i32
+  L.list2_off = (L.list_off + (size_t)l * m * 4 + 255) / 256 * 256;  // [l][m] i32
+  L.upd_off = (L.list2_off + (size_t)l * m * 4 + 255) / 256 * 256;
+  L.total = L.upd_off + tpq_compute_centroids_workspace_bytes(l, d, n);
+  return L;
+}
+
+template <int KS>
+static int run_levels(StepArgs sa, int l, int d, int* list2, int* count2, hipStream_t st) {
+  const int terms = KS * 16 + 2 + 3;
+  const float common = (float)(terms + 8) / 8388608.0f + (float)(d + 1) / 16777216.0f + 1.0f / 4194304.0f +
+                       1.0f / 524288.0f;  // accumulation, norm chain, shift rounding, key bits
+  {  // level 1
+    const size_t lds = (size_t)8 * (KS + 1) * 1024 + sizeof(BlockList);
+    auto kernel = coarse_kernel<KS>;
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                       "lloyd coarse_kernel attr");
+    if (rc) return rc;
+    sa.eps = 1.001f / 2048.0f + common;
+    const int64_t wide = (sa.T + 1) / 2, per_block = (int64_t)kWaves * kWide;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((wide + per_block - 1) / per_block), l), dim3(kWaves * 64), lds, st, sa);
+    TPQ_LAUNCH_CHECK("lloyd coarse_kernel");
+  }
+  {  // level 2
+    const size_t lds = (size_t)8 * (2 * KS + 1) * 1024 + sizeof(BlockList);
+    auto kernel = refine_kernel<KS>;
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                       "lloyd refine_kernel attr");
+    if (rc) return rc;
+    sa.eps = 3.03f / 4194304.0f + common;
+    sa.list_in = sa.list;
+    sa.count_in = sa.count;
+    sa.list = list2;
+    sa.count = count2;
+    const int64_t per_block = (int64_t)kWaves * kTiles;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((sa.T + per_block - 1) / per_block), l), dim3(kWaves * 64), lds, st, sa);
+    TPQ_LAUNCH_CHECK("lloyd refine_kernel");
+  }
+  return TPQ_OK;
+}
+
+}  // namespace lloyd
+}  // namespace tpq
+
+using namespace tpq;
+
+extern "C" int tpq_lloyd_supported(int l, int d, int64_t m, int n) {
+  if (!(l >= 1 && l <= 65535 && d >= 1 && d <= 64 && n >= 1 && n <= 256 && m >= 1 && m < (1LL << 31))) return 0;
+  const lloyd::PrepLayout L = lloyd::prep_layout(l, d, m);
+  return (L.T * L.KS * 1024 <= 0x7fffffffLL && (int64_t)d * m * 4 <= 0x7fffffffLL) ? 1 : 0;
+}
+
+extern "C" size_t tpq_lloyd_prepared_bytes(int l, int d, int64_t m) {
+  if (l < 1 || d < 1 || d > 64 || m < 1) return 0;
+  return lloyd::prep_layout(l, d, m).total;
+}
+
+extern "C" int tpq_lloyd_prepare(const float* data, const float* centroids0, void* prepared, size_t prepared_bytes,
+                                 int l, int d, int64_t m, int n, tpq_stream_t stream) {
+  TPQ_REQUIRE(data && centroids0 && prepared, "lloyd_prepare: null pointer");
+  if (!tpq_lloyd_supported(l, d, m, n)) {
+    set_error("lloyd_prepare: shape l=%d d=%d m=%lld n=%d not supported (d <= 64, n <= 256, slices < 2 GiB)", l, d,
+              (long long)m, n);
+    return TPQ_ERR_UNSUPPORTED;
+  }
+  const lloyd::PrepLayout L = lloyd::prep_layout(l, d, m);
+  TPQ_REQUIRE(prepared_bytes >= L.total, "lloyd_prepare: prepared block of %zu bytes needed", L.total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  char* p = reinterpret_cast<char*>(prepared);
+  float* mu = reinterpret_cast<float*>(p + L.mu_off);
+  float* scale = reinterpret_cast<float*>(p + L.scale_off);
+  int* flag = reinterpret_cast<int*>(p + L.flag_off);
+  unsigned* maxbits = reinterpret_cast<unsigned*>(p + L.maxbits_off);
+  int rc = check_hip(hipMemsetAsync(p + L.mu_off, 0, L.total - L.mu_off, st), "lloyd_prepare memset");
+  if (rc) return rc;
+  hipLaunchKernelGGL(lloyd::mu_kernel, dim3(d, l), dim3(256), 0, st, centroids0, mu, d, n);
+  TPQ_LAUNCH_CHECK("lloyd mu_kernel");
+  int chunks = (int)(4096 / ((int64_t)l * d));
+  if (chunks < 1) chunks = 1;
+  if ((int64_t)chunks * 4096 > m) chunks = (int)((m + 4095) / 4096);
+  hipLaunchKernelGGL(lloyd::maxabs_kernel, dim3(chunks, d, l), dim3(256), 0, st, data, mu, maxbits, flag, d, m);
+  TPQ_LAUNCH_CHECK("lloyd maxabs_kernel");
+  hipLaunchKernelGGL(lloyd::scale_kernel, dim3((l + 63) / 64), dim3(64), 0, st, maxbits, flag, scale, l);
+  TPQ_LAUNCH_CHECK("lloyd scale_kernel");
+  hipLaunchKernelGGL(lloyd::split_kernel, dim3((unsigned)((L.T + 3) / 4), l), dim3(256), 0, st, data, mu, scale,
+                     reinterpret_cast<lloyd::u32x4*>(p + L.hi_off), reinterpret_cast<lloyd::u32x4*>(p + L.mid_off),
+                     reinterpret_cast<float2*>(p + L.norms_off), d, m, L.T, L.KS);
+  TPQ_LAUNCH_CHECK("lloyd split_kernel");
+  return TPQ_OK;
+}
+
+extern "C" size_t tpq_lloyd_step_workspace_bytes(int l, int d, int64_t m, int n) {
+  if (!tpq_lloyd_supported(l, d, m, n)) return 0;
+  return lloyd::step_layout(l, d, m, n).total;
+}
+
+// diagnostics: byte offsets of the int32 [l] counts of points left undecided by level 1 / level 2
+extern "C" size_t tpq_lloyd_step_count_offset(int l, int d, int64_t m, int n, int level) {
+  if (!tpq_lloyd_supported(l, d, m, n)) return 0;
+  const lloyd::StepLayout L = lloyd::step_layout(l, d, m, n);
+  return level == 1 ? L.count_off : L.count2_off;
+}
+
+extern "C" int tpq_lloyd_step(const float* data, const void* prepared, const float* centroids, float* new_centroids,
+                              float* vals, int64_t* inds, int l, int d, int64_t m, int n, void* workspace,
+                              size_t workspace_bytes, tpq_stream_t stream) {
+  TPQ_REQUIRE(data && prepared && centroids && inds, "lloyd_step: null pointer");
+  if (!tpq_lloyd_supported(l, d, m, n)) {
+    set_error("lloyd_step: shape l=%d d=%d m=%lld n=%d not supported", l, d, (long long)m, n);
+    return TPQ_ERR_UNSUPPORTED;
+  }
+  const lloyd::PrepLayout P = lloyd::prep_layout(l, d, m);
+  const lloyd::StepLayout L = lloyd::step_layout(l, d, m, n);
+  TPQ_REQUIRE(workspace && workspace_bytes >= L.total, "lloyd_step: workspace of %zu bytes needed", L.total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const char* p = reinterpret_cast<const char*>(prepared);
+  char* ws = reinterpret_cast<char*>(workspace);
+  const float* mu = reinterpret_cast<const float*>(p + P.mu_off);
+  const float* scale = reinterpret_cast<const float*>(p + P.scale_off);
+  lloyd::u32x4* frags = reinterpret_cast<lloyd::u32x4*>(ws + L.frags_off);
+  unsigned* cmax = reinterpret_cast<unsigned*>(ws + L.cmax_off);
+  int* count = reinterpret_cast<int*>(ws + L.count_off);
+  int* cflag = reinterpret_cast<int*>(ws + L.cflag_off);
+  int* count2 = reinterpret_cast<int*>(ws + L.count2_off);
+  int* list = reinterpret_cast<int*>(ws + L.list_off);
+  int* list2 = reinterpret_cast<int*>(ws + L.list2_off);
+  int rc = check_hip(hipMemsetAsync(ws + L.cmax_off, 0, L.list_off - L.cmax_off, st), "lloyd_step memset");
+  if (rc) return rc;
+  const int KS = P.KS;
+  hipLaunchKernelGGL(lloyd::cprep_kernel, dim3(8, l), dim3(64), 0, st, centroids, mu, scale, frags, cmax, cflag, d, n,
+                     KS);
+  TPQ_LAUNCH_CHECK("lloyd cprep_kernel");
+  lloyd::StepArgs sa{reinterpret_cast<const lloyd::u32x4*>(p + P.hi_off),
+                     reinterpret_cast<const lloyd::u32x4*>(p + P.mid_off),
+                     reinterpret_cast<const float2*>(p + P.norms_off),
+                     frags, cmax, scale, reinterpret_cast<const int*>(p + P.flag_off), cflag, inds, vals,
+                     nullptr, nullptr, list, count, (int)m, P.T,
+                     0.f, (float)(d + 4) / 16777216.0f, sqrtf((float)d) / 8192.0f};
+  switch (KS) {
+    case 1: rc = lloyd::run_levels<1>(sa, l, d, list2, count2, st); break;
+    case 2: rc = lloyd::run_levels<2>(sa, l, d, list2, count2, st); break;
+    case 3: rc = lloyd::run_levels<3>(sa, l, d, list2, count2, st); break;
+    default: rc = lloyd::run_levels<4>(sa, l, d, list2, count2, st); break;
+  }
+  if (rc) return rc;
+  rc = launch_max_sim_list(data, centroids, vals, inds, l, d, (int)m, n, 1, list2, count2, nullptr, nullptr, 0, st);
+  if (rc) return rc;
+  if (new_centroids)
+    return tpq_compute_centroids(data, inds, new_centroids, l, d, m, n, ws + L.upd_off,
+                                 tpq_compute_centroids_workspace_bytes(l, d, n), stream);
+  return TPQ_OK;
+}

@@ -616,6 +616,67 @@ class MaxSimSelectHip:
         self._ws = None
 
 
+class LloydStepHip:
+    """One Lloyd iteration of MultiKMeans.fit on prepared data (tpq_lloyd_prepare / tpq_lloyd_step):
+    the get_labels -> compute_centroids pair of the reference's driver
+    (torchpq/clustering/MultiKMeans.py:415-453) for codebook-sized euclidean problems.
+
+        step = LloydStepHip(data, centroids0)       # once per fit: centre, scale, split, fragment order
+        maxsims, labels, new_centroids = step(centroids)
+
+    labels are MaxSimHip's (fp32), bit for bit; maxsims are the selection's fast maxima (exact for
+    re-checked points); new_centroids = ComputeCentroidsHip()(data, labels, k)."""
+
+    @staticmethod
+    def supported(l, d, m, n):
+        return bool(load().tpq_lloyd_supported(int(l), int(d), int(m), int(n)))
+
+    def __init__(self, data, centroids0):
+        assert data.dim() == 3 and centroids0.dim() == 3 and data.shape[:2] == centroids0.shape[:2]
+        assert data.dtype == centroids0.dtype == torch.float32
+        require_gpu(data, centroids0)
+        self.data = data.contiguous()
+        centroids0 = centroids0.contiguous()
+        l, d, m = self.data.shape
+        n = centroids0.shape[2]
+        assert self.supported(l, d, m, n), "shape not supported by tpq_lloyd_step (d <= 64, n <= 256)"
+        self.shape = (l, d, m, n)
+        lib = load()
+        nbytes = lib.tpq_lloyd_prepared_bytes(l, d, m)
+        self.prepared = torch.empty(nbytes, device=data.device, dtype=torch.uint8)
+        self._ws = None
+        with torch.cuda.device(data.device):
+            check(lib.tpq_lloyd_prepare(ptr(self.data), ptr(centroids0), ptr(self.prepared), nbytes, l, d, m, n,
+                                        stream_ptr(data.device)), "tpq_lloyd_prepare")
+
+    def __call__(self, centroids, update=True):
+        l, d, m, n = self.shape
+        assert tuple(centroids.shape) == (l, d, n) and centroids.dtype == torch.float32
+        centroids = centroids.contiguous()
+        require_gpu(centroids)
+        dev = self.data.device
+        lib = load()
+        vals = torch.empty(l, m, device=dev, dtype=torch.float32)
+        inds = torch.empty(l, m, device=dev, dtype=torch.int64)
+        new = torch.empty(l, d, n, device=dev, dtype=torch.float32) if update else None
+        ws_bytes = lib.tpq_lloyd_step_workspace_bytes(l, d, m, n)
+        if self._ws is None or self._ws.numel() < ws_bytes:
+            self._ws = None
+            self._ws = torch.empty(max(ws_bytes, 1), device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            check(lib.tpq_lloyd_step(ptr(self.data), ptr(self.prepared), ptr(centroids), ptr(new), ptr(vals),
+                                     ptr(inds), l, d, m, n, ptr(self._ws), ws_bytes, stream_ptr(dev)),
+                  "tpq_lloyd_step")
+        return vals, inds, new
+
+    def rechecked(self, level=2):
+        """points per sub-problem the last step left undecided after level 1 (coarse pass) or level 2
+        (= sent to the exact fp32 re-check); int32 [l], diagnostics"""
+        l, d, m, n = self.shape
+        off = load().tpq_lloyd_step_count_offset(l, d, m, n, int(level))
+        return self._ws[off:off + 4 * l].view(torch.int32).clone()
+
+
 class ComputeCentroidsHip:
     """K-means update (kernels/ComputeCentroidsCuda.py:43-81): data [l, d, n], labels [l, n]
     -> centroids [l, d, k]; empty clusters -> 0."""
