@@ -76,7 +76,11 @@ static PrepLayout prep_layout(int l, int d, int64_t m) {
   PrepLayout L;
   L.KS = ks_of(d);
   L.T = (m + 31) / 32;
-  // hi and mid pieces in separate arrays [l][T][KS][64] x 16 B: the coarse pass streams the hi pieces only
+  // hi and mid pieces as two row-major fp16 matrices [l][32 T points][16 KS dims]: the coarse pass streams
+  // the hi matrix only; a point's 16 KS values of a piece are ONE 32 KS-byte row, so that level 2 gathers a
+  // listed point with two cache lines (in MFMA-fragment order -- tile x k-step x lane x 16 B -- the
+  // 16-byte chunks of a point lie in 16 different lines: 1 KiB of traffic per gathered point).
+  // Lane (point, half) of a B operand reads 16 B at row + 32 st + 16 half.
   L.hi_off = 0;
   L.mid_off = (size_t)l * L.T * L.KS * 1024;
   L.norms_off = 2 * L.mid_off;
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ A,
   const bool iv = i < m;
   const float* Ab = A + (int64_t)b * d * m + (iv ? i : 0);
   const float s = scale[b];
-  const int64_t fo = ((int64_t)b * T + tile) * KS * 64 + lane;
+  const int64_t fo = (((int64_t)b * T + tile) * 32 + l31) * (2 * KS) + half;  // 16-byte chunks: row 2 KS, chunk 2 st + half
   float n2c = 0.f, n2r = 0.f;
   for (int st = 0; st < KS; ++st) {
     float x[8];
@@ -205,8 +209,8 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ A,
       n2c = fmaf(a, a, n2c);
       n2r = fmaf(x[j], x[j], n2r);
     }
-    hi[fo + st * 64] = __builtin_bit_cast(u32x4, h);
-    mid[fo + st * 64] = __builtin_bit_cast(u32x4, mm);
+    hi[fo + 2 * st] = __builtin_bit_cast(u32x4, h);
+    mid[fo + 2 * st] = __builtin_bit_cast(u32x4, mm);
   }
   n2c += __shfl_xor(n2c, 32, 64);
   n2r += __shfl_xor(n2r, 32, 64);
@@ -351,6 +355,27 @@ __device__ __forceinline__ void take_keys_pair(float& p1, float& p2, float v0, f
       : "v"(v0), "v"(v1), "n"(R0), "n"(R0 + 1));
 }
 
+// Level 1's keys carry 6 bits -- register number + 16 x (unit mod 4) -- so that the unit of the best value
+// needs no bookkeeping of its own (which half of the tile's units it came from is one compare per tile).
+// 2^-17 |v| off: in level 1's bound.
+// The tagging itself is plain C++ (the compiler selects v_and_or_b32): these instructions READ MFMA
+// results right behind the MFMAs, and the wait states that takes are only inserted for instructions
+// the hazard recogniser can see -- as operands of an asm block the accumulators were read too early
+// (labels wrong, differently on every run).
+template <int TAG>
+__device__ __forceinline__ float key6(float v) {
+  return __int_as_float((int)((__float_as_uint(v) & 0xffffffc0u) | (unsigned)TAG));
+}
+__device__ __forceinline__ void top2_keys_pair(float& p1, float& p2, float k0, float k1) {
+  float t0;
+  asm volatile(
+      "v_med3_f32 %2, %0, %3, %4\n\t"
+      "v_max3_f32 %0, %0, %3, %4\n\t"
+      "v_max_f32 %1, %1, %2"
+      : "+v"(p1), "+v"(p2), "=&v"(t0)
+      : "v"(k0), "v"(k1));
+}
+
 // ---- the cascade on prepared pieces ------------------------------------------------------------------
 // Level 1 (coarse_kernel): ONE product per k-step -- f0 = sum_k Ch ah - N on the hi pieces only (half the
 // bytes, 5 MFMAs per 32 x 32 tile instead of 13).  |f0 - g| carries the dropped pieces,
@@ -362,8 +387,8 @@ __device__ __forceinline__ void take_keys_pair(float& p1, float& p2, float v0, f
 // Every level decides a point only when its two best fast values are further apart than twice its
 // own rigorous bound, so the labels are tpq_max_sim's whatever the split between the levels.
 struct StepArgs {
-  const u32x4* hi;             // [l][T][KS][64]
-  const u32x4* mid;            // [l][T][KS][64]
+  const u32x4* hi;             // [l][32 T][16 KS] fp16, row-major
+  const u32x4* mid;            // likewise
   const float2* norms;         // [l][T * 32]: (|a'|^2, |x|^2)
   const u32x4* frags;          // [l][8][2 KS + 1][64]
   const unsigned* cmax2_bits;  // [l][2]: max N, max |c|^2
@@ -430,7 +455,8 @@ __device__ __forceinline__ void flush_list(const StepArgs& a, BlockList* bl, int
 // MFMA waits for the one before it.  LDS holds -N and the hi pieces of the centroids only (40 KiB).
 constexpr int kWide = kTiles / 2;  // wide tiles per wave and block
 
-template <int KS>
+// EXP (knock-outs, TPQ_LL_EXP; results are then wrong): 1 = no top-2 updates, 2 = no MFMAs, 4 = no piece loads
+template <int KS, int EXP = 0>
 __global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
   constexpr int FPU = 2 * KS + 1;  // fragments per unit in global memory
   constexpr int FL = KS + 1;       // ... in LDS
@@ -457,14 +483,15 @@ __global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
   auto wide_of = [&](int t) -> int64_t { return ((int64_t)blockIdx.x * kWide + t) * kWaves + wave; };
   auto frag_voff = [&](int t) -> int {
     const int64_t wt = wide_of(t);
-    return (t < kWide && 2 * wt < a.T) ? (int)(2 * wt * KS * 1024) + lane * 16 : 0x7ffffff0;
+    return (t < kWide && 2 * wt < a.T) ? (int)((2 * wt * 32 + l31) * (32 * KS)) + half * 16 : 0x7ffffff0;
   };
-  f16x8 xs[2][KS], xsn[2][KS];
-  float2 n2cur[2], n2nxt[2];
-  // fragment e of the wide tile: column tile e / KS, k-step e % KS (the second tile follows the first)
+  f16x8 xsb[2][2][KS];  // [buffer][column tile][k-step]
+  float2 n2b[2][2];     // [buffer][column tile]
+  // fragment e of the wide tile: column tile e / KS (32 rows further), k-step e % KS
   auto load_frag = [&](int voff, auto e_c, f16x8 (&dst)[2][KS]) {
     constexpr int e = decltype(e_c)::value;
-    dst[e / KS][e % KS] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, e * 1024, 0));
+    dst[e / KS][e % KS] = __builtin_bit_cast(
+        f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (e / KS) * (1024 * KS) + (e % KS) * 32, 0));
   };
   auto load_norm = [&](int t, int ct) -> float2 {
     const int64_t tile = 2 * wide_of(t) + ct;  // (clamped: a tile beyond the range reads tile 0's norms; never used)
@@ -472,25 +499,26 @@ __global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
   };
   {
     const int voff = frag_voff(0);
-    static_for<0, 2 * KS>([&](auto e_c) { load_frag(voff, e_c, xs); });
-    n2cur[0] = load_norm(0, 0);
-    n2cur[1] = load_norm(0, 1);
+    static_for<0, 2 * KS>([&](auto e_c) { load_frag(voff, e_c, xsb[0]); });
+    n2b[0][0] = load_norm(0, 0);
+    n2b[0][1] = load_norm(0, 1);
   }
-  n2nxt[0] = n2nxt[1] = make_float2(0.f, 0.f);
   __syncthreads();  // fragments (vmcnt(0) of the DMA) are in LDS
   const u32x4* fp = reinterpret_cast<const u32x4*>(smem) + lane;
   auto ldsf = [&](const u32x4* p) -> f16x8 { return __builtin_bit_cast(f16x8, *p); };
 
-  // ONE accumulator per column tile: a unit is its 2 KS + 2 MFMAs (the two tiles alternating, so no MFMA
-  // waits for the one before it), then the top-2 update of its 2 x 16 values; the SIMD's other wave has
-  // its MFMA phase meanwhile.  (Two accumulator sets, updating unit U - 1 between the MFMAs of unit U,
-  // put the kernel at 256 VGPRs + 53 spilled around the per-tile epilogue -- and a scratch reload
-  // waits, vmcnt being in order, for the piece loads issued before it.)
+  // ONE accumulator per column tile, the two tiles half a unit out of phase: while the KS + 1 MFMAs of
+  // tile 0 run, the 16 values tile 1 finished half a unit ago go through the top-2 update, and vice
+  // versa.  (Both tiles in phase -- all MFMAs of a unit, then all of its updates -- leaves the two
+  // waves of a SIMD in lockstep: their MFMA phases queue on the matrix pipe, then their update phases
+  // on the VALU port, 680 cycles per unit instead of ~360.  Two accumulator SETS, updating unit U - 1
+  // between the MFMAs of unit U, take 64 more registers: 256 VGPRs + 53 spilled around the per-tile
+  // epilogue, and a scratch reload waits, vmcnt being in order, for the piece loads issued before it.)
   f32x16 acc[2];
-  // one top-2 chain per column tile: the two tiles' updates alternate, so a chain's three dependent
-  // instructions always have the other chain's between them
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[1][r] = -3.0e38f;
   float b1[2] = {-INFINITY, -INFINITY}, b2[2] = {-INFINITY, -INFINITY};
-  int bu[2] = {0, 0};
+  float b1h[2] = {-INFINITY, -INFINITY};  // the best after units 0..3
   f16x8 c1k[KS];
 #pragma unroll
   for (int st = 0; st < KS; ++st) c1k[st] = ldsf(fp + (1 + st) * 64);
@@ -506,8 +534,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
   const float inv_s2 = (1.f / s) * (1.f / s);
 
   auto finish = [&](int ct, int64_t tile, float2 n2) {
-    const int r0 = __float_as_int(b1[ct]) & 15;
-    int idx = bu[ct] * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * half;
+    const int tag = __float_as_int(b1[ct]) & 63, r0 = tag & 15;
+    // a best key found in units 4..7 is greater than the best of units 0..3 (equal keys: b2 == b1, listed)
+    const int unit = (tag >> 4) + (b1[ct] > b1h[ct] ? 4 : 0);
+    int idx = unit * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * half;
     const float m1 = b1[ct], m2 = b2[ct];
     const float o1 = __shfl_xor(m1, 32, 64), o2 = __shfl_xor(m2, 32, 64);
     const int oi = __shfl_xor(idx, 32, 64);
@@ -517,77 +547,110 @@ __global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
     const int64_t fi = tile * 32 + l31;
     emit(a, bl, b, lane, half == 0 && fi < m, fi, idx, B1, B2, n2, s, cn, cnr, inv_s2, exact_all);
   };
-
-  auto unit = [&](auto u_c, int voff_next, const f16x8 (&xs)[2][KS], f16x8 (&xsn)[2][KS]) {
-    constexpr int U = decltype(u_c)::value;
-    const u32x4* up = fp + U * FL * 64;
-    const u32x4* upn = fp + ((U + 1) & 7) * FL * 64;  // the next unit (unit 0 of the next tile after 7)
-    const float before0 = b1[0], before1 = b1[1];
-    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const bf16x8 cfrag = __builtin_bit_cast(bf16x8, up[0]);
-    if constexpr (U < 4) {  // the next wide tile's hi pieces: 2 KS 16-byte loads over units 0..3
-      constexpr int l0 = (U * 2 * KS) / 4, l1 = ((U + 1) * 2 * KS) / 4;
-      static_for<l0, l1>([&](auto e_c) { load_frag(voff_next, e_c, xsn); });
-    }
-    static_for<0, KS>([&](auto s_c) {
-      constexpr int st = decltype(s_c)::value;
-      if constexpr (st == 0) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[0], xs[0][0], zero, 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[0], xs[1][0], zero, 0, 0, 0);
-      } else {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[st], xs[0][st], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[st], xs[1][st], acc[1], 0, 0, 0);
-      }
-      c1k[st] = ldsf(upn + (1 + st) * 64);  // this k-step's A operand of the NEXT unit
+  // the top-2 update of register pairs [P0, P1) of column tile CT, values of unit UT
+  auto update = [&](auto ct_c, auto ut_c, auto p0_c, auto p1_c) {
+    constexpr int CT = decltype(ct_c)::value, UT = decltype(ut_c)::value;
+    if constexpr (!(EXP & 1)) static_for<decltype(p0_c)::value, decltype(p1_c)::value>([&](auto q_c) {
+      constexpr int q = decltype(q_c)::value;
+      top2_keys_pair(b1[CT], b2[CT], key6<2 * q + 16 * (UT & 3)>(acc[CT][2 * q]),
+                     key6<2 * q + 1 + 16 * (UT & 3)>(acc[CT][2 * q + 1]));
     });
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, acc[1], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<0, 16>([&](auto q_c) {  // 16 register pairs, the two column tiles in turn
-      constexpr int q = decltype(q_c)::value, ct = q & 1, pq = q >> 1;
-      take_keys_pair<2 * pq>(b1[ct], b2[ct], acc[ct][2 * pq], acc[ct][2 * pq + 1]);
-    });
-    bu[0] = b1[0] > before0 ? U : bu[0];
-    bu[1] = b1[1] > before1 ? U : bu[1];
     __builtin_amdgcn_sched_barrier(0);
   };
   using std::integral_constant;
+  bool have_prev = false;
+  int64_t wt_prev = 0;
+  float2 n2prev1 = make_float2(0.f, 0.f);
 
-  auto tile = [&](int t, const f16x8 (&cur)[2][KS], f16x8 (&nxt)[2][KS]) {
+  auto unit = [&](auto u_c, int voff_next, const f16x8 (&xs)[2][KS], f16x8 (&xsn)[2][KS]) {
+    constexpr int U = decltype(u_c)::value, PU = (U + 7) & 7;
+    const u32x4* up = fp + U * FL * 64;
+    const u32x4* upn = fp + ((U + 1) & 7) * FL * 64;  // the next unit (unit 0 of the next tile after 7)
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16x8 cfrag = __builtin_bit_cast(bf16x8, up[0]);
+    if constexpr (U < 4 && !(EXP & 4)) {  // the next wide tile's hi pieces: 2 KS 16-byte loads over units 0..3
+      constexpr int l0 = (U * 2 * KS) / 4, l1 = ((U + 1) * 2 * KS) / 4;
+      static_for<l0, l1>([&](auto e_c) { load_frag(voff_next, e_c, xsn); });
+    }
+    if constexpr (U == 4) b1h[0] = b1[0];
+    if constexpr (U == 5) b1h[1] = b1[1];  // (tile 1's values of unit 4 are taken during unit 5)
+    // first half: MFMAs of column tile 0; update with tile 1's values of the previous unit
+    static_for<0, KS + 1>([&](auto g_c) {
+      constexpr int g = decltype(g_c)::value;
+      if constexpr (EXP & 2) {
+        acc[0][g] += (float)c1k[g % KS][0] + (float)xs[0][g % KS][1] + (float)cfrag[0];
+      } else if constexpr (g < KS) {
+        if constexpr (g == 0) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[0], xs[0][0], zero, 0, 0, 0);
+        } else {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[g], xs[0][g], acc[0], 0, 0, 0);
+        }
+      } else {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, acc[0], 0, 0, 0);
+      }
+      update(integral_constant<int, 1>{}, integral_constant<int, PU>{}, integral_constant<int, (g * 8) / (KS + 1)>{},
+             integral_constant<int, ((g + 1) * 8) / (KS + 1)>{});
+    });
+    if constexpr (U == 0) {  // tile 1 of the PREVIOUS wide tile is complete now
+      if (have_prev) finish(1, 2 * wt_prev + 1, n2prev1);
+      b1[1] = b2[1] = -INFINITY;
+    }
+    // second half: MFMAs of column tile 1 (then the A operand is free: fetch the next unit's); update
+    // with tile 0's values of this unit
+    static_for<0, KS + 1>([&](auto g_c) {
+      constexpr int g = decltype(g_c)::value;
+      if constexpr (EXP & 2) {
+        acc[1][g] += (float)c1k[g % KS][0] + (float)xs[1][g % KS][1] + (float)cfrag[0];
+        if constexpr (g < KS) c1k[g] = ldsf(upn + (1 + g) * 64);
+      } else if constexpr (g < KS) {
+        if constexpr (g == 0) {
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[0], xs[1][0], zero, 0, 0, 0);
+        } else {
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[g], xs[1][g], acc[1], 0, 0, 0);
+        }
+        c1k[g] = ldsf(upn + (1 + g) * 64);
+      } else {
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, acc[1], 0, 0, 0);
+      }
+      update(integral_constant<int, 0>{}, integral_constant<int, U>{}, integral_constant<int, (g * 8) / (KS + 1)>{},
+             integral_constant<int, ((g + 1) * 8) / (KS + 1)>{});
+    });
+  };
+
+  auto tile = [&](int t, auto cb_c) {
+    constexpr int CB = decltype(cb_c)::value, NX = 1 - CB;
     const int voff_next = frag_voff(t + 1);
-    n2nxt[0] = load_norm(t + 1, 0);
-    n2nxt[1] = load_norm(t + 1, 1);
-    b1[0] = b1[1] = b2[0] = b2[1] = -INFINITY;
-    bu[0] = bu[1] = 0;
-    unit(integral_constant<int, 0>{}, voff_next, cur, nxt);
-    unit(integral_constant<int, 1>{}, voff_next, cur, nxt);
-    unit(integral_constant<int, 2>{}, voff_next, cur, nxt);
-    unit(integral_constant<int, 3>{}, voff_next, cur, nxt);
-    unit(integral_constant<int, 4>{}, voff_next, cur, nxt);
-    unit(integral_constant<int, 5>{}, voff_next, cur, nxt);
-    unit(integral_constant<int, 6>{}, voff_next, cur, nxt);
-    unit(integral_constant<int, 7>{}, voff_next, cur, nxt);
-    const int64_t wt = wide_of(t);
-    finish(0, 2 * wt, n2cur[0]);
-    finish(1, 2 * wt + 1, n2cur[1]);
-    n2cur[0] = n2nxt[0];
-    n2cur[1] = n2nxt[1];
+    n2b[NX][0] = load_norm(t + 1, 0);
+    n2b[NX][1] = load_norm(t + 1, 1);
+    b1[0] = b2[0] = -INFINITY;
+    static_for<0, 8>([&](auto u_c) { unit(u_c, voff_next, xsb[CB], xsb[NX]); });
+    wt_prev = wide_of(t);
+    finish(0, 2 * wt_prev, n2b[CB][0]);
+    n2prev1 = n2b[CB][1];
+    have_prev = true;
   };
 #pragma unroll 1
   for (int t = 0; t < kWide; t += 2) {
     if (2 * ((int64_t)blockIdx.x * kWide + t) * kWaves >= a.T) break;
-    tile(t, xs, xsn);
+    tile(t, integral_constant<int, 0>{});
     if (t + 1 >= kWide || 2 * ((int64_t)blockIdx.x * kWide + t + 1) * kWaves >= a.T) break;
-    tile(t + 1, xsn, xs);
+    tile(t + 1, integral_constant<int, 1>{});
+  }
+  if (have_prev) {  // tile 1's values of the last unit
+    update(integral_constant<int, 1>{}, integral_constant<int, 7>{}, integral_constant<int, 0>{},
+           integral_constant<int, 8>{});
+    finish(1, 2 * wt_prev + 1, n2prev1);
   }
   flush_list(a, bl, b);
 }
 
 // ---- level 2 -----------------------------------------------------------------------------------------
 // The three-product selection (assign_fast.hip section 2b's loop order, fp16 pieces) over the points of
-// the level-1 list: a tile is 32 LISTED points, their pieces gathered from the fragment arrays (16
-// chunks of 16 B per point).  The grid covers the worst case (every point listed); blocks beyond the
+// the level-1 list: a tile is 32 LISTED points, their rows gathered from the hi and mid matrices (two
+// cache lines per point).  The grid covers the worst case (every point listed); blocks beyond the
 // list leave at once.
+constexpr int kTilesR = 8;  // 32-point tiles per wave and block: 2048 listed points per block (many small blocks:
+                            // the list is a few percent of the points and its length is only known on the device)
 template <int KS>
 __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
   constexpr int FPU = 2 * KS + 1;
@@ -597,7 +660,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
   const int m = a.m;
   int cnt = a.count_in[b];
   cnt = cnt < m ? cnt : m;
-  if ((int64_t)blockIdx.x * kTiles * kWaves * 32 >= cnt) return;  // block-uniform
+  if ((int64_t)blockIdx.x * kTilesR * kWaves * 32 >= cnt) return;  // block-uniform
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l31 = lane & 31, half = lane >> 5;
   BlockList* bl = reinterpret_cast<BlockList*>(smem + 8 * FPU * 1024);
@@ -617,17 +680,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
   const int* __restrict__ lst = a.list_in + (int64_t)b * m;
   // tile t of this wave = positions [32 tile, 32 tile + 32) of the list
   auto point_of = [&](int t) -> int {
-    const int64_t pos = (((int64_t)blockIdx.x * kTiles + t) * kWaves + wave) * 32 + l31;
-    return (t < kTiles && pos < cnt) ? lst[pos] : -1;
+    const int64_t pos = (((int64_t)blockIdx.x * kTilesR + t) * kWaves + wave) * 32 + l31;
+    return (t < kTilesR && pos < cnt) ? lst[pos] : -1;
   };
   auto voff_of = [&](int p) -> int {
-    return p >= 0 ? (p >> 5) * (KS * 1024) + ((p & 31) + 32 * half) * 16 : 0x7ffffff0;
+    return p >= 0 ? p * (32 * KS) + half * 16 : 0x7ffffff0;
   };
   f16x8 xs[KS][2], xsn[KS][2];
   auto load_frag = [&](int voff, auto e_c, f16x8 (&dst)[KS][2]) {
     constexpr int e = decltype(e_c)::value, st = e >> 1;
     dst[st][e & 1] = __builtin_bit_cast(
-        f16x8, __builtin_amdgcn_raw_buffer_load_b128((e & 1) ? rs_mid : rs_hi, voff, st * 1024, 0));
+        f16x8, __builtin_amdgcn_raw_buffer_load_b128((e & 1) ? rs_mid : rs_hi, voff, st * 32, 0));
   };
   auto load_norm = [&](int p) -> float2 { return nrm[p >= 0 ? p : 0]; };  // (clamped, never used when p < 0)
   int p_cur = point_of(0), p_nxt = point_of(1), p_nx2 = -1, p_prev = -1;
@@ -758,10 +821,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
     have_prev = true;
   };
 #pragma unroll 1
-  for (int t = 0; t < kTiles; t += 2) {
-    if (((int64_t)blockIdx.x * kTiles + t) * kWaves * 32 >= cnt) break;
+  for (int t = 0; t < kTilesR; t += 2) {
+    if (((int64_t)blockIdx.x * kTilesR + t) * kWaves * 32 >= cnt) break;
     tile(t, xs, xsn);
-    if (t + 1 >= kTiles || ((int64_t)blockIdx.x * kTiles + t + 1) * kWaves * 32 >= cnt) break;
+    if (t + 1 >= kTilesR || ((int64_t)blockIdx.x * kTilesR + t + 1) * kWaves * 32 >= cnt) break;
     tile(t + 1, xsn, xs);
   }
   if (have_prev) {  // the last unit of the last tile
@@ -808,11 +871,19 @@ static int run_levels(StepArgs sa, int l, int d, int* list2, int* count2, hipStr
   {  // level 1
     const size_t lds = (size_t)8 * (KS + 1) * 1024 + sizeof(BlockList);
     auto kernel = coarse_kernel<KS>;
+    if constexpr (KS == 4) {  // knock-outs (tools/kstats.sh with TPQ_LL_EXP=1|2|4|5)
+      const char* e = getenv("TPQ_LL_EXP");
+      const int exp = e ? atoi(e) : 0;
+      if (exp == 1) kernel = coarse_kernel<KS, 1>;
+      if (exp == 2) kernel = coarse_kernel<KS, 2>;
+      if (exp == 4) kernel = coarse_kernel<KS, 4>;
+      if (exp == 5) kernel = coarse_kernel<KS, 5>;
+    }
     int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                        "lloyd coarse_kernel attr");
     if (rc) return rc;
-    sa.eps = 1.001f / 2048.0f + common;
+    sa.eps = 1.001f / 2048.0f + common + 1.0f / 131072.0f;  // (6-bit keys: 2^-17)
     const int64_t wide = (sa.T + 1) / 2, per_block = (int64_t)kWaves * kWide;
     hipLaunchKernelGGL(kernel, dim3((unsigned)((wide + per_block - 1) / per_block), l), dim3(kWaves * 64), lds, st, sa);
     TPQ_LAUNCH_CHECK("lloyd coarse_kernel");
@@ -829,7 +900,7 @@ static int run_levels(StepArgs sa, int l, int d, int* list2, int* count2, hipStr
     sa.count_in = sa.count;
     sa.list = list2;
     sa.count = count2;
-    const int64_t per_block = (int64_t)kWaves * kTiles;
+    const int64_t per_block = (int64_t)kWaves * kTilesR;
     hipLaunchKernelGGL(kernel, dim3((unsigned)((sa.T + per_block - 1) / per_block), l), dim3(kWaves * 64), lds, st, sa);
     TPQ_LAUNCH_CHECK("lloyd refine_kernel");
   }
