@@ -393,73 +393,86 @@ def secondary_c4(device, stream_peak, steps=5):
 
 
 def secondary_c5(device, stream_peak, iters=3):
-    """configs[4]: MultiKMeans n_kmeans=64 d=64 n=1M k=256: the two kernels of one Lloyd iteration"""
+    """configs[4]: MultiKMeans n_kmeans=64 d=64 n=1M k=256: one Lloyd iteration as MultiKMeans.fit runs
+    it -- tpq_lloyd_step on data prepared once per fit (three-level exact assign + update) -- with the
+    per-kernel path (tpq_max_sim_select + tpq_compute_centroids) and the bit-exact fp32 assign beside it"""
     from torchpq_amd import kernels as K
     l, d, n, k = 64, 64, 1_000_000, 256
     g = torch.Generator(device=device)
     g.manual_seed(1237)
     data = torch.randn(l, d, n, generator=g, device=device)
     cent = data[:, :, torch.randperm(n, generator=g, device=device)[:k]].contiguous()
-    # the Lloyd loop of MultiKMeans.fit assigns with tpq_max_sim_split (exact 3-way bf16 split on the
-    # bf16 matrix cores, fp32-level accuracy); predict / encode use the bit-exact fp32-MFMA kernel,
-    # timed beside it
     from torchpq_amd.clustering import MultiKMeans
     mk = MultiKMeans(n_clusters=k)
     path = mk._assign_path(l, d, n, k, training=True)
-    assign = lambda a, b, **_: mk.get_labels(a, b, training=True)  # noqa: E731  (what fit() runs)
     assign_fp32 = K.MaxSimHip(distance="euclidean")
     update = K.ComputeCentroidsHip()
-    _, lab = assign(data, cent, dim=2, mode="tn")
-    _, lab32 = assign_fp32(data, cent, dim=2, mode="tn")
-    agree = float((lab == lab32).double().mean().item())
-    update(data, lab, k=k)
-    torch.cuda.synchronize()
 
-    def timeit(fn):
+    def timeit(fn, reps=iters):
+        fn()
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(iters):
+        for _ in range(reps):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters
+        return e0.elapsed_time(e1) / reps
 
-    t_assign = timeit(lambda: assign(data, cent, dim=2, mode="tn"))
+    step = mk._lloyd_step_for(data, cent)   # what fit() builds once per call (None: shape does not qualify)
+    assert step is not None, "configs[4] must take the prepared path"
+    t_prepare = timeit(lambda: K.LloydStepHip(data, cent), 1)
+    _, lab, new = step(cent)
+    _, lab32 = assign_fp32(data, cent, dim=2, mode="tn")
+    agree = float((lab == lab32).double().mean().item())
+    ref_new = update(data, lab32, k=k)
+    upd_err = float(((new - ref_new).abs().max() / ref_new.abs().max()).item())
+    lvl2 = float(step.rechecked(1).double().sum().item()) / (l * n)
+    lvl3 = float(step.rechecked(2).double().sum().item()) / (l * n)
+    t_step = timeit(lambda: step(cent))
+    t_assign = timeit(lambda: step(cent, update=False))
+    t_update = t_step - t_assign
     t_fp32 = timeit(lambda: assign_fp32(data, cent, dim=2, mode="tn"))
-    t_update = timeit(lambda: update(data, lab, k=k))
-    out = {"workload": f"MultiKMeans n_kmeans={l} d={d} n={n} k={k}, one Lloyd iteration = assign + update"}
+    t_sel = timeit(lambda: mk.get_labels(data, cent, training=True))
+    t_upd_sep = timeit(lambda: update(data, lab, k=k))
+    out = {"workload": f"MultiKMeans n_kmeans={l} d={d} n={n} k={k}, one Lloyd iteration = assign + update "
+                       "(tpq_lloyd_step on data prepared once per fit)"}
     flop = 2.0 * l * n * k * d
     byt = 4.0 * l * d * n
     tf = flop / t_assign / 1e9
     tf32 = flop / t_fp32 / 1e9
-    # matrix-pipe work actually issued per 32 points x 32 centroids x 16 dimensions: three piece products
-    # (select: two-piece split, error-bounded selection + exact re-check) or six (bf16x3 split kernel),
-    # plus one norm MFMA per 32 x 32 tile
+    # matrix-pipe work issued per 32 points x 32 centroids x 16 dimensions: level 1 = ONE fp16 product over
+    # all points, level 2 = three products over the undecided share, + one norm MFMA per 32 x 32 tile
     ks = (d + 15) // 16
-    prods = 3.0 if path == "select" else 6.0
-    issue_ratio = (prods * ks + 1.0) / ks * (16.0 * ks / d)
+    issue_ratio = ((1.0 * ks + 1.0) + lvl2 * (3.0 * ks + 1.0)) / ks * (16.0 * ks / d)
     peak_equiv = MFMA_BF16_PEAK_TFLOPS / issue_ratio
     out.update({
         "assign_ms": round(t_assign, 3), "update_ms": round(t_update, 3),
-        "iter_ms": round(t_assign + t_update, 3),
-        "iter_TFLOPs_end_to_end": round(flop / (t_assign + t_update) / 1e9, 1),
+        "iter_ms": round(t_step, 3), "prepare_ms_once_per_fit": round(t_prepare, 3),
+        "iter_TFLOPs_end_to_end": round(flop / t_step / 1e9, 1),
         "assign_labels_equal_to_fp32_kernel": round(agree, 6),
+        "new_centroids_max_rel_diff_vs_tpq_compute_centroids": upd_err,
+        "share_of_points_left_to_level_2": round(lvl2, 6), "share_re_checked_in_fp32": round(lvl3, 6),
         "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": round(peak_equiv, 1),
                      "unit": "TFLOP/s", "frac": round(tf / peak_equiv, 4), "traffic": None,
-                     "kernel": ("select_resident_kernel + max_sim_kernel over the re-check lists (bf16 MFMA top-2 "
-                                "selection with an error bound, exact fp32 re-check: the fp32 kernel's labels)"
-                                if path == "select" else
-                                "max_sim_split_kernel (bf16 MFMA, exact 3-way split, 6 piece products)"),
-                     "assign_path": path,
+                     "kernel": "coarse_kernel (one fp16 product, every point) + refine_kernel (three products, "
+                               "undecided share) + max_sim_kernel over the level-2 list (exact fp32): the fp32 "
+                               "kernel's labels",
+                     "assign_path": "lloyd_step", "per_kernel_assign_path": path,
                      "kernel_ms": round(t_assign, 3), "algorithmic_flops_per_launch": flop,
-                     "issued_bf16_TFLOPs": round(tf * issue_ratio, 1), "bf16_dense_peak": MFMA_BF16_PEAK_TFLOPS,
-                     "peak_note": f"fp32-equivalent: bf16 dense peak / {issue_ratio:.2f} MFMA flops issued per "
-                                  "algorithmic flop; frac = issued bf16 flop/s over the bf16 dense peak"},
+                     "issued_f16_TFLOPs": round(tf * issue_ratio, 1), "bf16_dense_peak": MFMA_BF16_PEAK_TFLOPS,
+                     "peak_note": f"fp32-equivalent: fp16/bf16 dense peak / {issue_ratio:.2f} MFMA flops issued per "
+                                  "algorithmic flop; frac = issued flop/s over the dense peak.  The coarse level "
+                                  "is VALU-bound (top-2 update: 2.5 instructions per value), not matrix-bound"},
+        "per_kernel_path": {"assign_ms": round(t_sel, 3), "update_ms": round(t_upd_sep, 3),
+                            "iter_ms": round(t_sel + t_upd_sep, 3),
+                            "what": "tpq_max_sim_select + tpq_compute_centroids on the fp32 data (round 2's "
+                                    "iteration; still the path of shapes / fits too small to prepare)"},
         "assign_fp32": {"ms": round(t_fp32, 3), "what": "tpq_max_sim, the bit-exact kernel of predict/encode",
                         "roofline": {"bound": "mfma", "achieved": round(tf32, 1), "peak": MFMA_F32_PEAK_TFLOPS,
                                      "unit": "TFLOP/s", "frac": round(tf32 / MFMA_F32_PEAK_TFLOPS, 4),
                                      "kernel": "max_sim_codebook_kernel (fp32 MFMA)"}},
-        "update_roofline": hbm_roofline(byt + 8.0 * l * n, t_update, "centroid_accum_mfma_kernel + finalize",
+        "update_roofline": hbm_roofline(byt + 8.0 * l * n, t_update, "update inside tpq_lloyd_step",
                                         stream_peak)})
     return out
 

@@ -13,7 +13,7 @@ import torch
 
 from .. import metric
 from ..CustomModule import CustomModule
-from ..kernels import CoarseAssignHip, ComputeCentroidsHip, MaxSimHip, MaxSimSelectHip
+from ..kernels import CoarseAssignHip, ComputeCentroidsHip, LloydStepHip, MaxSimHip, MaxSimSelectHip
 
 
 class MultiKMeans(CustomModule):
@@ -176,18 +176,47 @@ class MultiKMeans(CustomModule):
     def compute_centroids(self, data, labels):
         return self.compute_centroids_hip(data, labels, k=self.n_clusters)
 
+    # Codebook-sized euclidean problems (the "select" shapes) with at least this much work per
+    # iteration run the whole Lloyd iteration on PREPARED data (tpq_lloyd_prepare / tpq_lloyd_step):
+    # the points are centred, scaled and split into fp16 pieces once per fit() -- they never change,
+    # only the centroids do -- and every iteration is a three-level exact assign on those pieces + the
+    # update.  Same labels as the fp32 kernel, bit for bit.  Preparing costs about two iterations and
+    # a copy of the data in HBM; below `lloyd_min_iter` iterations it does not pay.
+    lloyd_min_work = 1 << 31   # multiply-adds per iteration: l * n * k * d
+    lloyd_min_iter = 4
+
+    def _lloyd_step_for(self, data, centroids):
+        """LloydStepHip for this fit(), or None when the shape / metric / size does not qualify (or HBM
+        has no room for the prepared copy: the per-kernel path is then used, same results)"""
+        l, d, n = data.shape
+        k = centroids.shape[2]
+        if (self.distance != "euclidean" or self.max_iter < self.lloyd_min_iter
+                or self._assign_path(l, d, n, k, True) != "select" or l * n * k * d < self.lloyd_min_work
+                or not LloydStepHip.supported(l, d, n, k)):
+            return None
+        try:
+            return LloydStepHip(data, centroids)
+        except torch.cuda.OutOfMemoryError:
+            return None
+
     def fit(self, data, centroids=None):
         """Lloyd iterations; returns labels [l, n_data] of the best redo."""
         assert data.is_contiguous(), "use .contiguous()"
         best = None
         tm = time()
+        step = False  # False: not decided yet; None: per-kernel path; else the prepared-data stepper
         for i in range(self.n_redo):
             if centroids is None:
                 centroids = self.initialize_centroids(data)
+            if step is False:  # the data is the same for every redo: prepared once
+                step = self._lloyd_step_for(data, centroids)
             labels = maxsims = error = None
             for j in range(self.max_iter):
-                maxsims, labels = self.get_labels(data, centroids, training=True)
-                new_centroids = self.compute_centroids(data, labels)
+                if step is not None:
+                    maxsims, labels, new_centroids = step(centroids)
+                else:
+                    maxsims, labels = self.get_labels(data, centroids, training=True)
+                    new_centroids = self.compute_centroids(data, labels)
                 error = self.calculate_error(centroids, new_centroids)
                 centroids = new_centroids
                 if self.verbose >= 3:
@@ -201,6 +230,7 @@ class MultiKMeans(CustomModule):
                 best = (inertia, centroids, labels)
             centroids = None
         self.register_buffer("centroids", best[1])
+        del step  # the prepared copy of the data and the step workspace
         self.max_sim_select_hip.release()  # its l x n int32 lists
         self.print_message(
             f"finished {self.n_redo} redos in {round(time() - tm, 4)} sec, final_inertia: {best[0]}", 1)
