@@ -76,13 +76,16 @@ static PrepLayout prep_layout(int l, int d, int64_t m) {
   PrepLayout L;
   L.KS = ks_of(d);
   L.T = (m + 31) / 32;
-  // hi and mid pieces as two row-major fp16 matrices [l][32 T points][16 KS dims]: the coarse pass streams
-  // the hi matrix only; a point's 16 KS values of a piece are ONE 32 KS-byte row, so that level 2 gathers a
-  // listed point with two cache lines (in MFMA-fragment order -- tile x k-step x lane x 16 B -- the
-  // 16-byte chunks of a point lie in 16 different lines: 1 KiB of traffic per gathered point).
-  // Lane (point, half) of a B operand reads 16 B at row + 32 st + 16 half.
+  // hi and mid pieces in two arrays [l][T tiles][Q = ceil(KS / 2) k-step pairs][32 points][64 B]: a point's
+  // 32 dimensions of a k-step pair are 64 contiguous bytes -- chunk 2 (st % 2) + half is what lane (point,
+  // half) of the B operand of k-step st reads.  The coarse pass streams the hi array only; the update
+  // streams one pair per wave; level 2 gathers a listed point as Q 64-byte pieces per array.  (Plain
+  // MFMA-fragment order -- tile x k-step x lane x 16 B -- scatters a point over 16 cache lines: 1 KiB of
+  // traffic per gathered point, level 2 at 1.6 ms instead of 0.6; plain row-major -- one 32 KS-byte row
+  // per point -- makes every 64-lane load touch 32 lines: the streaming kernels turn address-unit-bound,
+  // the update at 4.75 ms.  Here a 64-lane load touches 16 lines and uses half of each.)
   L.hi_off = 0;
-  L.mid_off = (size_t)l * L.T * L.KS * 1024;
+  L.mid_off = (size_t)l * L.T * ((L.KS + 1) / 2) * 2048;
   L.norms_off = 2 * L.mid_off;
   L.mu_off = L.norms_off + (size_t)l * L.T * 32 * 8;       // [l][T * 32] float2
   L.scale_off = L.mu_off + (size_t)l * 64 * 4;             // [l][64] f32
@@ -188,7 +191,8 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ A,
   const bool iv = i < m;
   const float* Ab = A + (int64_t)b * d * m + (iv ? i : 0);
   const float s = scale[b];
-  const int64_t fo = (((int64_t)b * T + tile) * 32 + l31) * (2 * KS) + half;  // 16-byte chunks: row 2 KS, chunk 2 st + half
+  const int Q = (KS + 1) / 2;
+  const int64_t fo = ((int64_t)b * T + tile) * Q * 128 + l31 * 4 + half;  // in 16-byte chunks
   float n2c = 0.f, n2r = 0.f;
   for (int st = 0; st < KS; ++st) {
     float x[8];
@@ -209,8 +213,12 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ A,
       n2c = fmaf(a, a, n2c);
       n2r = fmaf(x[j], x[j], n2r);
     }
-    hi[fo + 2 * st] = __builtin_bit_cast(u32x4, h);
-    mid[fo + 2 * st] = __builtin_bit_cast(u32x4, mm);
+    hi[fo + (st >> 1) * 128 + (st & 1) * 2] = __builtin_bit_cast(u32x4, h);
+    mid[fo + (st >> 1) * 128 + (st & 1) * 2] = __builtin_bit_cast(u32x4, mm);
+  }
+  if (KS & 1) {  // the empty second k-step of the last pair
+    hi[fo + (KS >> 1) * 128 + 2] = u32x4{0u, 0u, 0u, 0u};
+    mid[fo + (KS >> 1) * 128 + 2] = u32x4{0u, 0u, 0u, 0u};
   }
   n2c += __shfl_xor(n2c, 32, 64);
   n2r += __shfl_xor(n2r, 32, 64);
@@ -387,7 +395,7 @@ __device__ __forceinline__ void top2_keys_pair(float& p1, float& p2, float k0, f
 // Every level decides a point only when its two best fast values are further apart than twice its
 // own rigorous bound, so the labels are tpq_max_sim's whatever the split between the levels.
 struct StepArgs {
-  const u32x4* hi;             // [l][32 T][16 KS] fp16, row-major
+  const u32x4* hi;             // [l][T][Q][32 points][64 B]
   const u32x4* mid;            // likewise
   const float2* norms;         // [l][T * 32]: (|a'|^2, |x|^2)
   const u32x4* frags;          // [l][8][2 KS + 1][64]
@@ -476,22 +484,23 @@ __global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
                                        (__attribute__((address_space(3))) void*)(smem + f * 1024), 16, 0, 0);
     }
   }
-  const int64_t slice = a.T * KS * 1024;
+  constexpr int Q = (KS + 1) / 2;
+  const int64_t slice = a.T * Q * 2048;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(a.hi) + (size_t)b * slice), 0, (int)slice, 0x00020000);
   const float2* __restrict__ nrm = a.norms + (int64_t)b * a.T * 32;
   auto wide_of = [&](int t) -> int64_t { return ((int64_t)blockIdx.x * kWide + t) * kWaves + wave; };
   auto frag_voff = [&](int t) -> int {
     const int64_t wt = wide_of(t);
-    return (t < kWide && 2 * wt < a.T) ? (int)((2 * wt * 32 + l31) * (32 * KS)) + half * 16 : 0x7ffffff0;
+    return (t < kWide && 2 * wt < a.T) ? (int)(2 * wt * Q * 2048) + l31 * 64 + half * 16 : 0x7ffffff0;
   };
   f16x8 xsb[2][2][KS];  // [buffer][column tile][k-step]
   float2 n2b[2][2];     // [buffer][column tile]
-  // fragment e of the wide tile: column tile e / KS (32 rows further), k-step e % KS
+  // fragment e of the wide tile: column tile e / KS (the next tile), k-step e % KS
   auto load_frag = [&](int voff, auto e_c, f16x8 (&dst)[2][KS]) {
-    constexpr int e = decltype(e_c)::value;
-    dst[e / KS][e % KS] = __builtin_bit_cast(
-        f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (e / KS) * (1024 * KS) + (e % KS) * 32, 0));
+    constexpr int e = decltype(e_c)::value, ct = e / KS, st = e % KS;
+    dst[ct][st] = __builtin_bit_cast(
+        f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, ct * Q * 2048 + (st >> 1) * 2048 + (st & 1) * 32, 0));
   };
   auto load_norm = [&](int t, int ct) -> float2 {
     const int64_t tile = 2 * wide_of(t) + ct;  // (clamped: a tile beyond the range reads tile 0's norms; never used)
@@ -646,8 +655,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
 
 // ---- level 2 -----------------------------------------------------------------------------------------
 // The three-product selection (assign_fast.hip section 2b's loop order, fp16 pieces) over the points of
-// the level-1 list: a tile is 32 LISTED points, their rows gathered from the hi and mid matrices (two
-// cache lines per point).  The grid covers the worst case (every point listed); blocks beyond the
+// the level-1 list: a tile is 32 LISTED points, their pieces gathered from the hi and mid arrays (64
+// contiguous bytes per point, k-step pair and array).  The grid covers the worst case (every point listed); blocks beyond the
 // list leave at once.
 constexpr int kTilesR = 8;  // 32-point tiles per wave and block: 2048 listed points per block (many small blocks:
                             // the list is a few percent of the points and its length is only known on the device)
@@ -671,7 +680,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 1024 + lane * 16),
                                        (__attribute__((address_space(3))) void*)(smem + f * 1024), 16, 0, 0);
   }
-  const int64_t slice = a.T * KS * 1024;
+  constexpr int Q = (KS + 1) / 2;
+  const int64_t slice = a.T * Q * 2048;
   const __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(a.hi) + (size_t)b * slice), 0, (int)slice, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_mid = __builtin_amdgcn_make_buffer_rsrc(
@@ -684,13 +694,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
     return (t < kTilesR && pos < cnt) ? lst[pos] : -1;
   };
   auto voff_of = [&](int p) -> int {
-    return p >= 0 ? p * (32 * KS) + half * 16 : 0x7ffffff0;
+    return p >= 0 ? (p >> 5) * (Q * 2048) + (p & 31) * 64 + half * 16 : 0x7ffffff0;
   };
   f16x8 xs[KS][2], xsn[KS][2];
   auto load_frag = [&](int voff, auto e_c, f16x8 (&dst)[KS][2]) {
     constexpr int e = decltype(e_c)::value, st = e >> 1;
     dst[st][e & 1] = __builtin_bit_cast(
-        f16x8, __builtin_amdgcn_raw_buffer_load_b128((e & 1) ? rs_mid : rs_hi, voff, st * 32, 0));
+        f16x8, __builtin_amdgcn_raw_buffer_load_b128((e & 1) ? rs_mid : rs_hi, voff, (st >> 1) * 2048 + (st & 1) * 32, 0));
   };
   auto load_norm = [&](int p) -> float2 { return nrm[p >= 0 ? p : 0]; };  // (clamped, never used when p < 0)
   int p_cur = point_of(0), p_nxt = point_of(1), p_nx2 = -1, p_prev = -1;
@@ -844,6 +854,226 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
   flush_list(a, bl, b);
 }
 
+// ---- update from the pieces -------------------------------------------------------------------------
+// sums[cluster][dim] = sum_i onehot(label_i)[cluster] * (h_i + m_i)[dim] on v_mfma_f32_32x32x16_f16 (exact
+// products 1.0 * piece, fp32 sums: x is represented to 2^-22 relative, two ulps of fp32; the sums are
+// of the centred, scaled values s (x - mu), undone by finalize).  Against centroid_accum_mfma_kernel
+// (kmeans.hip) on the fp32 data: no splitting (it spends ~6.5 VALU instructions per element on three
+// bf16 pieces), no LDS staging of the data, 64 + 8 MFMAs per 32 points x 64 dimensions instead of 96.
+// The pieces are stored point-major (a lane of the assign kernels = one point, 8 dimensions); the
+// update contracts over POINTS, so its B operand wants lane = dimension, 8 points.  The transposition
+// runs on the matrix pipe: D = X I with the piece fragment as A (row = point, k = 16 dimensions)
+// and an identity slice as B puts X[point][dim] into the accumulator layout -- lane = column = dimension,
+// registers = rows = points -- exactly (one non-zero product per sum); eight v_cvt_pkrtz pack each
+// 16 registers into the two k-steps' B fragments.  Point of k-slot i of k-group g in k-step s:
+// 16 s + (i & 3) + 8 (i >> 2) + 4 g (the accumulator's row order) -- the one-hot operand uses the same.
+// One wave owns 256 clusters x 32 dimensions (128 accumulator registers); the block's waves are the
+// dimension tiles of the SAME points (their loads hit the same cache lines together).
+struct UpdArgs {
+  const u32x4* hi;
+  const u32x4* mid;
+  const int64_t* labels;  // [l][m]
+  const int* flag;        // [l]: flagged sub-problems are skipped here (flagged_accum_kernel)
+  float* sums;            // [l][d][k]
+  float* counts;          // [l][k]
+  int d, k, m;
+  int64_t T;
+};
+
+// Wave (dt, ch) of a block owns dimensions [32 dt, 32 dt + 32) x clusters [128 ch, 128 ch + 128): 64
+// accumulator registers, ~150 VGPRs in all -> three waves per SIMD.  (256 clusters per wave -- 128
+// accumulator registers, two waves per SIMD -- ran 4.75 ms at C5: with one staging set a wave has one
+// tile's loads in flight half of the time, 2048 waves x ~2 KiB, a third of what HBM latency x bandwidth
+// asks for; a second or third staging set does not fit beside 128 accumulator registers -- 116 / 465
+// spilled.  The four waves of a block read the same rows: one trip to HBM, the rest from L2 / L1.)
+// NH = cluster halves per dimension tile (1: a wave owns all 256 clusters, 128 accumulator registers, two
+// waves per SIMD; 2: 128 clusters, three waves per SIMD)
+template <int KS, int NH>
+__global__ __launch_bounds__(64 * NH * ((KS + 1) / 2), (NH == 1 ? 2 : 3)) void update_kernel(UpdArgs a) {
+  constexpr int DT = (KS + 1) / 2;
+  constexpr int NW = NH * DT;
+  constexpr int CW = 256 / NH, RT = 8 / NH;  // clusters / row tiles per wave
+  __shared__ __attribute__((aligned(16))) uint16_t otab_s[NW][2 * CW * 8];  // [k-group][cluster][8 slots] fp16
+  __shared__ int cnt_s[NW][CW];
+  const int b = blockIdx.y;
+  if (a.flag[b]) return;
+  const int wave = threadIdx.x >> 6, dt = wave / NH, ch = wave % NH;
+  const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+  uint16_t* otab = otab_s[wave];
+  int* cnt = cnt_s[wave];
+  const int64_t slice = a.T * DT * 2048;
+  const __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(a.hi) + (size_t)b * slice), 0, (int)slice, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_mid = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(a.mid) + (size_t)b * slice), 0, (int)slice, 0x00020000);
+  const int64_t* __restrict__ lrow = a.labels + (int64_t)b * a.m;
+  f32x16 acc[RT];  // [cluster row tile] x this wave's 32 dimensions
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+#pragma unroll
+  for (int u = 0; u < CW / 64; ++u) cnt[lane + 64 * u] = 0;
+#pragma unroll
+  for (int u = 0; u < CW / 32; ++u) reinterpret_cast<u32x4*>(otab)[lane + 64 * u] = u32x4{0u, 0u, 0u, 0u};
+  // identity slices: B[k][j] = (j == 16 ks2 + k), lane (j = l31, k-group half) holds k = 8 half .. + 7
+  f16x8 ident[2];
+#pragma unroll
+  for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ident[ks2][i] = (l31 == 16 * ks2 + 8 * half + i) ? (_Float16)1.0f : (_Float16)0.0f;
+  struct Staged {
+    f16x8 x[2][2];  // [piece][k-step of the pair]
+    int64_t label;
+    bool valid;
+  };
+  auto load_tile = [&](Staged& st, int64_t tile) {
+    const bool tv = tile < a.T;
+    const int64_t p = tile * 32 + l31;
+    // this wave's k-step pair of the tile: 2 KiB per array (an odd KS has a zero second half in its last pair)
+    const int voff = tv ? (int)((tile * DT + dt) * 2048) + l31 * 64 + half * 16 : 0x7ffffff0;
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      st.x[0][ks2] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_hi, voff, ks2 * 32, 0));
+      st.x[1][ks2] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_mid, voff, ks2 * 32, 0));
+    }
+    st.valid = tv && p < a.m;
+    st.label = lrow[st.valid ? p : 0];  // (raw: arithmetic right behind the load would wait for it on the spot)
+  };
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // tiles dealt round-robin to the blocks of a sub-problem (adjacent rows are read side by side).  A
+  // tile's fragments are consumed by its four transposing MFMAs and its label by one compare right at
+  // the start; the loads of the next tile go into the same registers immediately afterwards.
+  const int64_t step = gridDim.x;
+  Staged st;
+  load_tile(st, blockIdx.x);
+#pragma unroll 1
+  for (int64_t tile = blockIdx.x; tile < a.T; tile += step) {
+    // this wave's clusters only: label - CW ch in [0, CW)
+    const int64_t lab64 = st.label - CW * ch;
+    const int lab = (st.valid && st.label < a.k && lab64 >= 0 && lab64 < CW) ? (int)lab64 : -1;
+    // transposition: [32 points][32 dims] of each piece into accumulator layout, packed at once into the
+    // two k-steps' B fragments (one piece at a time: 16 transient registers)
+    u32x4 bop[2][2];  // [piece][k-step of 16 points], fp16 pairs
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) {
+      f32x16 tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.x[pc][0], ident[0], zero, 0, 0, 0);
+      tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.x[pc][1], ident[1], tr, 0, 0, 0);
+#pragma unroll
+      for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)  // (exact: every value IS an fp16 number)
+          bop[pc][sk][i] = __builtin_bit_cast(
+              uint32_t, __builtin_amdgcn_cvt_pkrtz(tr[8 * sk + 2 * i], tr[8 * sk + 2 * i + 1]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load_tile(st, tile + step);  // (beyond the range: offsets out of the buffer, label of point 0, valid = false)
+    __builtin_amdgcn_sched_barrier(0);
+    if (dt == 0 && half == 0 && lab >= 0) atomicAdd(&cnt[lab], 1);  // integer LDS atomic: fast
+    // this lane's point (l31; half 0 lanes write): k-step l31 >> 4, k-group (l31 >> 2) & 1, slot (l31 & 3) + 4 ((l31 >> 3) & 1)
+    uint16_t* oslot = &otab[((l31 >> 2) & 1) * (CW * 8) + (lab >= 0 ? lab : 0) * 8 + (l31 & 3) + 4 * ((l31 >> 3) & 1)];
+#pragma unroll
+    for (int sk = 0; sk < 2; ++sk) {
+      const bool writer = half == 0 && (l31 >> 4) == sk && lab >= 0;
+      if (writer) *oslot = (uint16_t)0x3C00;  // fp16 1.0
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const f16x8* orow = reinterpret_cast<const f16x8*>(&otab[half * (CW * 8) + l31 * 8]);
+      f16x8 aring[2];  // A operands are fetched one row tile (two MFMAs) ahead
+      aring[0] = orow[0];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        if (rt + 1 < RT) aring[(rt + 1) & 1] = orow[32 * (rt + 1)];
+        const f16x8 aop = aring[rt & 1];
+        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, __builtin_bit_cast(f16x8, bop[0][sk]), acc[rt], 0, 0, 0);
+        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, __builtin_bit_cast(f16x8, bop[1][sk]), acc[rt], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (writer) *oslot = (uint16_t)0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int dim = 32 * dt + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cluster = CW * ch + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float v = acc[rt][r];
+      if (dim < a.d && cluster < a.k && v != 0.f) unsafeAtomicAdd(&a.sums[((int64_t)b * a.d + dim) * a.k + cluster], v);
+    }
+  }
+  if (dt == 0) {
+#pragma unroll
+    for (int u = 0; u < CW / 64; ++u) {
+      const int c = lane + 64 * u;
+      if (CW * ch + c < a.k && cnt[c]) unsafeAtomicAdd(&a.counts[(int64_t)b * a.k + CW * ch + c], (float)cnt[c]);
+    }
+  }
+}
+
+// flagged sub-problems (data not finite / out of the fp16 range): raw fp32 sums straight to global atomics
+// (each point confined to its own cluster, as compute_centroids.cu:10-86 has it).  grid (64, l): the
+// blocks of an unflagged sub-problem leave at once (a grid over all points x dimensions was 16 M
+// empty blocks: 3.7 ms)
+__global__ __launch_bounds__(256) void flagged_accum_kernel(const float* __restrict__ data,
+                                                           const int64_t* __restrict__ labels,
+                                                           const int* __restrict__ flag, float* __restrict__ sums,
+                                                           float* __restrict__ counts, int d, int m, int k) {
+  const int b = blockIdx.y;
+  if (!flag[b]) return;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < m; i += (int64_t)gridDim.x * 256) {
+    const int64_t lab = labels[(int64_t)b * m + i];
+    if (lab < 0 || lab >= k) continue;
+    unsafeAtomicAdd(&counts[(int64_t)b * k + lab], 1.0f);
+    for (int e = 0; e < d; ++e)
+      unsafeAtomicAdd(&sums[((int64_t)b * d + e) * k + lab], data[((int64_t)b * d + e) * m + i]);
+  }
+}
+
+// centroid = mu + (sums / count) / s (raw sums / count for flagged sub-problems); empty cluster -> 0
+__global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__ sums, const float* __restrict__ counts,
+                                                      const float* __restrict__ mu, const float* __restrict__ scale,
+                                                      const int* __restrict__ flag, float* __restrict__ out, int d,
+                                                      int k, int64_t total) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int c = (int)(t % k);
+  const int dim = (int)((t / k) % d);
+  const int64_t b = t / ((int64_t)d * k);
+  const float cnt = counts[b * k + c];
+  float v = 0.f;  // compute_centroids.cu:82
+  if (cnt != 0.f) v = flag[b] ? sums[t] / cnt : mu[b * 64 + dim] + (sums[t] / cnt) * (1.f / scale[b]);
+  out[t] = v;
+}
+
+template <int KS>
+static int run_update(const UpdArgs& ua, const float* data, const float* mu, const float* scale, float* out, int l,
+                      hipStream_t st) {
+  constexpr int DT = (KS + 1) / 2;
+  // one round of resident waves: every wave ends with its (256 / NH) x 32 global atomics
+  const char* e = getenv("TPQ_LL_NH");  // (A/B)
+  const int nh = e ? atoi(e) : 1;
+  int64_t chunks = (nh == 1 ? 2048 : 3072) / ((int64_t)l * nh * DT);
+  if (chunks < 1) chunks = 1;
+  if (chunks > ua.T) chunks = ua.T;
+  if (nh == 1)
+    hipLaunchKernelGGL((update_kernel<KS, 1>), dim3((unsigned)chunks, l), dim3(64 * DT), 0, st, ua);
+  else
+    hipLaunchKernelGGL((update_kernel<KS, 2>), dim3((unsigned)chunks, l), dim3(128 * DT), 0, st, ua);
+  TPQ_LAUNCH_CHECK("lloyd update_kernel");
+  hipLaunchKernelGGL(flagged_accum_kernel, dim3(64, l), dim3(256), 0, st, data,
+                     ua.labels, ua.flag, ua.sums, ua.counts, ua.d, ua.m, ua.k);
+  TPQ_LAUNCH_CHECK("lloyd flagged_accum_kernel");
+  const int64_t total = (int64_t)l * ua.d * ua.k;
+  hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ua.sums, ua.counts, mu,
+                     scale, ua.flag, out, ua.d, ua.k, total);
+  TPQ_LAUNCH_CHECK("lloyd finalize_kernel");
+  return TPQ_OK;
+}
+
 // ---- step workspace --------------------------------------------------------------------------------
 struct StepLayout {
   size_t frags_off, cmax_off, count_off, cflag_off, count2_off, list_off, list2_off, upd_off, total;
@@ -915,7 +1145,7 @@ using namespace tpq;
 extern "C" int tpq_lloyd_supported(int l, int d, int64_t m, int n) {
   if (!(l >= 1 && l <= 65535 && d >= 1 && d <= 64 && n >= 1 && n <= 256 && m >= 1 && m < (1LL << 31))) return 0;
   const lloyd::PrepLayout L = lloyd::prep_layout(l, d, m);
-  return (L.T * L.KS * 1024 <= 0x7fffffffLL && (int64_t)d * m * 4 <= 0x7fffffffLL) ? 1 : 0;
+  return (L.T * ((L.KS + 1) / 2) * 2048 <= 0x7fffffffLL && (int64_t)d * m * 4 <= 0x7fffffffLL) ? 1 : 0;
 }
 
 extern "C" size_t tpq_lloyd_prepared_bytes(int l, int d, int64_t m) {
@@ -1013,8 +1243,23 @@ extern "C" int tpq_lloyd_step(const float* data, const void* prepared, const flo
   if (rc) return rc;
   rc = launch_max_sim_list(data, centroids, vals, inds, l, d, (int)m, n, 1, list2, count2, nullptr, nullptr, 0, st);
   if (rc) return rc;
-  if (new_centroids)
-    return tpq_compute_centroids(data, inds, new_centroids, l, d, m, n, ws + L.upd_off,
-                                 tpq_compute_centroids_workspace_bytes(l, d, n), stream);
+  if (new_centroids) {
+    if (getenv("TPQ_LL_OLD_UPDATE"))  // (A/B: the fp32-data update of kmeans.hip)
+      return tpq_compute_centroids(data, inds, new_centroids, l, d, m, n, ws + L.upd_off,
+                                   tpq_compute_centroids_workspace_bytes(l, d, n), stream);
+    float* sums = reinterpret_cast<float*>(ws + L.upd_off);
+    float* counts = sums + (size_t)l * d * n;
+    rc = check_hip(hipMemsetAsync(sums, 0, tpq_compute_centroids_workspace_bytes(l, d, n), st), "lloyd_step memset");
+    if (rc) return rc;
+    lloyd::UpdArgs ua{reinterpret_cast<const lloyd::u32x4*>(p + P.hi_off),
+                      reinterpret_cast<const lloyd::u32x4*>(p + P.mid_off), inds,
+                      reinterpret_cast<const int*>(p + P.flag_off), sums, counts, d, n, (int)m, P.T};
+    switch (KS) {
+      case 1: return lloyd::run_update<1>(ua, data, mu, scale, new_centroids, l, st);
+      case 2: return lloyd::run_update<2>(ua, data, mu, scale, new_centroids, l, st);
+      case 3: return lloyd::run_update<3>(ua, data, mu, scale, new_centroids, l, st);
+      default: return lloyd::run_update<4>(ua, data, mu, scale, new_centroids, l, st);
+    }
+  }
   return TPQ_OK;
 }
