@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     for w in ("c2", "c3", "c4", "c5"):
         src = os.path.join(ROOT, "gpurun_out", tag, w)
         if not os.path.isdir(src):

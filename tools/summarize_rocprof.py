@@ -40,6 +40,29 @@ def main():
                     out["grid"] = int(r["Grid_Size"])
             for k, v in agg.items():
                 out["pmc"][k] = {"launches": len(v), "mean": sum(v) / len(v)}
+            # every kernel of the k-means step, per kernel (c5: coarse / refine / exact re-check / update)
+            per = collections.defaultdict(lambda: collections.defaultdict(list))
+            for r in csv.DictReader(open(f)):
+                for tag in ("coarse_kernel", "refine_kernel", "update_kernel", "max_sim_kernel",
+                            "select_resident_kernel", "centroid_accum_mfma_kernel", "max_sim_codebook_kernel"):
+                    if tag in r["Kernel_Name"]:
+                        per[tag][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            for tag, ctrs in per.items():
+                dst = out.setdefault("pmc_by_kernel", {}).setdefault(tag, {})
+                for k, v in ctrs.items():
+                    dst[k] = {"launches": len(v), "mean": sum(v) / len(v)}
+    for tag, c in out.get("pmc_by_kernel", {}).items():  # derived shares (SQ_* in quad-cycles, MI355X_MICROARCH.md)
+        d = {}
+        if "GRBM_GUI_ACTIVE" in c:
+            d["cycles_per_launch"] = c["GRBM_GUI_ACTIVE"]["mean"] / 8.0  # summed over the 8 XCDs
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+                d["mfma_busy_share"] = c["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 1024.0 / d["cycles_per_launch"]
+        if "SQ_WAVE_CYCLES" in c:
+            for k in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"):
+                if k in c:
+                    d[k.lower() + "_share_of_wave_cycles"] = c[k]["mean"] / c["SQ_WAVE_CYCLES"]["mean"]
+        if d:
+            c["derived"] = d
     p = out["pmc"]
     if "FETCH_SIZE" in p:
         # FETCH_SIZE is in KiB and, on gfx950, counts 64 B per 128-B request: x2 (MI355X_MICROARCH HBM)

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
                                                          const int* __restrict__ list,
                                                          const int* __restrict__ count,
                                                          unsigned long long* __restrict__ keys,
-                                                         const float* __restrict__ Ac, int cap, int pos0) {
+                                                         const float* __restrict__ Ac, int cap, int pos0,
+                                                         int tile_stride) {
   // list != nullptr (tpq_coarse_assign's exact re-check): the points are columns list[0 .. *count)
   // of A, results go to inds[list[p]], vals may be null; the grid covers the worst case and blocks
   // beyond *count leave at once.  keys != nullptr (one problem, many centroids, few points): the
@@ -83,15 +84,21 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
   const int b = keys ? 0 : blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l31 = lane & 31, half = lane >> 5;
-  const int pos = pos0 + blockIdx.x * 128 + wave * 32 + l31;  // this lane's point (position in the list)
   int m_eff = m;
   if (list) {
     list += (int64_t)b * m;  // one list per sub-problem
     m_eff = count[b];
     m_eff = m_eff < m ? m_eff : m;
     if (Ac) m_eff = m_eff < cap ? m_eff : cap;
-    if (pos0 + (int)blockIdx.x * 128 >= m_eff) return;  // block-uniform
   }
+  // tile_stride > 0 (batched lists, tpq_lloyd_step): the grid is a FEW blocks per sub-problem, each
+  // walking the 128-point tiles tile0, tile0 + tile_stride, ... of its list -- a grid over the worst
+  // case (every point listed) is 500 000 blocks at configs[4], nearly all of them empty, and costs
+  // more than the listed 0.3 % of the points do
+  for (int tile0 = blockIdx.x;; tile0 += tile_stride) {
+  const int pos = pos0 + tile0 * 128 + wave * 32 + l31;  // this lane's point (position in the list)
+  if (list && pos0 + tile0 * 128 >= m_eff) return;  // block-uniform
+  if (!list && tile0 * 128 >= m) return;
   const bool iv = pos < m_eff;
   const int i = list ? (iv ? list[pos] : 0) : pos;  // column of A / slot of the outputs
   // Every global load below is `uniform row pointer [per-lane 32-bit offset]`: the row pointer
@@ -272,6 +279,9 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
       inds[(int64_t)b * m + i] = besti;
     }
   }
+  if (tile_stride <= 0) return;
+  __syncthreads();  // the next tile's first slab overwrites cs / b2s
+  }
 }
 
 // Ac[k][p] = A[k][list[p]] for p < min(*count, cap): grid (ceil(cap / 256), d)
@@ -321,11 +331,11 @@ int launch_max_sim_list(const float* A, const float* B, float* vals, int64_t* in
                        cap);
     TPQ_LAUNCH_CHECK("gather_columns_kernel");
     hipLaunchKernelGGL(max_sim_kernel, dim3((cap + 127) / 128, splits), dim3(256), ms_lds, st, A, B, vals, inds, d,
-                       m, n, euclid, list, count, keys, static_cast<const float*>(Ac), cap, 0);
+                       m, n, euclid, list, count, keys, static_cast<const float*>(Ac), cap, 0, 0);
     TPQ_LAUNCH_CHECK("max_sim_kernel (list, compact)");
     if (cap < m) {  // more listed points than the compact copy holds: gather for the rest
       hipLaunchKernelGGL(max_sim_kernel, dim3((m - cap + 127) / 128, splits), dim3(256), ms_lds, st, A, B, vals,
-                         inds, d, m, n, euclid, list, count, keys, static_cast<const float*>(nullptr), 0, cap);
+                         inds, d, m, n, euclid, list, count, keys, static_cast<const float*>(nullptr), 0, cap, 0);
       TPQ_LAUNCH_CHECK("max_sim_kernel (list, overflow)");
     }
     hipLaunchKernelGGL(max_sim_list_decode_kernel, dim3((m + 255) / 256), dim3(256), 0, st, list, count, keys,
@@ -333,9 +343,12 @@ int launch_max_sim_list(const float* A, const float* B, float* vals, int64_t* in
     TPQ_LAUNCH_CHECK("max_sim_list_decode_kernel");
     return TPQ_OK;
   }
-  hipLaunchKernelGGL(max_sim_kernel, dim3((m + 127) / 128, l), dim3(256), ms_lds, st, A, B, vals, inds, d,
+  // a few looping blocks per sub-problem (see the kernel): all CUs busy twice over, no empty blocks
+  int per = (2048 + l - 1) / l;
+  per = per < (m + 127) / 128 ? per : (m + 127) / 128;
+  hipLaunchKernelGGL(max_sim_kernel, dim3(per, l), dim3(256), ms_lds, st, A, B, vals, inds, d,
                      m, n, euclid, list, count, static_cast<unsigned long long*>(nullptr),
-                     static_cast<const float*>(nullptr), 0, 0);
+                     static_cast<const float*>(nullptr), 0, 0, per);
   TPQ_LAUNCH_CHECK("max_sim_kernel (list)");
   return TPQ_OK;
 }
@@ -966,7 +979,7 @@ extern "C" int tpq_max_sim(const float* A, const float* B, float* vals, int64_t*
   hipLaunchKernelGGL(max_sim_kernel, dim3((m + 127) / 128, l), dim3(256), ms_lds, st, A, B, vals,
                      inds, d, m, n, euclid, static_cast<const int*>(nullptr),
                      static_cast<const int*>(nullptr), static_cast<unsigned long long*>(nullptr),
-                     static_cast<const float*>(nullptr), 0, 0);
+                     static_cast<const float*>(nullptr), 0, 0, 0);
   TPQ_LAUNCH_CHECK("max_sim_kernel");
   return TPQ_OK;
 }
