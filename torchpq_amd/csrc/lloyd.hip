@@ -58,6 +58,9 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+#ifndef TPQ_LL_PF
+#define TPQ_LL_PF 0  // update kernel: tiles ahead of an L2 prefetch by LDS-DMA (0 = none; see the kernel)
+#endif
 constexpr int kWaves = 8;
 #ifndef TPQ_LL_TILES
 #define TPQ_LL_TILES 32
@@ -895,6 +898,7 @@ __global__ __launch_bounds__(64 * NH * ((KS + 1) / 2), (NH == 1 ? 2 : 3)) void u
   constexpr int CW = 256 / NH, RT = 8 / NH;  // clusters / row tiles per wave
   __shared__ __attribute__((aligned(16))) uint16_t otab_s[NW][2 * CW * 8];  // [k-group][cluster][8 slots] fp16
   __shared__ int cnt_s[NW][CW];
+  __shared__ __attribute__((aligned(16))) char pf_s[NW][4096];  // landing zone of the L2 prefetch (never read)
   const int b = blockIdx.y;
   if (a.flag[b]) return;
   const int wave = threadIdx.x >> 6, dt = wave / NH, ch = wave % NH;
@@ -968,6 +972,25 @@ __global__ __launch_bounds__(64 * NH * ((KS + 1) / 2), (NH == 1 ? 2 : 3)) void u
     }
     __builtin_amdgcn_sched_barrier(0);
     load_tile(st, tile + step);  // (beyond the range: offsets out of the buffer, label of point 0, valid = false)
+    if (TPQ_LL_PF) {
+      // (Experiment, off: the registers can hold ONE tile in flight -- a second staging set beside 128
+      // accumulator registers spills -- and it has only this tile's update MFMAs, half a microsecond,
+      // to land.  Pulling the tile three steps on into L2 by LDS-DMA into a landing zone nobody reads
+      // costs no registers, but hipcc cannot tell the landing zone from the one-hot table: it puts
+      // s_waitcnt vmcnt(0) in front of every LDS access of the loop, i.e. waits for the loads it has
+      // just issued.)
+      int64_t pt = tile + TPQ_LL_PF * step;
+      pt = pt < a.T ? pt : tile;
+      const char* g_hi = reinterpret_cast<const char*>(a.hi) + (size_t)b * slice + (pt * DT + dt) * 2048 + lane * 16;
+      const char* g_mid = reinterpret_cast<const char*>(a.mid) + (size_t)b * slice + (pt * DT + dt) * 2048 + lane * 16;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g_hi + q * 1024),
+                                         (__attribute__((address_space(3))) void*)(pf_s[wave] + q * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g_mid + q * 1024),
+                                         (__attribute__((address_space(3))) void*)(pf_s[wave] + 2048 + q * 1024), 16, 0, 0);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (dt == 0 && half == 0 && lab >= 0) atomicAdd(&cnt[lab], 1);  // integer LDS atomic: fast
     // this lane's point (l31; half 0 lanes write): k-step l31 >> 4, k-group (l31 >> 2) & 1, slot (l31 & 3) + 4 ((l31 >> 3) & 1)
