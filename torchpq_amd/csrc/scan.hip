@@ -27,6 +27,8 @@
 //                        candidates exactly (ascending j) at the end of the query and dumps its
 //                        list; scan_merge_refine_kernel (one wave per query) merges the lists.
 //                        Results are bit-identical to scan_ref_kernel.
+#include <atomic>
+
 #include "scan_device.h"
 
 namespace tpq {
@@ -190,7 +192,8 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
     return dispatch_ref(a, Rr, st);
   }
   const int n_lists = n_split * packed_waves(m);
-  const int RL = list_regs_scan(k, packed_waves(m));  // registers of the per-wave lists (<= R)
+  // registers of the per-wave lists (<= R)
+  const int RL = list_regs_scan(k, packed_waves(m));
   a.small_lists = RL < R ? 1 : 0;
   rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, RL, n_lists), "ivfpq_scan_packed");
   if (rc) return rc;
@@ -198,11 +201,9 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
 #ifdef TPQ_SCAN_PROFILE
   a.prof = g_scan_prof;
 #endif
-  if (ra || a.small_lists) {  // the scan kernel may raise a flag itself (residual: a slot covered by
-                              // two probes; large k: a wave's short list overflowed)
-    rc = check_hip(hipMemsetAsync(a.flags, 0, (size_t)nq * 4, st), "ivfpq_scan_packed memset");
-    if (rc) return rc;
-  }
+  // flags: raised == equal to this call's epoch; no zeroing pass (it was a launch of its own)
+  static std::atomic<unsigned> g_epoch{0x5eed0001u};
+  a.epoch = (int)(g_epoch.fetch_add(0x9e3779b1u) | 1u);
   switch (m) {
 #define TPQ_CASE_M(M) case M: rc = dispatch_packed_##M(a, ra, RL, R, st); break;
     TPQ_PACKED_M_LIST(TPQ_CASE_M)

@@ -26,13 +26,16 @@ struct ScanArgs {
   int64_t* out_ids;
   float* ws_vals;  // [nq][n_split][64R]
   int* ws_idx;
-  int* flags;             // [nq] packed path: 1 = candidate band overflowed, redo exactly
+  int* flags;             // [nq] packed path: == epoch: candidate band overflowed, redo exactly.  Never zeroed:
+                          // "raised" is equality with this call's epoch (the workspace arrives as garbage; a
+                          // word that happens to equal the epoch costs one needless exact redo, never a wrong result)
   float* ws_delta;        // [nq] packed path: fast-vs-exact error bound of the query
   const int* only_flagged;  // reference kernel: when set, only queries with a non-zero flag run
   int64_t n_slots;
   int nq, max_nprobe, m, k, n_split;
   unsigned long long* prof;  // -DTPQ_SCAN_PROFILE builds: [nq][16] phase timestamps (10 ns ticks)
   int small_lists;           // packed path, large k: per-wave lists hold fewer than k + 8 entries
+  int epoch;                 // value that marks a raised flag in this call (non-zero)
 };
 
 #ifdef TPQ_SCAN_PROFILE
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_ref_kernel(ScanArgs a) {
 
   const int q = blockIdx.x / a.n_split;
   const int part = blockIdx.x - q * a.n_split;
-  if (a.only_flagged && a.only_flagged[q] == 0) return;  // exact redo of flagged queries only
+  if (a.only_flagged && a.only_flagged[q] != a.epoch) return;  // exact redo of flagged queries only
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   int n_probe = (int)a.n_probe_list[q];
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_residual_kernel(ScanArgs a,
   float* xq = reinterpret_cast<float*>(tau_key + 1);  // part1 built here: query [m*ds], |q_j|^2 [m]
 
   const int q = blockIdx.x;
-  if (a.only_flagged && a.only_flagged[q] == 0) return;  // exact redo of flagged queries only
+  if (a.only_flagged && a.only_flagged[q] != a.epoch) return;  // exact redo of flagged queries only
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
   int n_probe = (int)a.n_probe_list[q];
@@ -502,10 +505,10 @@ __device__ __forceinline__ void finalize_and_write(const ScanArgs& a, int q, con
   const Key klast = readlane_key(top.k[R - 1], 63);
   const bool overflow = (key_index(klast) != kPadIdx) && !(key_value(klast) < ek - delta2);
   write_final<R>(a, q, top);
-  if (RES || a.small_lists) {  // flags were zeroed by the host; the scan may already have raised this one
-    if (lane_id() == 0 && overflow) a.flags[q] = 1;
+  if (RES || a.small_lists) {  // the scan kernel may already have raised this one
+    if (lane_id() == 0 && overflow) a.flags[q] = a.epoch;
   } else {
-    if (lane_id() == 0) a.flags[q] = overflow ? 1 : 0;
+    if (lane_id() == 0) a.flags[q] = overflow ? a.epoch : 0;
   }
 }
 
@@ -954,7 +957,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
       // it evicted was worse still.)
       const Key kl = readlane_key(sel.top.k[R - 1], 63);
 #ifndef TPQ_EXP_NO_OVERFLOW_FLAG  // knock-out for tests/test_gpu_kernels.py's adversarial case
-      if (key_index(kl) != kPadIdx && key_value(kl) >= cut && lane == 0) a.flags[q] = 1;
+      if (key_index(kl) != kPadIdx && key_value(kl) >= cut && lane == 0) a.flags[q] = a.epoch;
 #endif
     }
     constexpr int RR = refine_rows(M);
@@ -980,7 +983,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
           myp = (hit && myp < 0) ? pp : myp;
           n_match += hit ? 1 : 0;
         }
-        if (n_match > 1) a.flags[q] = 1;
+        if (n_match > 1) a.flags[q] = a.epoch;
         myp = myp < 0 ? 0 : myp;
         init = pbase[myp];
         p2 = ra.part2 + (int64_t)pcell[myp] * (M * 256);
@@ -1014,7 +1017,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
 template <int R>
 __global__ __launch_bounds__(64) void scan_merge_kernel(ScanArgs a) {
   const int q = blockIdx.x;
-  if (a.only_flagged && a.only_flagged[q] == 0) return;
+  if (a.only_flagged && a.only_flagged[q] != a.epoch) return;
   WaveTopK<R> top;
   top.init();
   for (int part = 0; part < a.n_split; ++part) {

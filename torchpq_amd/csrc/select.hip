@@ -35,22 +35,16 @@ struct ProbeEpilogue {
   float inv_t;                    // 1 / temperature; <= 0: n_probe_list = k
 };
 
+// one wave selects row `row` (its values at xr[0 .. cols), global memory or LDS) -- the body of
+// topk_select_kernel and of probe_small_kernel
 template <int R>
-__global__ __launch_bounds__(kSelWaves * 64) void topk_select_kernel(const float* __restrict__ x,
-                                                                    const float* __restrict__ a2,
-                                                                    const float* __restrict__ b2,
-                                                                    float* __restrict__ vals,
-                                                                    int64_t* __restrict__ idx,
-                                                                    int rows, int cols, int k,
-                                                                    ProbeEpilogue pe, GroupFilter gf) {
-  __shared__ float qv[kSelWaves * 64];
-  __shared__ int qi[kSelWaves * 64];
-  const int wave = threadIdx.x >> 6, lane = lane_id();
-  const int row = blockIdx.x * kSelWaves + wave;
-  if (row >= rows) return;
+__device__ __forceinline__ void select_row(float* qvw, int* qiw, const float* xr, const float* __restrict__ a2,
+                                           const float* __restrict__ b2, float* __restrict__ vals,
+                                           int64_t* __restrict__ idx, int row, int cols, int k,
+                                           const ProbeEpilogue& pe, const GroupFilter& gf) {
+  const int lane = lane_id();
   WaveSelector<R> sel;
-  sel.init(qv + wave * 64, qi + wave * 64, k);
-  const float* __restrict__ xr = x + (int64_t)row * cols;
+  sel.init(qvw, qiw, k);
   const float ra2 = a2 ? a2[row] : 0.f;
   if (gf.gmax) {
     // phase 1: the k-th largest group maximum
@@ -62,7 +56,7 @@ __global__ __launch_bounds__(kSelWaves * 64) void topk_select_kernel(const float
     }
     sel.flush();
     const float tau0 = sel.top.kth_value(k);  // -inf while there are fewer than k groups
-    sel.init(qv + wave * 64, qi + wave * 64, k);
+    sel.init(qvw, qiw, k);
     // phase 2: only the groups that can hold a member of the top-k, four (eight loads) at a time
     for (int base = 0; base < gf.n_groups; base += 64) {
       const int g = base + lane;
@@ -175,6 +169,89 @@ __global__ __launch_bounds__(kSelWaves * 64) void topk_select_kernel(const float
     n = n < 1 ? 1 : (n > k ? k : n);
     pe.n_probe_list[row] = n;
   }
+}
+
+template <int R>
+__global__ __launch_bounds__(kSelWaves * 64) void topk_select_kernel(const float* __restrict__ x,
+                                                                    const float* __restrict__ a2,
+                                                                    const float* __restrict__ b2,
+                                                                    float* __restrict__ vals,
+                                                                    int64_t* __restrict__ idx,
+                                                                    int rows, int cols, int k,
+                                                                    ProbeEpilogue pe, GroupFilter gf) {
+  __shared__ float qv[kSelWaves * 64];
+  __shared__ int qi[kSelWaves * 64];
+  const int wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * kSelWaves + wave;
+  if (row >= rows) return;
+  select_row<R>(qv + wave * 64, qi + wave * 64, x + (int64_t)row * cols, a2, b2, vals, idx, row, cols, k, pe, gf);
+}
+
+// Small batches (tpq_ivfpq_coarse_probe, nq <= kProbeSmallMaxQ): the whole coarse step of a query in ONE
+// block -- its sims row computed into LDS, selected by wave 0 -- instead of the sims kernel + the select
+// kernel (at one query the launch gaps and the second kernel's start-up are most of the 28 us).
+// One thread per cell: dot, |C|^2 and (every thread) |x|^2 as ascending-k fmaf chains, v = (2 dot - |x|^2)
+// - |C|^2: the arithmetic of coarse_sims_kernel and oracle_coarse_sims, bit for bit.  The chains are
+// sequential in k, the loads are not: 16 in flight per thread.
+constexpr int kProbeSmallThreads = 1024;
+constexpr int kProbeSmallMaxQ = 64;
+constexpr int kProbeSmallMaxCells = 8192;   // sims row in LDS (32 KiB)
+constexpr int kProbeSmallMaxD = 1024;       // query in LDS
+
+template <int R>
+__global__ __launch_bounds__(kProbeSmallThreads) void probe_small_kernel(const float* __restrict__ x,
+                                                                        const float* __restrict__ C,
+                                                                        float* __restrict__ vals,
+                                                                        int64_t* __restrict__ idx, int d, int nq,
+                                                                        int n_cells, int k, ProbeEpilogue pe) {
+  __shared__ float row_s[kProbeSmallMaxCells];
+  __shared__ float xq[kProbeSmallMaxD];
+  __shared__ float qv[64];
+  __shared__ int qi[64];
+  const int q = blockIdx.x;
+  for (int t = threadIdx.x; t < d; t += kProbeSmallThreads) xq[t] = x[(int64_t)t * nq + q];
+  __syncthreads();
+  float q2 = 0.f;
+  for (int t = 0; t < d; ++t) q2 = fmaf(xq[t], xq[t], q2);
+  for (int c = threadIdx.x; c < n_cells; c += kProbeSmallThreads) {
+    const float* __restrict__ p = C + c;
+    float acc = 0.f, c2 = 0.f;
+    int t = 0;
+    // 64 loads in flight per thread (the chains are sequential in k, the loads are not): at one query
+    // the block is alone on the chip and the 512 KiB of centroids come from L2 / the Infinity Cache --
+    // with 16 in flight the eight round trips were most of the kernel's 30 us
+    for (; t + 64 <= d; t += 64) {
+      float y[64];
+#pragma unroll
+      for (int u = 0; u < 64; ++u) y[u] = p[(int64_t)(t + u) * n_cells];
+#pragma unroll
+      for (int u = 0; u < 64; ++u) {
+        acc = fmaf(y[u], xq[t + u], acc);
+        c2 = fmaf(y[u], y[u], c2);
+      }
+    }
+    for (; t + 16 <= d; t += 16) {
+      float y[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) y[u] = p[(int64_t)(t + u) * n_cells];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        acc = fmaf(y[u], xq[t + u], acc);
+        c2 = fmaf(y[u], y[u], c2);
+      }
+    }
+    for (; t < d; ++t) {
+      const float y = p[(int64_t)t * n_cells];
+      acc = fmaf(y, xq[t], acc);
+      c2 = fmaf(y, y, c2);
+    }
+    float v = 2.f * acc;
+    v = v - q2;
+    v = v - c2;
+    row_s[c] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) select_row<R>(qv, qi, row_s, nullptr, nullptr, vals, idx, q, n_cells, k, pe, GroupFilter{nullptr, 0});
 }
 
 // IVFPQIndex.py:499-512.  One wave per row.
@@ -565,6 +642,24 @@ extern "C" int tpq_ivfpq_coarse_probe(const float* query, const float* centroids
     return TPQ_ERR_WORKSPACE;
   }
   float* sims = reinterpret_cast<float*>(workspace);
+  ProbeEpilogue pe{cell_start_tbl, cell_size_tbl, cell_start, cell_size, n_probe_list,
+                   smart_temperature > 0.f ? 1.0f / smart_temperature : 0.f};
+  if (nq <= kProbeSmallMaxQ && n_cells <= kProbeSmallMaxCells && d <= kProbeSmallMaxD &&
+      (long long)n_cells * d <= (1 << 20)) {  // one launch: sims row in LDS + select, one block per query
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int r = (n_probe + 63) / 64;
+#define TPQ_PS(RR)                                                                                         \
+  hipLaunchKernelGGL(probe_small_kernel<RR>, dim3(nq), dim3(kProbeSmallThreads), 0, st, query, centroids, \
+                     topk_sims, cells, d, nq, n_cells, n_probe, pe)
+    if (r <= 1) TPQ_PS(1);
+    else if (r <= 2) TPQ_PS(2);
+    else if (r <= 4) TPQ_PS(4);
+    else if (r <= 8) TPQ_PS(8);
+    else TPQ_PS(16);
+#undef TPQ_PS
+    TPQ_LAUNCH_CHECK("probe_small_kernel");
+    return TPQ_OK;
+  }
   // large problems: blocks = 128-query groups x centroid-chunk groups (a block walks several
   // 256-centroid chunks once there are enough blocks to fill the chip a few times over) and the
   // row select is restricted by the group maxima; small ones: 64 x 256 tiles, full row select
@@ -591,8 +686,6 @@ extern "C" int tpq_ivfpq_coarse_probe(const float* query, const float* centroids
     gf = GroupFilter{gmax, n_groups};
   }
   TPQ_LAUNCH_CHECK("coarse_sims_kernel");
-  ProbeEpilogue pe{cell_start_tbl, cell_size_tbl, cell_start, cell_size, n_probe_list,
-                   smart_temperature > 0.f ? 1.0f / smart_temperature : 0.f};
   return select_impl(sims, nullptr, nullptr, topk_sims, cells, nq, n_cells, n_probe, stream, pe, gf);
 }
 
