@@ -252,8 +252,10 @@ int tpq_max_sim_split(const float* A, const float* B, float* vals, int64_t* inds
  *          -> kernels/MaxSimCuda.py:296-340, kernel max_sim_tn torchpq/kernels/cuda/max_sim.cu:182-309
  * A f32 [d][m] points, B f32 [d][n] centroids (one problem) -> inds i64 [m] = arg-max over the
  * centroids of the oracle's fp32 arithmetic (ascending-k fmaf chains; ties -> smallest index).
- * An error-bounded top-2 selection on split-bf16 MFMAs decides every point whose two best fast
- * values differ by more than twice the bound; the others are re-evaluated exactly on the device.
+ * An error-bounded top-2 selection decides every point whose two best fast values differ by more
+ * than twice the bound; the others are re-evaluated exactly on the device.  Euclidean problems with
+ * >= 4 096 centroids take the three-level fp16 cascade of tpq_lloyd_step (points prepared per call,
+ * the centroids in chunks of 256); the others the two-piece bf16 selection.
  * vals (optional, f32 [m]): the maximum itself -- the FAST value (within the bound, ~1e-5 of the
  * scale) for points decided by the selection, the exact one for re-checked points: good for an
  * inertia, not for bit comparisons.

@@ -191,3 +191,59 @@ def test_fit_prepared_path_equals_per_kernel_path_on_wide_problems():
     agree = float((out["prepared"][0] == out["kernels"][0]).double().mean())
     assert agree > 0.9995, agree            # (5 iterations amplify last-bit differences of the update)
     assert float((out["prepared"][1] - out["kernels"][1]).abs().max()) < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# tpq_coarse_assign through the cascade (one problem, many centroids, d <= 128)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["gauss", "sift", "offset", "huge", "heavy", "clusters"])
+@pytest.mark.parametrize("d,m,n", [(128, 6000, 1000), (100, 3001, 777), (64, 5000, 4200), (33, 2000, 300),
+                                   (128, 300, 5000), (7, 4097, 257), (128, 70000, 4096)])
+def test_coarse_assign_cascade_labels_are_the_fp32_arg_max(kind, d, m, n, monkeypatch):
+    """the fp16 cascade behind tpq_coarse_assign (forced on for every shape: by default it takes over
+    from 4 096 centroids on): labels == tpq_max_sim == the C oracle, chunked (n > 256) or not"""
+    import torchpq_amd.kernels as K
+    monkeypatch.setenv("TPQ_COARSE_ASSIGN_CASCADE_MIN_N", "1")
+    rng = np.random.default_rng(hash((kind, d, m, n)) % 2 ** 31)
+    x, cent = _data(kind, 1, d, m, min(n, m), rng)
+    if n > m:  # more centroids than points: pad with perturbed copies
+        extra = cent[:, :, rng.integers(0, cent.shape[2], n - m)] * (1 + 1e-3 * rng.standard_normal((1, d, n - m)))
+        cent = np.concatenate([cent, extra.astype(np.float32)], axis=2)
+    A, B = T(x[0]), T(cent[0])
+    op = K.CoarseAssignHip(distance="euclidean")
+    vals, lab = op(A, B, return_vals=True)
+    _, l32 = K.MaxSimHip(distance="euclidean")(A, B, dim=1)
+    assert torch.equal(lab, l32)
+    if m * n * d < 3e9:
+        _, el = c_oracle.max_sim(x, cent, "euclidean", "expanded")
+        assert np.array_equal(N(lab), el[0])
+    assert 0 <= op.last_rechecked() <= m
+
+
+def test_coarse_assign_cascade_ties_and_flags(monkeypatch):
+    """duplicated centroids across chunk boundaries (ties must go to the smaller index), a NaN point and
+    an out-of-range centroid (the problem is flagged: everything re-checked exactly)"""
+    import torchpq_amd.kernels as K
+    monkeypatch.setenv("TPQ_COARSE_ASSIGN_CASCADE_MIN_N", "1")
+    rng = np.random.default_rng(5)
+    d, m, n = 48, 3000, 1024
+    x = rng.integers(-9, 9, (d, m)).astype(np.float32)
+    cent = x[:, :n].copy()
+    cent[:, 512:] = cent[:, :512]                      # chunk 2, 3 repeat chunk 0, 1
+    op = K.CoarseAssignHip(distance="euclidean")
+    lab = op(T(x), T(cent))
+    _, el = c_oracle.max_sim(x[None], cent[None], "euclidean", "expanded")
+    assert np.array_equal(N(lab), el[0]) and N(lab).max() < 512
+    assert op.last_rechecked() == m
+    x2 = (rng.standard_normal((d, m)) * 3).astype(np.float32)
+    c2 = x2[:, :n].copy()
+    x2[3, 17] = np.nan
+    lab = op(T(x2), T(c2))
+    _, l32 = K.MaxSimHip(distance="euclidean")(T(x2), T(c2), dim=1)
+    assert torch.equal(lab, l32) and op.last_rechecked() == m
+    x3 = (rng.standard_normal((d, m)) * 3).astype(np.float32)
+    c3 = x3[:, :n].copy()
+    c3[:, 700] = 1.0e8
+    lab = op(T(x3), T(c3))
+    _, l32 = K.MaxSimHip(distance="euclidean")(T(x3), T(c3), dim=1)
+    assert torch.equal(lab, l32) and op.last_rechecked() == m

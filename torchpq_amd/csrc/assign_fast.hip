@@ -37,6 +37,12 @@
 #include "common.h"
 
 namespace tpq {
+// the three-level fp16 cascade of lloyd.hip for one problem with many centroids (euclidean, d <= 128)
+int lloyd_assign_supported(int d, int64_t m, int n);
+size_t lloyd_assign_workspace_bytes(int d, int64_t m, int n);
+size_t lloyd_assign_count_offset(int d, int64_t m, int n);
+int lloyd_assign(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n, char* ws,
+                 hipStream_t st);
 int launch_max_sim_list(const float* A, const float* B, float* vals, int64_t* inds, int l, int d, int m, int n,
                         int euclid, const int* list, const int* count, unsigned long long* keys, float* Ac, int cap,
                         hipStream_t st);  // kmeans.hip
@@ -886,9 +892,14 @@ extern "C" int tpq_coarse_assign_supported(int d, int64_t m, int n) {
              : 0;
 }
 
+// workspace = [the two-piece bf16 selection's layout][the cascade's layout]: either path may run (the
+// cascade takes euclidean problems, the selection inner products), the diagnostics word stays where it was
+static size_t af_old_total(int d, int64_t m, int n) {
+  return (afast::layout(af_ks(d), TPQ_AF_NP, m, n, d).total + 255) / 256 * 256;
+}
 extern "C" size_t tpq_coarse_assign_workspace_bytes(int d, int64_t m, int n) {
   if (!tpq_coarse_assign_supported(d, m, n)) return 0;
-  return afast::layout(af_ks(d), TPQ_AF_NP, m, n, d).total;
+  return af_old_total(d, m, n) + (m > 0 && lloyd_assign_supported(d, m, n) ? lloyd_assign_workspace_bytes(d, m, n) : 0);
 }
 
 // diagnostics: byte offset, inside the workspace, of the int32 number of points the last call sent
@@ -913,6 +924,15 @@ extern "C" int tpq_coarse_assign(const float* A, const float* B, float* vals, in
   const int euclid = metric == TPQ_METRIC_NEG_SQ_L2 ? 1 : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   char* ws = reinterpret_cast<char*>(workspace);
+  if (euclid && lloyd_assign_supported(d, m, n)) {  // the fp16 cascade (lloyd.hip)
+    char* cws = ws + af_old_total(d, m, n);
+    int rc = lloyd_assign(A, B, vals, inds, d, m, n, cws, st);
+    if (rc) return rc;
+    // diagnostics: the number of exactly re-checked points where tpq_coarse_assign_count_offset points
+    return check_hip(hipMemcpyAsync(ws + afast::layout(af_ks(d), TPQ_AF_NP, m, n).count_off,
+                                    cws + lloyd_assign_count_offset(d, m, n), 4, hipMemcpyDeviceToDevice, st),
+                     "coarse_assign count copy");
+  }
   switch (af_ks(d)) {
     case 2: return afast::run<2, TPQ_AF_NP, TPQ_AF_CT>(A, B, vals, inds, d, (int)m, n, euclid, ws, st);
     case 4: return afast::run<4, TPQ_AF_NP, TPQ_AF_CT>(A, B, vals, inds, d, (int)m, n, euclid, ws, st);

@@ -62,6 +62,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define TPQ_LL_PF 0  // update kernel: tiles ahead of an L2 prefetch by LDS-DMA (0 = none; see the kernel)
 #endif
 constexpr int kWaves = 8;
+constexpr int kMu = 128;  // floats per sub-problem in the centring table (d <= 128)
 #ifndef TPQ_LL_TILES
 #define TPQ_LL_TILES 32
 #endif
@@ -91,7 +92,7 @@ static PrepLayout prep_layout(int l, int d, int64_t m) {
   L.mid_off = (size_t)l * L.T * ((L.KS + 1) / 2) * 2048;
   L.norms_off = 2 * L.mid_off;
   L.mu_off = L.norms_off + (size_t)l * L.T * 32 * 8;       // [l][T * 32] float2
-  L.scale_off = L.mu_off + (size_t)l * 64 * 4;             // [l][64] f32
+  L.scale_off = L.mu_off + (size_t)l * kMu * 4;            // [l][kMu] f32
   L.flag_off = L.scale_off + (size_t)l * 4;                // [l] f32
   L.maxbits_off = L.flag_off + (size_t)l * 4;              // [l] i32
   L.total = (L.maxbits_off + (size_t)l * 4 + 255) / 256 * 256;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void mu_kernel(const float* __restrict__ B, fl
   }
   if (threadIdx.x == 0) {
     const float v = red[0] / (float)n;
-    mu[b * 64 + k] = (v == v && fabsf(v) <= 3.0e38f) ? v : 0.f;  // a non-finite mean: no centring (flagged below)
+    mu[b * kMu + k] = (v == v && fabsf(v) <= 3.0e38f) ? v : 0.f;  // a non-finite mean: no centring (flagged below)
   }
 }
 
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void maxabs_kernel(const float* __restrict__ A
                                                     int64_t m) {
   const int k = blockIdx.y, b = blockIdx.z;
   const float* row = A + ((int64_t)b * d + k) * m;
-  const float mk = mu[b * 64 + k];
+  const float mk = mu[b * kMu + k];
   float mx = 0.f;
   int bad = 0;
   const int64_t per = (m + gridDim.x - 1) / gridDim.x;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ A,
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = 16 * st + 8 * half + j;
-      const float a = (iv && k < d) ? (x[j] - mu[b * 64 + k]) * s : 0.f;
+      const float a = (iv && k < d) ? (x[j] - mu[b * kMu + k]) * s : 0.f;
       const _Float16 hh = (_Float16)a;
       const float r = a - (float)hh;
       h[j] = hh;
@@ -250,12 +251,12 @@ __global__ __launch_bounds__(64) void cprep_kernel(const float* __restrict__ B, 
   const int FPU = 2 * KS + 1;
   const float* Bb = B + (int64_t)b * d * n;
   const float s = scale[b];
-  u32x4* out = frags + ((int64_t)b * 8 + unit) * FPU * 64 + lane;
+  u32x4* out = frags + ((int64_t)b * gridDim.x + unit) * FPU * 64 + lane;  // (gridDim.x = 8 units per chunk of 256)
   float N = 0.f, sraw = 0.f;
   if (c < n)
     for (int k = 0; k < d; ++k) {
       const float y = Bb[(int64_t)k * n + c];
-      const float cc = (y - mu[b * 64 + k]) * s;
+      const float cc = (y - mu[b * kMu + k]) * s;
       N = fmaf(cc, cc, N);
       sraw = fmaf(y, y, sraw);
     }
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(64) void cprep_kernel(const float* __restrict__ B, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = 16 * st + 8 * half + j;
-      const float C = (k < d && c < n) ? 2.f * ((Bb[(int64_t)k * n + c] - mu[b * 64 + k]) * s) : 0.f;
+      const float C = (k < d && c < n) ? 2.f * ((Bb[(int64_t)k * n + c] - mu[b * kMu + k]) * s) : 0.f;
       bad |= !(fabsf(C) <= 65000.f);  // beyond fp16's range (or NaN): the whole sub-problem goes exact
       const _Float16 hh = (_Float16)C;
       const float r = C - (float)hh;
@@ -415,6 +416,12 @@ struct StepArgs {
   int m;
   int64_t T;
   float eps, eps_exact, eta;   // eps: this level's fast-path bound, relative to (|a'| + |c'|max)^2; eta times sqrt(d)
+  // more than 256 centroids (tpq_coarse_assign): blockIdx.y = CHUNK of 256 centroids (all chunks in one
+  // launch: one chunk's blocks alone fill half the chip); a chunk's (best, second) and in-chunk index of
+  // every point go to part_*[chunk][point or list position], decide_kernel folds the chunks and decides
+  float2* part_b;              // [chunks][m]  (nullptr: a single chunk, decided in the kernel)
+  uint8_t* part_i;             // [chunks][m]
+  int chunk_frag_stride;       // 16-byte units between the fragment blocks of consecutive chunks
 };
 
 // label, value and -- unless the two best fast values are more than 2 delta apart -- a list entry.
@@ -422,15 +429,23 @@ struct StepArgs {
 // once per block (flush_list): a RETURNING global atomic per tile put a memory round trip -- and,
 // vmcnt being in order, the wait for every load issued before it -- into each tile of level 1,
 // where 92 % of the tiles hold an undecided point (19 ms instead of 2).
-constexpr int kBlockPoints = kWaves * kTiles * 32;  // points a block decides = capacity of its staged list
-struct BlockList {
+template <int CAP>
+struct BlockListT {
   int n;
   int base;
-  int item[kBlockPoints];
+  int item[CAP];
 };
-__device__ __forceinline__ void emit(const StepArgs& a, BlockList* bl, int b, int lane, bool valid, int64_t fi, int idx,
-                                     float B1, float B2, float2 n2, float s, float cn, float cnr, float inv_s2,
-                                     bool exact_all) {
+template <int CAP>
+__device__ __forceinline__ void emit(const StepArgs& a, BlockListT<CAP>* bl, int b, int lane, bool valid, int64_t fi,
+                                     int idx, float B1, float B2, float2 n2, float s, float cn, float cnr,
+                                     float inv_s2, bool exact_all, int64_t part_slot = -1) {
+  if (a.part_b != nullptr) {  // chunked: this chunk's result of the point; decide_kernel does the rest
+    if (valid) {
+      a.part_b[part_slot] = make_float2(B1, B2);
+      a.part_i[part_slot] = (uint8_t)idx;
+    }
+    return;
+  }
   // (v_sqrt_f32: 1 ulp; the norms only scale the bound, whose 1.25 covers it)
   const float an = __builtin_amdgcn_sqrtf(n2.x), anr = __builtin_amdgcn_sqrtf(n2.y) * s;
   const float t1 = an + cn, t2 = anr + cnr * s;
@@ -451,7 +466,8 @@ __device__ __forceinline__ void emit(const StepArgs& a, BlockList* bl, int b, in
   }
 }
 // end of the block: reserve [base, base + n) of the sub-problem's list with one global atomic, copy
-__device__ __forceinline__ void flush_list(const StepArgs& a, BlockList* bl, int b) {
+template <int CAP>
+__device__ __forceinline__ void flush_list(const StepArgs& a, BlockListT<CAP>* bl, int b) {
   __syncthreads();
   if (threadIdx.x == 0) bl->base = bl->n ? atomicAdd(a.count + b, bl->n) : 0;
   __syncthreads();
@@ -466,20 +482,25 @@ __device__ __forceinline__ void flush_list(const StepArgs& a, BlockList* bl, int
 // MFMA waits for the one before it.  LDS holds -N and the hi pieces of the centroids only (40 KiB).
 constexpr int kWide = kTiles / 2;  // wide tiles per wave and block
 
-// EXP (knock-outs, TPQ_LL_EXP; results are then wrong): 1 = no top-2 updates, 2 = no MFMAs, 4 = no piece loads
-template <int KS, int EXP = 0>
+constexpr int kCoarseList = kWaves * kWide * 64;  // points a level-1 block decides = capacity of its staged list
+
+template <int KS>
 __global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
   constexpr int FPU = 2 * KS + 1;  // fragments per unit in global memory
   constexpr int FL = KS + 1;       // ... in LDS
+  constexpr int Q = (KS + 1) / 2;
+  typedef BlockListT<kCoarseList> BL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = blockIdx.y;
+  const bool chunked = a.part_b != nullptr;
+  const int b = chunked ? 0 : blockIdx.y, chunk = chunked ? blockIdx.y : 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l31 = lane & 31, half = lane >> 5;
   const int m = a.m;
-  BlockList* bl = reinterpret_cast<BlockList*>(smem + 8 * FL * 1024);
+  BL* bl = reinterpret_cast<BL*>(smem + 8 * FL * 1024);
   if (threadIdx.x == 0) bl->n = 0;
   {
-    const char* src = reinterpret_cast<const char*>(a.frags) + (size_t)b * 8 * FPU * 1024;
+    const char* src = reinterpret_cast<const char*>(a.frags) + (size_t)b * 8 * FPU * 1024 +
+                      (size_t)chunk * a.chunk_frag_stride * 16;
     for (int f = wave; f < 8 * FL; f += kWaves) {
       const int unit = f / FL, j = f % FL;
       const int sf = unit * FPU + (j ? 2 * j - 1 : 0);  // -N, then the hi piece of k-step j - 1
@@ -487,7 +508,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
                                        (__attribute__((address_space(3))) void*)(smem + f * 1024), 16, 0, 0);
     }
   }
-  constexpr int Q = (KS + 1) / 2;
   const int64_t slice = a.T * Q * 2048;
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char*>(reinterpret_cast<const char*>(a.hi) + (size_t)b * slice), 0, (int)slice, 0x00020000);
@@ -519,21 +539,23 @@ __global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
   const u32x4* fp = reinterpret_cast<const u32x4*>(smem) + lane;
   auto ldsf = [&](const u32x4* p) -> f16x8 { return __builtin_bit_cast(f16x8, *p); };
 
-  // ONE accumulator per column tile, the two tiles half a unit out of phase: while the KS + 1 MFMAs of
-  // tile 0 run, the 16 values tile 1 finished half a unit ago go through the top-2 update, and vice
-  // versa.  (Both tiles in phase -- all MFMAs of a unit, then all of its updates -- leaves the two
-  // waves of a SIMD in lockstep: their MFMA phases queue on the matrix pipe, then their update phases
-  // on the VALU port, 680 cycles per unit instead of ~360.  Two accumulator SETS, updating unit U - 1
-  // between the MFMAs of unit U, take 64 more registers: 256 VGPRs + 53 spilled around the per-tile
-  // epilogue, and a scratch reload waits, vmcnt being in order, for the piece loads issued before it.)
+  // ONE accumulator per column tile.  A unit = its 2 (KS + 1) MFMAs -- the two tiles in turn on every A
+  // operand, so no MFMA waits for the one before it and the centroid fragments cross the LDS port once
+  // per TWO MFMAs -- then the top-2 update of its 2 x 16 values; the SIMD's other wave has its MFMAs
+  // meanwhile.  The A operands run through a three-slot ring two k-steps ahead (all KS of a unit in
+  // registers: 32 of them at d = 128).  Tried on the way (C5, all within 3 % of each other: the kernel is
+  // bound by the VALU work of the update, not by its schedule): the two tiles half a unit out of phase
+  // (updates of one between the MFMAs of the other); four waves per SIMD without register prefetch;
+  // two accumulator SETS (updating unit U - 1 between the MFMAs of unit U): 256 VGPRs + 53 spilled
+  // around the per-tile epilogue -- and a scratch reload waits, vmcnt being in order, for the piece
+  // loads issued before it.
   f32x16 acc[2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[1][r] = -3.0e38f;
   float b1[2] = {-INFINITY, -INFINITY}, b2[2] = {-INFINITY, -INFINITY};
   float b1h[2] = {-INFINITY, -INFINITY};  // the best after units 0..3
-  f16x8 c1k[KS];
-#pragma unroll
-  for (int st = 0; st < KS; ++st) c1k[st] = ldsf(fp + (1 + st) * 64);
+  // A operands: k-steps 0 and 1 of a unit in a0 / a1 -- re-loaded for the NEXT unit as soon as this unit's
+  // MFMAs have taken them --, k-steps >= 2 through a three-slot ring two k-steps ahead
+  f16x8 a0 = ldsf(fp + 1 * 64), a1 = a0, aring[3];
+  if constexpr (KS > 1) a1 = ldsf(fp + 2 * 64);
   bf16x8 bones = {0, 0, 0, 0, 0, 0, 0, 0};
   if (half == 0) {
     bones[0] = (__bf16)1.0f;
@@ -557,76 +579,51 @@ __global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
     const float B2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
     if (o1 > m1 || (o1 == m1 && oi < idx)) idx = oi;
     const int64_t fi = tile * 32 + l31;
-    emit(a, bl, b, lane, half == 0 && fi < m, fi, idx, B1, B2, n2, s, cn, cnr, inv_s2, exact_all);
-  };
-  // the top-2 update of register pairs [P0, P1) of column tile CT, values of unit UT
-  auto update = [&](auto ct_c, auto ut_c, auto p0_c, auto p1_c) {
-    constexpr int CT = decltype(ct_c)::value, UT = decltype(ut_c)::value;
-    if constexpr (!(EXP & 1)) static_for<decltype(p0_c)::value, decltype(p1_c)::value>([&](auto q_c) {
-      constexpr int q = decltype(q_c)::value;
-      top2_keys_pair(b1[CT], b2[CT], key6<2 * q + 16 * (UT & 3)>(acc[CT][2 * q]),
-                     key6<2 * q + 1 + 16 * (UT & 3)>(acc[CT][2 * q + 1]));
-    });
-    __builtin_amdgcn_sched_barrier(0);
+    emit(a, bl, b, lane, half == 0 && fi < m, fi, idx, B1, B2, n2, s, cn, cnr, inv_s2, exact_all,
+         (int64_t)chunk * m + fi);
   };
   using std::integral_constant;
-  bool have_prev = false;
-  int64_t wt_prev = 0;
-  float2 n2prev1 = make_float2(0.f, 0.f);
 
   auto unit = [&](auto u_c, int voff_next, const f16x8 (&xs)[2][KS], f16x8 (&xsn)[2][KS]) {
-    constexpr int U = decltype(u_c)::value, PU = (U + 7) & 7;
+    constexpr int U = decltype(u_c)::value;
     const u32x4* up = fp + U * FL * 64;
     const u32x4* upn = fp + ((U + 1) & 7) * FL * 64;  // the next unit (unit 0 of the next tile after 7)
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bf16x8 cfrag = __builtin_bit_cast(bf16x8, up[0]);
-    if constexpr (U < 4 && !(EXP & 4)) {  // the next wide tile's hi pieces: 2 KS 16-byte loads over units 0..3
+    if constexpr (U < 4) {  // the next wide tile's hi pieces: 2 KS 16-byte loads over units 0..3
       constexpr int l0 = (U * 2 * KS) / 4, l1 = ((U + 1) * 2 * KS) / 4;
       static_for<l0, l1>([&](auto e_c) { load_frag(voff_next, e_c, xsn); });
     }
-    if constexpr (U == 4) b1h[0] = b1[0];
-    if constexpr (U == 5) b1h[1] = b1[1];  // (tile 1's values of unit 4 are taken during unit 5)
-    // first half: MFMAs of column tile 0; update with tile 1's values of the previous unit
-    static_for<0, KS + 1>([&](auto g_c) {
-      constexpr int g = decltype(g_c)::value;
-      if constexpr (EXP & 2) {
-        acc[0][g] += (float)c1k[g % KS][0] + (float)xs[0][g % KS][1] + (float)cfrag[0];
-      } else if constexpr (g < KS) {
-        if constexpr (g == 0) {
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[0], xs[0][0], zero, 0, 0, 0);
-        } else {
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[g], xs[0][g], acc[0], 0, 0, 0);
-        }
-      } else {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, acc[0], 0, 0, 0);
-      }
-      update(integral_constant<int, 1>{}, integral_constant<int, PU>{}, integral_constant<int, (g * 8) / (KS + 1)>{},
-             integral_constant<int, ((g + 1) * 8) / (KS + 1)>{});
-    });
-    if constexpr (U == 0) {  // tile 1 of the PREVIOUS wide tile is complete now
-      if (have_prev) finish(1, 2 * wt_prev + 1, n2prev1);
-      b1[1] = b2[1] = -INFINITY;
+    if constexpr (U == 4) {
+      b1h[0] = b1[0];
+      b1h[1] = b1[1];
     }
-    // second half: MFMAs of column tile 1 (then the A operand is free: fetch the next unit's); update
-    // with tile 0's values of this unit
-    static_for<0, KS + 1>([&](auto g_c) {
-      constexpr int g = decltype(g_c)::value;
-      if constexpr (EXP & 2) {
-        acc[1][g] += (float)c1k[g % KS][0] + (float)xs[1][g % KS][1] + (float)cfrag[0];
-        if constexpr (g < KS) c1k[g] = ldsf(upn + (1 + g) * 64);
-      } else if constexpr (g < KS) {
-        if constexpr (g == 0) {
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[0], xs[1][0], zero, 0, 0, 0);
-        } else {
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[g], xs[1][g], acc[1], 0, 0, 0);
-        }
-        c1k[g] = ldsf(upn + (1 + g) * 64);
+    static_for<0, KS>([&](auto s_c) {
+      constexpr int st = decltype(s_c)::value;
+      if constexpr (st + 2 < KS) aring[(st + 2) % 3] = ldsf(up + (1 + st + 2) * 64);
+      if constexpr (st == 0) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xs[0][0], zero, 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xs[1][0], zero, 0, 0, 0);
+        a0 = ldsf(upn + 1 * 64);
+      } else if constexpr (st == 1) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xs[0][1], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xs[1][1], acc[1], 0, 0, 0);
+        a1 = ldsf(upn + 2 * 64);
       } else {
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[st % 3], xs[0][st], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[st % 3], xs[1][st], acc[1], 0, 0, 0);
       }
-      update(integral_constant<int, 0>{}, integral_constant<int, U>{}, integral_constant<int, (g * 8) / (KS + 1)>{},
-             integral_constant<int, ((g + 1) * 8) / (KS + 1)>{});
+      __builtin_amdgcn_sched_barrier(0);
     });
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, acc[1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, 16>([&](auto q_c) {  // 16 register pairs, the two column tiles in turn
+      constexpr int q = decltype(q_c)::value, ct = q & 1, pq = q >> 1;
+      top2_keys_pair(b1[ct], b2[ct], key6<2 * pq + 16 * (U & 3)>(acc[ct][2 * pq]),
+                     key6<2 * pq + 1 + 16 * (U & 3)>(acc[ct][2 * pq + 1]));
+    });
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   auto tile = [&](int t, auto cb_c) {
@@ -634,12 +631,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
     const int voff_next = frag_voff(t + 1);
     n2b[NX][0] = load_norm(t + 1, 0);
     n2b[NX][1] = load_norm(t + 1, 1);
-    b1[0] = b2[0] = -INFINITY;
+    b1[0] = b1[1] = b2[0] = b2[1] = -INFINITY;
     static_for<0, 8>([&](auto u_c) { unit(u_c, voff_next, xsb[CB], xsb[NX]); });
-    wt_prev = wide_of(t);
-    finish(0, 2 * wt_prev, n2b[CB][0]);
-    n2prev1 = n2b[CB][1];
-    have_prev = true;
+    const int64_t wt = wide_of(t);
+    finish(0, 2 * wt, n2b[CB][0]);
+    finish(1, 2 * wt + 1, n2b[CB][1]);
   };
 #pragma unroll 1
   for (int t = 0; t < kWide; t += 2) {
@@ -648,12 +644,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
     if (t + 1 >= kWide || 2 * ((int64_t)blockIdx.x * kWide + t + 1) * kWaves >= a.T) break;
     tile(t + 1, integral_constant<int, 1>{});
   }
-  if (have_prev) {  // tile 1's values of the last unit
-    update(integral_constant<int, 1>{}, integral_constant<int, 7>{}, integral_constant<int, 0>{},
-           integral_constant<int, 8>{});
-    finish(1, 2 * wt_prev + 1, n2prev1);
-  }
-  flush_list(a, bl, b);
+  if (!chunked) flush_list(a, bl, b);
 }
 
 // ---- level 2 -----------------------------------------------------------------------------------------
@@ -663,22 +654,28 @@ __global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
 // list leave at once.
 constexpr int kTilesR = 8;  // 32-point tiles per wave and block: 2048 listed points per block (many small blocks:
                             // the list is a few percent of the points and its length is only known on the device)
+constexpr int kRefineList = kTilesR * kWaves * 32;  // points a level-2 block decides
 template <int KS>
 __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
   constexpr int FPU = 2 * KS + 1;
   constexpr int NM = 3 * KS + 1;  // MFMAs per unit
+  constexpr bool PF = KS <= 4;    // the next tile's pieces prefetched into a second register set (d <= 64);
+                                  // beyond, that set does not fit: the pieces are loaded when the tile is done
+  typedef BlockListT<kRefineList> BL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = blockIdx.y;
+  const bool chunked = a.part_b != nullptr;
+  const int b = chunked ? 0 : blockIdx.y, chunk = chunked ? blockIdx.y : 0;
   const int m = a.m;
   int cnt = a.count_in[b];
   cnt = cnt < m ? cnt : m;
   if ((int64_t)blockIdx.x * kTilesR * kWaves * 32 >= cnt) return;  // block-uniform
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int l31 = lane & 31, half = lane >> 5;
-  BlockList* bl = reinterpret_cast<BlockList*>(smem + 8 * FPU * 1024);
+  BL* bl = reinterpret_cast<BL*>(smem + 8 * FPU * 1024);
   if (threadIdx.x == 0) bl->n = 0;
   {
-    const char* src = reinterpret_cast<const char*>(a.frags) + (size_t)b * 8 * FPU * 1024;
+    const char* src = reinterpret_cast<const char*>(a.frags) + (size_t)b * 8 * FPU * 1024 +
+                      (size_t)chunk * a.chunk_frag_stride * 16;
     for (int f = wave; f < 8 * FPU; f += kWaves)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 1024 + lane * 16),
                                        (__attribute__((address_space(3))) void*)(smem + f * 1024), 16, 0, 0);
@@ -692,14 +689,15 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
   const float2* __restrict__ nrm = a.norms + (int64_t)b * a.T * 32;
   const int* __restrict__ lst = a.list_in + (int64_t)b * m;
   // tile t of this wave = positions [32 tile, 32 tile + 32) of the list
+  auto pos_of = [&](int t) -> int64_t { return (((int64_t)blockIdx.x * kTilesR + t) * kWaves + wave) * 32 + l31; };
   auto point_of = [&](int t) -> int {
-    const int64_t pos = (((int64_t)blockIdx.x * kTilesR + t) * kWaves + wave) * 32 + l31;
+    const int64_t pos = pos_of(t);
     return (t < kTilesR && pos < cnt) ? lst[pos] : -1;
   };
   auto voff_of = [&](int p) -> int {
     return p >= 0 ? (p >> 5) * (Q * 2048) + (p & 31) * 64 + half * 16 : 0x7ffffff0;
   };
-  f16x8 xs[KS][2], xsn[KS][2];
+  f16x8 xs[KS][2], xsn[PF ? KS : 1][2];
   auto load_frag = [&](int voff, auto e_c, f16x8 (&dst)[KS][2]) {
     constexpr int e = decltype(e_c)::value, st = e >> 1;
     dst[st][e & 1] = __builtin_bit_cast(
@@ -739,7 +737,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
   const bool exact_all = (a.flag[b] | a.cflag[b]) != 0;
   const float inv_s2 = (1.f / s) * (1.f / s);
 
-  auto finish_tile = [&](int p, float2 n2) {
+  auto finish_tile = [&](int p, float2 n2, int64_t pos) {
     const int r0 = __float_as_int(b1[0]) & 15, r1 = __float_as_int(b1[1]) & 15;
     const int ia = bu[0] * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * half;
     const int ib = bu[1] * 32 + (r1 & 3) + 8 * (r1 >> 2) + 4 * half;
@@ -752,11 +750,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
     const float B1 = fmaxf(m1, o1);
     const float B2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
     if (o1 > m1 || (o1 == m1 && oi < idx)) idx = oi;
-    emit(a, bl, b, lane, half == 0 && p >= 0, p, idx, B1, B2, n2, s, cn, cnr, inv_s2, exact_all);
+    emit(a, bl, b, lane, half == 0 && p >= 0, p, idx, B1, B2, n2, s, cn, cnr, inv_s2, exact_all,
+         (int64_t)chunk * m + pos);
   };
 
   auto unit = [&](auto u_c, f32x16& acc, const f32x16& fin, int voff_next, const f16x8 (&xs)[KS][2],
-                  f16x8 (&xsn)[KS][2]) {
+                  f16x8 (&xsn)[PF ? KS : 1][2]) {
     constexpr int U = decltype(u_c)::value, FU = (U + 7) & 7;
     const u32x4* up = fp + U * FPU * 64;
     const u32x4* upn = fp + ((U + 1) & 7) * FPU * 64;  // the next unit (unit 0 of the next tile after 7)
@@ -773,9 +772,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
             take_keys_pair<2 * q>(b1[q & 1], b2[q & 1], fin[2 * q], fin[2 * q + 1]);
         });
       }
-      if constexpr (U < 4 && mi == 0) {  // the next tile's pieces: 2 KS gathered 16-byte loads over units 0..3
+      if constexpr (U < 4 && mi == 0 && PF) {  // the next tile's pieces: 2 KS gathered 16-byte loads over units 0..3
         constexpr int l0 = (U * 2 * KS) / 4, l1 = ((U + 1) * 2 * KS) / 4;
-        static_for<l0, l1>([&](auto e_c) { load_frag(voff_next, e_c, xsn); });
+        static_for<l0, l1>([&](auto e_c) {
+          constexpr int e = decltype(e_c)::value, st = e >> 1;
+          xsn[st][e & 1] = __builtin_bit_cast(
+              f16x8, __builtin_amdgcn_raw_buffer_load_b128((e & 1) ? rs_mid : rs_hi, voff_next,
+                                                           (st >> 1) * 2048 + (st & 1) * 32, 0));
+        });
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -811,12 +815,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
   using std::integral_constant;
 
   bool have_prev = false;
-  auto tile = [&](int t, const f16x8 (&cur)[KS][2], f16x8 (&nxt)[KS][2]) {
+  int t_last = 0;
+  auto tile = [&](int t, f16x8 (&cur)[KS][2], f16x8 (&nxt)[PF ? KS : 1][2]) {
     const int voff_next = voff_of(p_nxt);
     n2nxt = load_norm(p_nxt);
     p_nx2 = point_of(t + 2);
     unit(integral_constant<int, 0>{}, accA, accB, voff_next, cur, nxt);
-    if (have_prev) finish_tile(p_prev, n2prev);
+    if (have_prev) finish_tile(p_prev, n2prev, pos_of(t - 1));
     b1[0] = b1[1] = b2[0] = b2[1] = -INFINITY;
     bu[0] = bu[1] = 0;
     unit(integral_constant<int, 1>{}, accB, accA, voff_next, cur, nxt);
@@ -826,19 +831,25 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
     unit(integral_constant<int, 5>{}, accB, accA, voff_next, cur, nxt);
     unit(integral_constant<int, 6>{}, accA, accB, voff_next, cur, nxt);
     unit(integral_constant<int, 7>{}, accB, accA, voff_next, cur, nxt);
+    if constexpr (!PF) static_for<0, 2 * KS>([&](auto e_c) { load_frag(voff_next, e_c, cur); });
     p_prev = p_cur;
     p_cur = p_nxt;
     p_nxt = p_nx2;
     n2prev = n2cur;
     n2cur = n2nxt;
     have_prev = true;
+    t_last = t;
   };
 #pragma unroll 1
   for (int t = 0; t < kTilesR; t += 2) {
     if (((int64_t)blockIdx.x * kTilesR + t) * kWaves * 32 >= cnt) break;
     tile(t, xs, xsn);
     if (t + 1 >= kTilesR || ((int64_t)blockIdx.x * kTilesR + t + 1) * kWaves * 32 >= cnt) break;
-    tile(t + 1, xsn, xs);
+    if constexpr (PF) {
+      tile(t + 1, xsn, xs);
+    } else {
+      tile(t + 1, xs, xsn);
+    }
   }
   if (have_prev) {  // the last unit of the last tile
     const float before0 = b1[0], before1 = b1[1];
@@ -852,9 +863,234 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
     }
     bu[0] = b1[0] > before0 ? 7 : bu[0];
     bu[1] = b1[1] > before1 ? 7 : bu[1];
-    finish_tile(p_prev, n2prev);
+    finish_tile(p_prev, n2prev, pos_of(t_last));
   }
-  flush_list(a, bl, b);
+  if (!chunked) flush_list(a, bl, b);
+}
+
+// ---- level 2, many centroids --------------------------------------------------------------------------
+// The loop order of assign_fast.hip: a wave keeps ITS 32 listed points (hi and mid pieces, gathered once)
+// in registers for the whole sweep and ALL centroid chunks stream through a double-buffered LDS ring
+// (half a chunk = 4 units = 128 centroids per buffer, LDS-DMA, one barrier per half chunk); the running
+// top-2 never leaves the registers.  (refine_kernel per chunk re-gathers the points for every chunk and
+// leaves each wave waiting for its gathers: 2.25 ms for 8 % of 1 M points x 16 384 centroids.)
+constexpr int kStreamList = kWaves * 32;
+
+template <int KS>
+__global__ __launch_bounds__(kWaves * 64, 2) void refine_stream_kernel(StepArgs a, int n_half) {
+  constexpr int FPU = 2 * KS + 1;
+  constexpr int NM = 3 * KS + 1;  // MFMAs per unit
+  constexpr int HB = 4 * FPU * 1024;  // bytes of a half chunk of fragments
+  constexpr int Q = (KS + 1) / 2;
+  typedef BlockListT<kStreamList> BL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int m = a.m;
+  int cnt = a.count_in[0];
+  cnt = cnt < m ? cnt : m;
+  if ((int64_t)blockIdx.x * kWaves * 32 >= cnt) return;  // block-uniform
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l31 = lane & 31, half = lane >> 5;
+  BL* bl = reinterpret_cast<BL*>(smem + 2 * HB);
+  if (threadIdx.x == 0) bl->n = 0;
+  auto stage = [&](int h) {  // half chunk h -> buffer h & 1 (the fragment blocks of the chunks are contiguous)
+    const char* src = reinterpret_cast<const char*>(a.frags) + (size_t)h * HB;
+    char* dst = smem + (h & 1) * HB;
+    for (int f = wave; f < 4 * FPU; f += kWaves)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + f * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+  };
+  stage(0);
+  const int64_t slice = a.T * Q * 2048;
+  const __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(a.hi)), 0, (int)slice, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_mid = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(a.mid)), 0, (int)slice, 0x00020000);
+  const int64_t pos = ((int64_t)blockIdx.x * kWaves + wave) * 32 + l31;
+  const int p = pos < cnt ? a.list_in[pos] : -1;
+  const float2 n2 = a.norms[p >= 0 ? p : 0];
+  f16x8 xs[KS][2];
+  {
+    const int voff = p >= 0 ? (p >> 5) * (Q * 2048) + (p & 31) * 64 + half * 16 : 0x7ffffff0;
+    static_for<0, 2 * KS>([&](auto e_c) {
+      constexpr int e = decltype(e_c)::value, st = e >> 1;
+      xs[st][e & 1] = __builtin_bit_cast(
+          f16x8, __builtin_amdgcn_raw_buffer_load_b128((e & 1) ? rs_mid : rs_hi, voff, (st >> 1) * 2048 + (st & 1) * 32, 0));
+    });
+  }
+  auto ldsf = [&](const u32x4* q) -> f16x8 { return __builtin_bit_cast(f16x8, *q); };
+  f32x16 accA, accB;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accB[r] = -3.0e38f;
+  float b1[2] = {-INFINITY, -INFINITY}, b2[2] = {-INFINITY, -INFINITY};
+  int bu[2] = {0, 0};
+  f16x8 c1k[KS], c2r[3];
+  bf16x8 bones = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (half == 0) {
+    bones[0] = (__bf16)1.0f;
+    bones[1] = (__bf16)1.0f;
+    bones[2] = (__bf16)1.0f;
+  }
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // unit U of the half chunk in `base`; the values of the unit before it (`fin`, global unit number gprev)
+  // go through the top-2 update between the MFMAs
+  auto unit = [&](auto u_c, const u32x4* base, f32x16& acc, const f32x16& fin, int gprev) {
+    constexpr int U = decltype(u_c)::value;
+    const u32x4* up = base + U * FPU * 64;
+    const float before0 = b1[0], before1 = b1[1];
+    const bf16x8 cfrag = __builtin_bit_cast(bf16x8, up[0]);
+    if constexpr (U == 0) {  // the buffer is only known to have landed after the barrier: cold start
+      c1k[0] = ldsf(up + 1 * 64);
+      c2r[0] = ldsf(up + 2 * 64);
+      if constexpr (KS > 1) {
+        c1k[1] = ldsf(up + 3 * 64);
+        c2r[1] = ldsf(up + 4 * 64);
+      }
+    }
+    auto fill = [&](auto mi_c) {
+      constexpr int mi = decltype(mi_c)::value;
+      if constexpr (mi >= 2) {  // 8 register pairs of the previous unit's values over gaps 2 .. NM - 1
+        constexpr int lo = ((mi - 2) * 16) / (NM - 2), hi = ((mi - 1) * 16) / (NM - 2);
+        static_for<0, 8>([&](auto q_c) {
+          constexpr int q = decltype(q_c)::value;
+          if constexpr (2 * q + 1 >= lo && 2 * q + 1 < hi)
+            take_keys_pair<2 * q>(b1[q & 1], b2[q & 1], fin[2 * q], fin[2 * q + 1]);
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // small products first: corrections (C2 a1, C1 a2), main (C1 a1), then -N
+    static_for<0, KS>([&](auto s_c) {
+      constexpr int st = decltype(s_c)::value;
+      if constexpr (st + 2 < KS) {
+        c1k[st + 2] = ldsf(up + (1 + (st + 2) * 2) * 64);
+        c2r[(st + 2) % 3] = ldsf(up + (2 + (st + 2) * 2) * 64);
+      }
+      if constexpr (st == 0) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c2r[0], xs[0][0], zero, 0, 0, 0);
+      } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c2r[st % 3], xs[st][0], acc, 0, 0, 0);
+      }
+      fill(std::integral_constant<int, 2 * st>{});
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[st], xs[st][1], acc, 0, 0, 0);
+      fill(std::integral_constant<int, 2 * st + 1>{});
+    });
+    if constexpr (U < 3) {  // the next unit of the same buffer
+      const u32x4* upn = up + FPU * 64;
+      c2r[0] = ldsf(upn + 2 * 64);
+      if constexpr (KS > 1) c2r[1] = ldsf(upn + (2 + 2) * 64);
+    }
+    static_for<0, KS>([&](auto s_c) {
+      constexpr int st = decltype(s_c)::value;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c1k[st], xs[st][0], acc, 0, 0, 0);
+      if constexpr (st < 2 && U < 3) c1k[st] = ldsf(up + FPU * 64 + (1 + st * 2) * 64);
+      fill(std::integral_constant<int, 2 * KS + st>{});
+    });
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, acc, 0, 0, 0);
+    fill(std::integral_constant<int, 3 * KS>{});
+    bu[0] = b1[0] > before0 ? gprev : bu[0];
+    bu[1] = b1[1] > before1 ? gprev : bu[1];
+  };
+  using std::integral_constant;
+#pragma unroll 1
+  for (int h = 0; h < n_half; ++h) {
+    __syncthreads();  // half chunk h has landed (vmcnt(0) + barrier); everyone is done with the other buffer
+    if (h + 1 < n_half) stage(h + 1);
+    const u32x4* base = reinterpret_cast<const u32x4*>(smem + (h & 1) * HB) + lane;
+    const int g = 4 * h;
+    unit(integral_constant<int, 0>{}, base, accA, accB, g - 1);
+    if (h == 0) {  // (the values processed under the very first unit were the -3e38 fill)
+      b1[0] = b1[1] = b2[0] = b2[1] = -INFINITY;
+      bu[0] = bu[1] = 0;
+    }
+    unit(integral_constant<int, 1>{}, base, accB, accA, g);
+    unit(integral_constant<int, 2>{}, base, accA, accB, g + 1);
+    unit(integral_constant<int, 3>{}, base, accB, accA, g + 2);
+  }
+  {  // the last unit's values
+    const int glast = 4 * n_half - 1;
+    const float before0 = b1[0], before1 = b1[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = (r >> 1) & 1;
+      const float v = __int_as_float((__float_as_int(accB[r]) & ~15) | r);
+      const float t = fminf(v, b1[c]);
+      b1[c] = fmaxf(v, b1[c]);
+      b2[c] = fmaxf(b2[c], t);
+    }
+    bu[0] = b1[0] > before0 ? glast : bu[0];
+    bu[1] = b1[1] > before1 ? glast : bu[1];
+  }
+  const float s = a.scale[0];
+  const float cn = sqrtf(__uint_as_float(a.cmax2_bits[0])), cnr = sqrtf(__uint_as_float(a.cmax2_bits[1]));
+  const bool exact_all = (a.flag[0] | a.cflag[0]) != 0;
+  const float inv_s2 = (1.f / s) * (1.f / s);
+  {
+    const int r0 = __float_as_int(b1[0]) & 15, r1 = __float_as_int(b1[1]) & 15;
+    const int ia = bu[0] * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * half;
+    const int ib = bu[1] * 32 + (r1 & 3) + 8 * (r1 >> 2) + 4 * half;
+    const bool tb = b1[1] > b1[0] || (b1[1] == b1[0] && ib < ia);
+    int idx = tb ? ib : ia;
+    const float m1 = fmaxf(b1[0], b1[1]);
+    const float m2 = fmaxf(fminf(b1[0], b1[1]), fmaxf(b2[0], b2[1]));
+    const float o1 = __shfl_xor(m1, 32, 64), o2 = __shfl_xor(m2, 32, 64);
+    const int oi = __shfl_xor(idx, 32, 64);
+    const float B1 = fmaxf(m1, o1);
+    const float B2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
+    if (o1 > m1 || (o1 == m1 && oi < idx)) idx = oi;
+    emit(a, bl, 0, lane, half == 0 && p >= 0, p, idx, B1, B2, n2, s, cn, cnr, inv_s2, exact_all);
+  }
+  flush_list(a, bl, 0);
+}
+
+// ---- chunked runs: fold the chunks and decide -----------------------------------------------------------
+// One thread per point (level 1) or per list position (level 2): the chunks' (best, second, in-chunk
+// index) in chunk order -- on a tie the earlier chunk, the smaller index, stays, and the tie itself makes
+// second == best: the point is listed --, then the decision of emit().  grid (ceil(m / 256))
+template <int LEVEL>
+__global__ __launch_bounds__(256) void decide_kernel(StepArgs a, int n_chunks) {
+  const int m = a.m;
+  const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int cnt = m;
+  if (LEVEL == 2) {
+    cnt = a.count_in[0];
+    cnt = cnt < m ? cnt : m;
+    if ((int64_t)blockIdx.x * 256 >= cnt) return;  // block-uniform
+  }
+  const bool valid = pos < cnt;
+  const int p = valid ? (LEVEL == 1 ? (int)pos : a.list_in[pos]) : 0;
+  float B1 = -INFINITY, B2 = -INFINITY;
+  int idx = 0;
+  if (valid)
+    for (int c = 0; c < n_chunks; ++c) {
+      const float2 v = a.part_b[(int64_t)c * m + pos];
+      const int i = a.part_i[(int64_t)c * m + pos];
+      const float n2 = fmaxf(fminf(B1, v.x), fmaxf(B2, v.y));
+      idx = v.x > B1 ? c * 256 + i : idx;
+      B1 = fmaxf(B1, v.x);
+      B2 = n2;
+    }
+  const float s = a.scale[0];
+  const float cn = sqrtf(__uint_as_float(a.cmax2_bits[0])), cnr = sqrtf(__uint_as_float(a.cmax2_bits[1]));
+  const float2 n2 = a.norms[p];
+  const float an = sqrtf(n2.x), anr = sqrtf(n2.y) * s;
+  const float t1 = an + cn, t2 = anr + cnr * s;
+  float delta = 1.25f * (a.eps * t1 * t1 + a.eta * (2.f * cn + an) + a.eps_exact * t2 * t2);
+  if ((a.flag[0] | a.cflag[0]) != 0) delta = INFINITY;
+  if (valid) {
+    a.inds[p] = idx;
+    if (a.vals) a.vals[p] = (B1 - n2.x) * ((1.f / s) * (1.f / s));
+  }
+  const bool listed = valid && !(B1 - B2 > 2.f * delta);
+  const unsigned long long mk = __ballot(listed);
+  if (mk) {
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mk) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(a.count, __popcll(mk));
+    base = __shfl(base, leader, 64);
+    if (listed) a.list[base + __popcll(mk & ((1ull << lane) - 1ull))] = p;
+  }
 }
 
 // ---- update from the pieces -------------------------------------------------------------------------
@@ -1068,7 +1304,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__
   const int64_t b = t / ((int64_t)d * k);
   const float cnt = counts[b * k + c];
   float v = 0.f;  // compute_centroids.cu:82
-  if (cnt != 0.f) v = flag[b] ? sums[t] / cnt : mu[b * 64 + dim] + (sums[t] / cnt) * (1.f / scale[b]);
+  if (cnt != 0.f) v = flag[b] ? sums[t] / cnt : mu[b * kMu + dim] + (sums[t] / cnt) * (1.f / scale[b]);
   out[t] = v;
 }
 
@@ -1116,39 +1352,37 @@ static StepLayout step_layout(int l, int d, int64_t m, int n) {
   return L;
 }
 
-template <int KS>
-static int run_levels(StepArgs sa, int l, int d, int* list2, int* count2, hipStream_t st) {
+// the fast-path bounds of level 1 / level 2, relative to (|a'| + |c'|max)^2
+static float level_eps(int KS, int d, int level) {
   const int terms = KS * 16 + 2 + 3;
   const float common = (float)(terms + 8) / 8388608.0f + (float)(d + 1) / 16777216.0f + 1.0f / 4194304.0f +
                        1.0f / 524288.0f;  // accumulation, norm chain, shift rounding, key bits
+  return level == 1 ? 1.001f / 2048.0f + common + 1.0f / 131072.0f  // hi pieces only; 6-bit keys: 2^-17
+                    : 3.03f / 4194304.0f + common;
+}
+
+template <int KS>
+static int run_levels(StepArgs sa, int l, int d, int* list2, int* count2, hipStream_t st) {
   {  // level 1
-    const size_t lds = (size_t)8 * (KS + 1) * 1024 + sizeof(BlockList);
+    const size_t lds = (size_t)8 * (KS + 1) * 1024 + sizeof(BlockListT<kCoarseList>);
     auto kernel = coarse_kernel<KS>;
-    if constexpr (KS == 4) {  // knock-outs (tools/kstats.sh with TPQ_LL_EXP=1|2|4|5)
-      const char* e = getenv("TPQ_LL_EXP");
-      const int exp = e ? atoi(e) : 0;
-      if (exp == 1) kernel = coarse_kernel<KS, 1>;
-      if (exp == 2) kernel = coarse_kernel<KS, 2>;
-      if (exp == 4) kernel = coarse_kernel<KS, 4>;
-      if (exp == 5) kernel = coarse_kernel<KS, 5>;
-    }
     int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                        "lloyd coarse_kernel attr");
     if (rc) return rc;
-    sa.eps = 1.001f / 2048.0f + common + 1.0f / 131072.0f;  // (6-bit keys: 2^-17)
+    sa.eps = level_eps(KS, d, 1);
     const int64_t wide = (sa.T + 1) / 2, per_block = (int64_t)kWaves * kWide;
     hipLaunchKernelGGL(kernel, dim3((unsigned)((wide + per_block - 1) / per_block), l), dim3(kWaves * 64), lds, st, sa);
     TPQ_LAUNCH_CHECK("lloyd coarse_kernel");
   }
   {  // level 2
-    const size_t lds = (size_t)8 * (2 * KS + 1) * 1024 + sizeof(BlockList);
+    const size_t lds = (size_t)8 * (2 * KS + 1) * 1024 + sizeof(BlockListT<kRefineList>);
     auto kernel = refine_kernel<KS>;
     int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                        "lloyd refine_kernel attr");
     if (rc) return rc;
-    sa.eps = 3.03f / 4194304.0f + common;
+    sa.eps = level_eps(KS, d, 2);
     sa.list_in = sa.list;
     sa.count_in = sa.count;
     sa.list = list2;
@@ -1160,7 +1394,169 @@ static int run_levels(StepArgs sa, int l, int d, int* list2, int* count2, hipStr
   return TPQ_OK;
 }
 
+
+// ---- many centroids: tpq_coarse_assign through the cascade (one problem, d <= 128) --------------------
+// The centroids in chunks of 256 = blockIdx.y of ONE launch per level (a chunk's blocks alone fill half
+// the chip); a chunk's (best, second, in-chunk index) of every point goes to part_*, decide_kernel folds
+// the chunks and decides.  Level 1 = coarse_kernel over the points' hi pieces, level 2 = refine_kernel
+// over the undecided points, level 3 = the exact kernel over what is left (compact copy + centroid
+// splits, as in assign_fast.hip).  16 GB of piece streaming at 1 M x 16 384 x 128 instead of the
+// three-product sweep of assign_fast_kernel.
+struct AssignLayout {
+  PrepLayout P;
+  int KS, chunks, cap;
+  size_t prep_off, frags_off, cmax_off, cflag_off, count1_off, count2_off, partb_off, parti_off, list1_off, list2_off,
+      keys_off, ac_off, total;
+};
+static AssignLayout assign_layout(int d, int64_t m, int n) {
+  AssignLayout L;
+  L.P = prep_layout(1, d, m);
+  L.KS = L.P.KS;
+  L.chunks = (n + 255) / 256;
+  L.cap = (int)((m / 4 + 127) / 128 * 128);
+  if (L.cap < 128) L.cap = 128;
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  L.prep_off = 0;
+  L.frags_off = up(L.P.total);
+  L.cmax_off = up(L.frags_off + (size_t)L.chunks * 8 * (2 * L.KS + 1) * 1024);
+  L.cflag_off = L.cmax_off + 8;
+  L.count1_off = L.cflag_off + 4;
+  L.count2_off = L.count1_off + 4;
+  L.partb_off = up(L.count2_off + 4);                               // [chunks][m] float2
+  L.parti_off = up(L.partb_off + (size_t)L.chunks * m * 8);         // [chunks][m] u8
+  L.list1_off = up(L.parti_off + (size_t)L.chunks * m);
+  L.list2_off = up(L.list1_off + (size_t)m * 4);
+  L.keys_off = up(L.list2_off + (size_t)m * 4);        // [m] u64 (level 3: zeroed)
+  L.ac_off = up(L.keys_off + (size_t)m * 8);           // [d][cap] f32
+  L.total = up(L.ac_off + (size_t)d * L.cap * 4);
+  return L;
+}
+
+template <int KS>
+static int run_assign(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n, char* ws,
+                      const AssignLayout& L, hipStream_t st) {
+  const PrepLayout& P = L.P;
+  char* p = ws + L.prep_off;
+  float* mu = reinterpret_cast<float*>(p + P.mu_off);
+  float* scale = reinterpret_cast<float*>(p + P.scale_off);
+  int* flag = reinterpret_cast<int*>(p + P.flag_off);
+  unsigned* maxbits = reinterpret_cast<unsigned*>(p + P.maxbits_off);
+  u32x4* frags = reinterpret_cast<u32x4*>(ws + L.frags_off);
+  unsigned* cmax = reinterpret_cast<unsigned*>(ws + L.cmax_off);
+  int* cflag = reinterpret_cast<int*>(ws + L.cflag_off);
+  int* count1 = reinterpret_cast<int*>(ws + L.count1_off);
+  int* count2 = reinterpret_cast<int*>(ws + L.count2_off);
+  float2* part_b = reinterpret_cast<float2*>(ws + L.partb_off);
+  uint8_t* part_i = reinterpret_cast<uint8_t*>(ws + L.parti_off);
+  int* list1 = reinterpret_cast<int*>(ws + L.list1_off);
+  int* list2 = reinterpret_cast<int*>(ws + L.list2_off);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws + L.keys_off);
+  float* Ac = reinterpret_cast<float*>(ws + L.ac_off);
+  int rc = check_hip(hipMemsetAsync(p + P.mu_off, 0, P.total - P.mu_off, st), "coarse_assign memset");
+  if (rc) return rc;
+  rc = check_hip(hipMemsetAsync(ws + L.cmax_off, 0, L.partb_off - L.cmax_off, st), "coarse_assign memset");
+  if (rc) return rc;
+  rc = check_hip(hipMemsetAsync(keys, 0, (size_t)m * 8, st), "coarse_assign keys memset");
+  if (rc) return rc;
+  // prepare the points (per call: the points change from call to call, the centroids are the codebook)
+  hipLaunchKernelGGL(mu_kernel, dim3(d, 1), dim3(256), 0, st, B, mu, d, n);
+  TPQ_LAUNCH_CHECK("lloyd mu_kernel");
+  int chunks = (int)(4096 / (int64_t)d);
+  if (chunks < 1) chunks = 1;
+  if ((int64_t)chunks * 4096 > m) chunks = (int)((m + 4095) / 4096);
+  hipLaunchKernelGGL(maxabs_kernel, dim3(chunks, d, 1), dim3(256), 0, st, A, mu, maxbits, flag, d, m);
+  TPQ_LAUNCH_CHECK("lloyd maxabs_kernel");
+  hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(64), 0, st, maxbits, flag, scale, 1);
+  TPQ_LAUNCH_CHECK("lloyd scale_kernel");
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)((P.T + 3) / 4), 1), dim3(256), 0, st, A, mu, scale,
+                     reinterpret_cast<u32x4*>(p + P.hi_off), reinterpret_cast<u32x4*>(p + P.mid_off),
+                     reinterpret_cast<float2*>(p + P.norms_off), d, m, P.T, KS);
+  TPQ_LAUNCH_CHECK("lloyd split_kernel");
+  hipLaunchKernelGGL(cprep_kernel, dim3(8 * L.chunks, 1), dim3(64), 0, st, B, mu, scale, frags, cmax, cflag, d, n, KS);
+  TPQ_LAUNCH_CHECK("lloyd cprep_kernel");
+  const bool chunked = L.chunks > 1;
+  const int chunk_stride = 8 * (2 * KS + 1) * 64;  // 16-byte units
+  StepArgs sa{reinterpret_cast<const u32x4*>(p + P.hi_off), reinterpret_cast<const u32x4*>(p + P.mid_off),
+              reinterpret_cast<const float2*>(p + P.norms_off), frags, cmax, scale, flag, cflag, inds, vals,
+              nullptr, nullptr, list1, count1, (int)m, P.T,
+              level_eps(KS, d, 1), (float)(d + 4) / 16777216.0f, sqrtf((float)d) / 8192.0f,
+              chunked ? part_b : nullptr, chunked ? part_i : nullptr, chunk_stride};
+  {
+    const size_t lds = (size_t)8 * (KS + 1) * 1024 + sizeof(BlockListT<kCoarseList>);
+    auto kernel = coarse_kernel<KS>;
+    rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "lloyd coarse_kernel attr");
+    if (rc) return rc;
+    const int64_t wide = (P.T + 1) / 2, per_block = (int64_t)kWaves * kWide;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((wide + per_block - 1) / per_block), L.chunks), dim3(kWaves * 64), lds,
+                       st, sa);
+    TPQ_LAUNCH_CHECK("lloyd coarse_kernel");
+    if (chunked) {
+      hipLaunchKernelGGL(decide_kernel<1>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, sa, L.chunks);
+      TPQ_LAUNCH_CHECK("lloyd decide_kernel");
+    }
+  }
+  {
+    const size_t lds = (size_t)8 * (2 * KS + 1) * 1024 + sizeof(BlockListT<kRefineList>);
+    auto kernel = refine_kernel<KS>;
+    rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "lloyd refine_kernel attr");
+    if (rc) return rc;
+    sa.eps = level_eps(KS, d, 2);
+    sa.list_in = list1;
+    sa.count_in = count1;
+    sa.list = list2;
+    sa.count = count2;
+    if (chunked) {  // the points stay in registers, the chunks stream
+      sa.part_b = nullptr;
+      sa.part_i = nullptr;
+      const size_t lds2 = (size_t)2 * 4 * (2 * KS + 1) * 1024 + sizeof(BlockListT<kStreamList>);
+      auto k2 = refine_stream_kernel<KS>;
+      rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds2), "lloyd refine_stream_kernel attr");
+      if (rc) return rc;
+      hipLaunchKernelGGL(k2, dim3((unsigned)((m + kWaves * 32 - 1) / (kWaves * 32))), dim3(kWaves * 64), lds2, st, sa,
+                         2 * L.chunks);
+      TPQ_LAUNCH_CHECK("lloyd refine_stream_kernel");
+    } else {
+      const int64_t per_block = (int64_t)kWaves * kTilesR;
+      hipLaunchKernelGGL(kernel, dim3((unsigned)((P.T + per_block - 1) / per_block), 1), dim3(kWaves * 64), lds, st, sa);
+      TPQ_LAUNCH_CHECK("lloyd refine_kernel");
+    }
+  }
+  return launch_max_sim_list(A, B, vals, inds, 1, d, (int)m, n, 1, list2, count2, keys, Ac, L.cap, st);
+}
+
 }  // namespace lloyd
+
+// hooks for tpq_coarse_assign (assign_fast.hip): the cascade takes euclidean problems with d <= 128
+int lloyd_assign_supported(int d, int64_t m, int n) {
+  if (!(d >= 1 && d <= 128 && n >= 1 && n <= (1 << 24) && m >= 1 && m < (1LL << 31))) return 0;
+  if (getenv("TPQ_COARSE_ASSIGN_OLD")) return 0;  // (A/B: the two-piece bf16 selection of assign_fast.hip)
+  // below ~4 096 centroids the per-call preparation (max-abs + split of the points, the fold of the
+  // chunks) costs more than the lighter sweep saves: 128 x 2 048: 1.66 vs 1.48 ms, 128 x 4 096: 2.37 vs 2.76,
+  // 128 x 16 384: 8.5 vs 11.0, 64 x 16 384: 4.7 vs 6.0, 128 x 65 536: 39.9 vs 47.4 (1 M points)
+  const char* mn = getenv("TPQ_COARSE_ASSIGN_CASCADE_MIN_N");  // (tests: force the cascade on small shapes)
+  if (n < (mn ? atoi(mn) : 4096)) return 0;
+  const lloyd::PrepLayout P = lloyd::prep_layout(1, d, m);
+  return (P.T * ((P.KS + 1) / 2) * 2048 <= 0x7fffffffLL && (int64_t)d * m * 4 <= 0x7fffffffLL) ? 1 : 0;
+}
+size_t lloyd_assign_workspace_bytes(int d, int64_t m, int n) { return lloyd::assign_layout(d, m, n).total; }
+size_t lloyd_assign_count_offset(int d, int64_t m, int n) { return lloyd::assign_layout(d, m, n).count2_off; }
+int lloyd_assign(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n, char* ws,
+                 hipStream_t st) {
+  const lloyd::AssignLayout L = lloyd::assign_layout(d, m, n);
+  switch (L.KS) {
+    case 1: return lloyd::run_assign<1>(A, B, vals, inds, d, m, n, ws, L, st);
+    case 2: return lloyd::run_assign<2>(A, B, vals, inds, d, m, n, ws, L, st);
+    case 3: return lloyd::run_assign<3>(A, B, vals, inds, d, m, n, ws, L, st);
+    case 4: return lloyd::run_assign<4>(A, B, vals, inds, d, m, n, ws, L, st);
+    case 5: return lloyd::run_assign<5>(A, B, vals, inds, d, m, n, ws, L, st);
+    case 6: return lloyd::run_assign<6>(A, B, vals, inds, d, m, n, ws, L, st);
+    case 7: return lloyd::run_assign<7>(A, B, vals, inds, d, m, n, ws, L, st);
+    default: return lloyd::run_assign<8>(A, B, vals, inds, d, m, n, ws, L, st);
+  }
+}
 }  // namespace tpq
 
 using namespace tpq;
@@ -1256,7 +1652,8 @@ extern "C" int tpq_lloyd_step(const float* data, const void* prepared, const flo
                      reinterpret_cast<const float2*>(p + P.norms_off),
                      frags, cmax, scale, reinterpret_cast<const int*>(p + P.flag_off), cflag, inds, vals,
                      nullptr, nullptr, list, count, (int)m, P.T,
-                     0.f, (float)(d + 4) / 16777216.0f, sqrtf((float)d) / 8192.0f};
+                     0.f, (float)(d + 4) / 16777216.0f, sqrtf((float)d) / 8192.0f,
+                     nullptr, nullptr, 0};
   switch (KS) {
     case 1: rc = lloyd::run_levels<1>(sa, l, d, list2, count2, st); break;
     case 2: rc = lloyd::run_levels<2>(sa, l, d, list2, count2, st); break;
