@@ -1134,7 +1134,6 @@ __global__ __launch_bounds__(64 * NH * ((KS + 1) / 2), (NH == 1 ? 2 : 3)) void u
   constexpr int CW = 256 / NH, RT = 8 / NH;  // clusters / row tiles per wave
   __shared__ __attribute__((aligned(16))) uint16_t otab_s[NW][2 * CW * 8];  // [k-group][cluster][8 slots] fp16
   __shared__ int cnt_s[NW][CW];
-  __shared__ __attribute__((aligned(16))) char pf_s[NW][4096];  // landing zone of the L2 prefetch (never read)
   const int b = blockIdx.y;
   if (a.flag[b]) return;
   const int wave = threadIdx.x >> 6, dt = wave / NH, ch = wave % NH;
@@ -1162,43 +1161,73 @@ __global__ __launch_bounds__(64 * NH * ((KS + 1) / 2), (NH == 1 ? 2 : 3)) void u
   for (int ks2 = 0; ks2 < 2; ++ks2)
 #pragma unroll
     for (int i = 0; i < 8; ++i) ident[ks2][i] = (l31 == 16 * ks2 + 8 * half + i) ? (_Float16)1.0f : (_Float16)0.0f;
-  struct Staged {
-    f16x8 x[2][2];  // [piece][k-step of the pair]
-    int64_t label;
-    bool valid;
+  // **The points of a tile are taken in the order of their clusters.**  A k-step of 16 random labels
+  // touches 7 of the 8 cluster row tiles, so the one-hot multiply runs 8 x 2 MFMAs per k-step for 16
+  // non-zero rows; with the tile's 32 points SORTED by label the first k-step holds the lower half of
+  // the labels and the second the upper half -- 4 to 5 row tiles each -- and the row tiles outside
+  // [first label, last label] of the k-step are skipped (wave-uniform branches): 4 + 2 x ~4.5 x 2 = 22
+  // MFMAs per tile instead of 36.  The permutation costs nothing to apply: a lane loads the fragment of the
+  // point of its SORTED position (the loads are per-lane addressed anyway), so the transposed pieces come
+  // out in sorted order.  Cost: the labels of a tile are needed before its pieces (they are fetched three
+  // steps ahead) and the grouping below, one step ahead, behind the MFMAs.
+  constexpr unsigned kBad = 256u << 5;  // key of a point that is not this wave's (sorts last, row tile 8)
+  // (grouping by cluster ROW TILE is all the skipping needs: a counting sort over the 9 row-tile values --
+  // one ballot + two popcounts each -- and ONE ds_permute, instead of a 15-stage bitonic network whose
+  // dependent cross-lane round trips cost more than the MFMAs they saved: 3.8 vs 3.5 ms at C5)
+  auto sort32 = [&](unsigned key) -> unsigned {
+    const unsigned rt = key >> 10;  // 0..7, 8 = not this wave's point
+    const unsigned below_me = (1u << l31) - 1u;
+    unsigned pos = 0, base = 0;
+#pragma unroll
+    for (unsigned r = 0; r <= 8; ++r) {
+      const unsigned m32 = (unsigned)__ballot(rt == r);  // lanes 0..31 (32..63 hold the same points)
+      pos = rt == r ? base + __popc(m32 & below_me) : pos;
+      base += __popc(m32);
+    }
+    // lane `pos` (of the same half-wave) receives this lane's key
+    return (unsigned)__builtin_amdgcn_ds_permute((int)((pos + 32 * half) * 4), (int)key);
   };
-  auto load_tile = [&](Staged& st, int64_t tile) {
-    const bool tv = tile < a.T;
+  // raw label of point l31 of `tile` (int64, clamped address: validity is applied when it is used)
+  auto load_label = [&](int64_t tile) -> int64_t {
     const int64_t p = tile * 32 + l31;
-    // this wave's k-step pair of the tile: 2 KiB per array (an odd KS has a zero second half in its last pair)
-    const int voff = tv ? (int)((tile * DT + dt) * 2048) + l31 * 64 + half * 16 : 0x7ffffff0;
+    return lrow[(tile < a.T && p < a.m) ? p : 0];
+  };
+  auto key_of = [&](int64_t tile, int64_t label) -> unsigned {
+    const int64_t p = tile * 32 + l31;
+    const int64_t rel = label - CW * ch;  // this wave's clusters only: label - CW ch in [0, CW)
+    const bool ok = tile < a.T && p < a.m && label < a.k && rel >= 0 && rel < CW;
+    return ok ? (((unsigned)rel << 5) | (unsigned)l31) : (kBad | (unsigned)l31);
+  };
+  f16x8 x[2][2];  // [piece][k-step of the pair] of the tile in flight, rows in sorted order
+  auto load_pieces = [&](int64_t tile, unsigned skey) {
+    // lane (sorted position l31, half) takes the fragment of point (skey & 31) of the tile
+    const int voff = tile < a.T ? (int)((tile * DT + dt) * 2048) + (int)(skey & 31u) * 64 + half * 16 : 0x7ffffff0;
 #pragma unroll
     for (int ks2 = 0; ks2 < 2; ++ks2) {
-      st.x[0][ks2] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_hi, voff, ks2 * 32, 0));
-      st.x[1][ks2] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_mid, voff, ks2 * 32, 0));
+      x[0][ks2] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_hi, voff, ks2 * 32, 0));
+      x[1][ks2] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_mid, voff, ks2 * 32, 0));
     }
-    st.valid = tv && p < a.m;
-    st.label = lrow[st.valid ? p : 0];  // (raw: arithmetic right behind the load would wait for it on the spot)
   };
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // tiles dealt round-robin to the blocks of a sub-problem (adjacent rows are read side by side).  A
-  // tile's fragments are consumed by its four transposing MFMAs and its label by one compare right at
-  // the start; the loads of the next tile go into the same registers immediately afterwards.
+  // tile's fragments are consumed by its four transposing MFMAs right at the start; the loads of the
+  // next tile go into the same registers immediately afterwards.
   const int64_t step = gridDim.x;
-  Staged st;
-  load_tile(st, blockIdx.x);
+  unsigned skey = sort32(key_of(blockIdx.x, load_label(blockIdx.x)));  // sorted keys of the tile in flight
+  load_pieces(blockIdx.x, skey);
+  unsigned skey_n1 = sort32(key_of(blockIdx.x + step, load_label(blockIdx.x + step)));  // ... of the next tile
+  int64_t lab_n2 = load_label(blockIdx.x + 2 * step);                  // raw labels of the tile after that
 #pragma unroll 1
   for (int64_t tile = blockIdx.x; tile < a.T; tile += step) {
-    // this wave's clusters only: label - CW ch in [0, CW)
-    const int64_t lab64 = st.label - CW * ch;
-    const int lab = (st.valid && st.label < a.k && lab64 >= 0 && lab64 < CW) ? (int)lab64 : -1;
+    const unsigned rt_mine = skey >> 10;                       // cluster row tile of this lane's point (8: none)
+    const int lab = skey < kBad ? (int)(skey >> 5) : -1;
     // transposition: [32 points][32 dims] of each piece into accumulator layout, packed at once into the
     // two k-steps' B fragments (one piece at a time: 16 transient registers)
     u32x4 bop[2][2];  // [piece][k-step of 16 points], fp16 pairs
 #pragma unroll
     for (int pc = 0; pc < 2; ++pc) {
-      f32x16 tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.x[pc][0], ident[0], zero, 0, 0, 0);
-      tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.x[pc][1], ident[1], tr, 0, 0, 0);
+      f32x16 tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[pc][0], ident[0], zero, 0, 0, 0);
+      tr = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[pc][1], ident[1], tr, 0, 0, 0);
 #pragma unroll
       for (int sk = 0; sk < 2; ++sk)
 #pragma unroll
@@ -1207,51 +1236,45 @@ __global__ __launch_bounds__(64 * NH * ((KS + 1) / 2), (NH == 1 ? 2 : 3)) void u
               uint32_t, __builtin_amdgcn_cvt_pkrtz(tr[8 * sk + 2 * i], tr[8 * sk + 2 * i + 1]));
     }
     __builtin_amdgcn_sched_barrier(0);
-    load_tile(st, tile + step);  // (beyond the range: offsets out of the buffer, label of point 0, valid = false)
-    if (TPQ_LL_PF) {
-      // (Experiment, off: the registers can hold ONE tile in flight -- a second staging set beside 128
-      // accumulator registers spills -- and it has only this tile's update MFMAs, half a microsecond,
-      // to land.  Pulling the tile three steps on into L2 by LDS-DMA into a landing zone nobody reads
-      // costs no registers, but hipcc cannot tell the landing zone from the one-hot table: it puts
-      // s_waitcnt vmcnt(0) in front of every LDS access of the loop, i.e. waits for the loads it has
-      // just issued.)
-      int64_t pt = tile + TPQ_LL_PF * step;
-      pt = pt < a.T ? pt : tile;
-      const char* g_hi = reinterpret_cast<const char*>(a.hi) + (size_t)b * slice + (pt * DT + dt) * 2048 + lane * 16;
-      const char* g_mid = reinterpret_cast<const char*>(a.mid) + (size_t)b * slice + (pt * DT + dt) * 2048 + lane * 16;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g_hi + q * 1024),
-                                         (__attribute__((address_space(3))) void*)(pf_s[wave] + q * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g_mid + q * 1024),
-                                         (__attribute__((address_space(3))) void*)(pf_s[wave] + 2048 + q * 1024), 16, 0, 0);
-      }
-    }
+    // the next tile's pieces, in the order sorted during the previous step (the fragments are free now)
+    load_pieces(tile + step, skey_n1);
     __builtin_amdgcn_sched_barrier(0);
     if (dt == 0 && half == 0 && lab >= 0) atomicAdd(&cnt[lab], 1);  // integer LDS atomic: fast
-    // this lane's point (l31; half 0 lanes write): k-step l31 >> 4, k-group (l31 >> 2) & 1, slot (l31 & 3) + 4 ((l31 >> 3) & 1)
+    // this lane's point (sorted position l31; half 0 lanes write): k-step l31 >> 4, k-group (l31 >> 2) & 1,
+    // slot (l31 & 3) + 4 ((l31 >> 3) & 1)
     uint16_t* oslot = &otab[((l31 >> 2) & 1) * (CW * 8) + (lab >= 0 ? lab : 0) * 8 + (l31 & 3) + 4 * ((l31 >> 3) & 1)];
 #pragma unroll
     for (int sk = 0; sk < 2; ++sk) {
+      // row tiles of this k-step's 16 (sorted) points: [lo, hi]; invalid points sort last (row tile 8)
+      const int lo = (int)__builtin_amdgcn_readlane((int)rt_mine, 16 * sk);
+      int hi = (int)__builtin_amdgcn_readlane((int)rt_mine, 16 * sk + 15);
+      hi = hi < RT ? hi : RT - 1;
       const bool writer = half == 0 && (l31 >> 4) == sk && lab >= 0;
       if (writer) *oslot = (uint16_t)0x3C00;  // fp16 1.0
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const f16x8* orow = reinterpret_cast<const f16x8*>(&otab[half * (CW * 8) + l31 * 8]);
-      f16x8 aring[2];  // A operands are fetched one row tile (two MFMAs) ahead
-      aring[0] = orow[0];
+      f16x8 aop[RT];  // all A operands of the k-step are requested before its first MFMA
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        if (rt + 1 < RT) aring[(rt + 1) & 1] = orow[32 * (rt + 1)];
-        const f16x8 aop = aring[rt & 1];
-        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, __builtin_bit_cast(f16x8, bop[0][sk]), acc[rt], 0, 0, 0);
-        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop, __builtin_bit_cast(f16x8, bop[1][sk]), acc[rt], 0, 0, 0);
-      }
+      for (int rt = 0; rt < RT; ++rt)
+        if (rt >= lo && rt <= hi) aop[rt] = orow[32 * rt];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        if (rt >= lo && rt <= hi) {
+          acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop[rt], __builtin_bit_cast(f16x8, bop[0][sk]), acc[rt], 0, 0, 0);
+          acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aop[rt], __builtin_bit_cast(f16x8, bop[1][sk]), acc[rt], 0, 0, 0);
+        }
       __builtin_amdgcn_wave_barrier();
       if (writer) *oslot = (uint16_t)0;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
+    // the tile two steps on: sort its labels (fetched a step ago) -- 15 dependent cross-lane stages, behind
+    // this tile's MFMAs and in front of nothing: the pieces just requested have that long to land -- and
+    // fetch the labels of the tile three steps on
+    skey = skey_n1;
+    skey_n1 = sort32(key_of(tile + 2 * step, lab_n2));
+    lab_n2 = load_label(tile + 3 * step);
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
