@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TPQ_VERSION 200 /* 0.2.0 */
+#define TPQ_VERSION 300 /* 0.3.0 */
 
 #define TPQ_OK 0
 #define TPQ_ERR_INVALID_ARGUMENT (-1)
