@@ -41,7 +41,8 @@ namespace tpq {
 int lloyd_assign_supported(int d, int64_t m, int n);
 size_t lloyd_assign_workspace_bytes(int d, int64_t m, int n);
 size_t lloyd_assign_count_offset(int d, int64_t m, int n);
-int lloyd_assign(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n, char* ws,
+int lloyd_wide_supported(int d, int64_t m, int n);
+int lloyd_assign(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n, int euclid, char* ws,
                  hipStream_t st);
 int launch_max_sim_list(const float* A, const float* B, float* vals, int64_t* inds, int l, int d, int m, int n,
                         int euclid, const int* list, const int* count, unsigned long long* keys, float* Ac, int cap,
@@ -886,26 +887,40 @@ extern "C" int tpq_max_sim_select(const float* A, const float* B, float* vals, i
 static int af_ks(int d) { return d <= 32 ? 2 : (d <= 64 ? 4 : 8); }
 
 extern "C" int tpq_coarse_assign_supported(int d, int64_t m, int n) {
+  if (d > 128) return m == 0 ? (d <= 1024 && n >= 1) : lloyd_wide_supported(d, m, n);  // the GEMM-shaped cascade
   return (d >= 1 && d <= 128 && n >= 1 && n <= (1 << 24) && m >= 0 && m < (1LL << 31) &&
           (int64_t)af_ks(d) * 16 * m * 4 <= 0x7fffffffLL)
              ? 1
              : 0;
 }
 
+// d > 128: the cascade's dozen launches and the preparation of the points cost ~0.2 ms + a pass over the
+// data; below this many multiply-adds the fp32 kernel is done sooner (same labels either way)
+static bool wide_cascade_pays(int d, int64_t m, int n) {
+  const char* e = getenv("TPQ_COARSE_ASSIGN_WIDE_MIN_WORK");  // (tests: force the cascade on small shapes)
+  const double min_work = e ? atof(e) : 8589934592.0;
+  return (double)m * (double)n * (double)d >= min_work;
+}
+
 // workspace = [the two-piece bf16 selection's layout][the cascade's layout]: either path may run (the
 // cascade takes euclidean problems, the selection inner products), the diagnostics word stays where it was
 static size_t af_old_total(int d, int64_t m, int n) {
+  if (d > 128) return 256;  // wide vectors: the diagnostics word alone
   return (afast::layout(af_ks(d), TPQ_AF_NP, m, n, d).total + 255) / 256 * 256;
 }
 extern "C" size_t tpq_coarse_assign_workspace_bytes(int d, int64_t m, int n) {
   if (!tpq_coarse_assign_supported(d, m, n)) return 0;
+  if (d > 128) {  // [diagnostics word][the cascade's layout, or -- small problems -- the fp32 kernel's maxima]
+    const size_t cascade = m > 0 ? lloyd_assign_workspace_bytes(d, m, n) : 0, plain = ((size_t)m * 4 + 255) / 256 * 256;
+    return 256 + (cascade > plain ? cascade : plain);
+  }
   return af_old_total(d, m, n) + (m > 0 && lloyd_assign_supported(d, m, n) ? lloyd_assign_workspace_bytes(d, m, n) : 0);
 }
 
 // diagnostics: byte offset, inside the workspace, of the int32 number of points the last call sent
 // to the exact re-check
 extern "C" size_t tpq_coarse_assign_count_offset(int d, int64_t m, int n) {
-  if (!tpq_coarse_assign_supported(d, m, n)) return 0;
+  if (!tpq_coarse_assign_supported(d, m, n) || d > 128) return 0;
   return afast::layout(af_ks(d), TPQ_AF_NP, m, n).count_off;
 }
 
@@ -914,7 +929,8 @@ extern "C" int tpq_coarse_assign(const float* A, const float* B, float* vals, in
   TPQ_REQUIRE(A && B && inds, "coarse_assign: null pointer");
   TPQ_REQUIRE(metric == TPQ_METRIC_NEG_SQ_L2 || metric == TPQ_METRIC_INNER, "coarse_assign: bad metric %d", metric);
   if (!tpq_coarse_assign_supported(d, m, n)) {
-    set_error("coarse_assign: shape d=%d m=%lld n=%d not supported (d <= 128, padded slice < 2 GiB); use tpq_max_sim",
+    set_error("coarse_assign: shape d=%d m=%lld n=%d not supported (d <= 1024; d <= 128: padded slice < 2 GiB; "
+              "d > 128: m < 2^28, n <= 2^22); use tpq_max_sim",
               d, (long long)m, n);
     return TPQ_ERR_UNSUPPORTED;
   }
@@ -924,12 +940,16 @@ extern "C" int tpq_coarse_assign(const float* A, const float* B, float* vals, in
   const int euclid = metric == TPQ_METRIC_NEG_SQ_L2 ? 1 : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   char* ws = reinterpret_cast<char*>(workspace);
-  if (euclid && lloyd_assign_supported(d, m, n)) {  // the fp16 cascade (lloyd.hip)
+  if (d > 128 && !wide_cascade_pays(d, m, n)) {  // a small problem: the fp32 kernel itself
+    check_hip(hipMemsetAsync(ws, 0, 4, st), "coarse_assign memset");
+    return tpq_max_sim(A, B, vals ? vals : reinterpret_cast<float*>(ws + 256), inds, 1, d, (int)m, n, metric, stream);
+  }
+  if (d > 128 || (euclid && lloyd_assign_supported(d, m, n))) {  // the fp16 cascade (lloyd.hip)
     char* cws = ws + af_old_total(d, m, n);
-    int rc = lloyd_assign(A, B, vals, inds, d, m, n, cws, st);
+    int rc = lloyd_assign(A, B, vals, inds, d, m, n, euclid, cws, st);
     if (rc) return rc;
     // diagnostics: the number of exactly re-checked points where tpq_coarse_assign_count_offset points
-    return check_hip(hipMemcpyAsync(ws + afast::layout(af_ks(d), TPQ_AF_NP, m, n).count_off,
+    return check_hip(hipMemcpyAsync(ws + (d > 128 ? 0 : afast::layout(af_ks(d), TPQ_AF_NP, m, n).count_off),
                                     cws + lloyd_assign_count_offset(d, m, n), 4, hipMemcpyDeviceToDevice, st),
                      "coarse_assign count copy");
   }

@@ -1550,6 +1550,653 @@ static int run_assign(const float* A, const float* B, float* vals, int64_t* inds
   return launch_max_sim_list(A, B, vals, inds, 1, d, (int)m, n, 1, list2, count2, keys, Ac, L.cap, st);
 }
 
+// =========================================================================================================
+// Wide vectors (128 < d <= 1024): GEMM-shaped, and the exact step works on CANDIDATES (the
+// coarse assign of a GIST-dimension index -- 1 M x 16 384 x 960 -- is 270-320 ms on the fp32 MFMA)
+// =========================================================================================================
+// Beyond 128 dimensions a wave can no longer keep its points' pieces in registers, so both operands are
+// streamed: a block owns 256 points x ALL centroids; per block of 256 centroids it runs the K loop over the
+// k-steps with both operands' fragments coming through a double-buffered LDS ring by LDS-DMA (4 k-steps per
+// stage: 32 KiB of centroid fragments + 32 KiB of point fragments), 8 waves as 4 point slabs x 2 centroid
+// halves, each wave 64 points x 128 centroids = 8 accumulators; after the K loop the -N MFMAs and the
+// epilogue over the 128 values per lane -- amortised over KS x 8 MFMAs.
+//
+// At d ~ 1000 every (d 2^-24)-sized term of the bound -- the fast path's accumulation AND the exact kernel's
+// own rounding, which no fast path can remove -- is worth percents of the points: a third product pass
+// (level 2 of the narrow path) would turn 18 % undecided into 11 %, and the exact kernel over 11 % of a
+// million points is a third of the full problem.  So the wide path never runs the exact kernel over all
+// centroids.  What the bound does give for an undecided point is a short list of CANDIDATES: the exact
+// winner w satisfies f_w >= f_best - 2 delta.  Three passes:
+//   1. gemm_kernel<false>: hi pieces, key top-2 of every point; gdecide_kernel decides 80 % and lists the rest
+//      with its threshold f_best - 2 delta;
+//   2. gemm_kernel<true> over the listed points (hi pieces gathered into a compact fragment array): every
+//      (point, centroid) at or above the point's threshold goes to a pair list -- 2-3 per listed point;
+//   3. pair_exact_kernel: the exact kernel's value of each pair -- the SAME instruction sequence as
+//      max_sim_kernel (kmeans.hip): ascending-k fma chains for |x|^2 and |c|^2, v_mfma_f32_32x32x2f32 over
+//      ascending k pairs, 2 acc - |x|^2 - |c|^2 -- 32 pairs per wave on the diagonal of a 32 x 32 tile,
+//      folded per point with the 64-bit atomicMax key of the exact kernel's split mode (value, then the
+//      smaller index).
+// Pair lists that overflow (degenerate data: duplicates by the thousand, non-finite values) fall back to
+// the exact kernel over the level-1 list: correctness never depends on the candidate counts.
+// Operand layout: plain MFMA-fragment order [tile of 32 rows][k-step][lane] x 16 B for points and
+// centroids alike (every access is a 1-KiB stream).
+constexpr int kGK = 4;                       // k-steps per LDS stage
+constexpr int kGStage = 2 * 8 * kGK * 1024;  // bytes of a stage: 8 centroid units + 8 point tiles, kGK k-steps each
+constexpr int kPairList = 4096;              // LDS-staged (row, centroid) entries per block between flushes
+
+struct PairList {
+  int n;
+  int base;
+  unsigned item[kPairList];  // row in the block (8 bits) << 22 | centroid
+};
+
+struct GemmArgs {
+  const u32x4* cfr;      // centroid operand [units][KA][64]
+  const u32x4* pfr;      // point operand [tiles][KA][64]
+  const u32x4* cnorm;    // [units][64]: -N as three bf16 pieces at k = 0, 1, 2 (-3e38 beyond n)
+  float2* part_b;        // pass 1: [2 * ysplit][rows] (best, second) per centroid half
+  int* part_i;           // pass 1: [2 * ysplit][rows] centroid index
+  int KA;                // k-steps of the operands (multiple of kGK)
+  int n_cblocks;         // blocks of 256 centroids
+  int64_t rows;          // points (pass 1) / capacity of the compact array (pass 2)
+  const int* count_in;   // pass 2: number of listed points on the device (rows = min(this, capacity))
+  const float* thr;      // pass 2: [capacity] threshold of the listed point
+  uint2* pairs;          // pass 2: (list position, centroid)
+  int* pair_count;
+  int pair_cap;
+  int* overflow;         // pass 2: set when a pair was dropped
+};
+
+// the block's staged pairs -> the global list.  Called by all threads, at points where nobody appends.
+__device__ __forceinline__ void flush_pairs(const GemmArgs& a, PairList* pl) {
+  if (threadIdx.x == 0) {
+    const int n = pl->n < kPairList ? pl->n : kPairList;
+    if (pl->n > kPairList) atomicOr(a.overflow, 1);
+    pl->base = n ? atomicAdd(a.pair_count, n) : 0;
+  }
+  __syncthreads();
+  const int n = pl->n < kPairList ? pl->n : kPairList, base = pl->base;
+  for (int i = threadIdx.x; i < n; i += kWaves * 64) {
+    const unsigned e = pl->item[i];
+    if (base + i < a.pair_cap)
+      a.pairs[base + i] = make_uint2(blockIdx.x * 256u + (e >> 22), e & 0x3fffffu);
+    else
+      atomicOr(a.overflow, 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) pl->n = 0;
+}
+
+template <bool CAND>
+__global__ __launch_bounds__(kWaves * 64) void gemm_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages, the block's -N fragments (8 KiB), PairList
+  int64_t rows = a.rows;
+  if (CAND) {
+    const int c = *a.count_in;
+    rows = c < a.rows ? c : a.rows;
+  }
+  if ((int64_t)blockIdx.x * 256 >= rows) return;  // block-uniform
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;  // point slab (64 points), centroid half (128 centroids)
+  const int cb_per = (a.n_cblocks + gridDim.y - 1) / gridDim.y;
+  const int cb0 = blockIdx.y * cb_per, cb1 = (cb0 + cb_per) < a.n_cblocks ? (cb0 + cb_per) : a.n_cblocks;
+  if (cb0 >= cb1) return;
+  const int n_kst = a.KA / kGK;  // stages per centroid block (>= 3: d > 128)
+  const int n_stage = (cb1 - cb0) * n_kst;
+  char* nbuf = smem + 2 * kGStage;
+  PairList* pl = reinterpret_cast<PairList*>(nbuf + 8 * 1024);
+  if (CAND && threadIdx.x == 0) pl->n = 0;
+  // stage g = (centroid block cb0 + g / n_kst, k-steps [kGK (g % n_kst), + kGK)) -> buffer g & 1: units
+  // 0..7 then point tiles 0..7, each kGK consecutive 1-KiB fragments
+  auto stage = [&](int g) {
+    const int cb = cb0 + g / n_kst, k0 = (g % n_kst) * kGK;
+    char* dst = smem + (g & 1) * kGStage;
+    for (int f = wave; f < 16 * kGK; f += kWaves) {
+      const int who = f / kGK, kk = f % kGK;  // 0..7 centroid units, 8..15 point tiles
+      const char* src = who < 8 ? reinterpret_cast<const char*>(a.cfr) + (((size_t)(cb * 8 + who)) * a.KA + k0 + kk) * 1024
+                                : reinterpret_cast<const char*>(a.pfr) +
+                                      (((size_t)blockIdx.x * 8 + (who - 8)) * a.KA + k0 + kk) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+    }
+  };
+  stage(0);
+  f32x16 acc[4][2];  // [centroid row tile of this wave's half][point column tile of its slab]
+  float b1[2] = {-INFINITY, -INFINITY}, b2[2] = {-INFINITY, -INFINITY};
+  int bu[2] = {0, 0};
+  float thr[2] = {INFINITY, INFINITY};
+  if (CAND) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int64_t row = (int64_t)blockIdx.x * 256 + wr * 64 + ct * 32 + l31;
+      if (row < rows) thr[ct] = a.thr[row];
+    }
+  }
+  bf16x8 bones = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (half == 0) {
+    bones[0] = (__bf16)1.0f;
+    bones[1] = (__bf16)1.0f;
+    bones[2] = (__bf16)1.0f;
+  }
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int g = 0; g < n_stage; ++g) {
+    __syncthreads();  // stage g has landed; everyone is done with the other buffer (and with nbuf)
+    if (g + 1 < n_stage) stage(g + 1);
+    const int kst = g % n_kst;
+    if (kst == 0) {  // a new centroid block: its -N fragments (8 KiB; read after the K loop) and fresh accumulators
+      const int cb = cb0 + g / n_kst;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(a.cnorm) +
+                                                         ((size_t)cb * 8 + wave) * 1024 + lane * 16),
+          (__attribute__((address_space(3))) void*)(nbuf + wave * 1024), 16, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        acc[rt][0] = zero;
+        acc[rt][1] = zero;
+      }
+      // (pairs are appended in the epilogue of the previous centroid block, before the barrier above:
+      // pl->n is stable here, and the condition uniform)
+      if (CAND && pl->n >= kPairList / 2) flush_pairs(a, pl);
+    }
+    const u32x4* sb = reinterpret_cast<const u32x4*>(smem + (g & 1) * kGStage) + lane;
+#pragma unroll
+    for (int kk = 0; kk < kGK; ++kk) {
+      f16x8 af[4], bf[2];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) af[rt] = __builtin_bit_cast(f16x8, sb[((wc * 4 + rt) * kGK + kk) * 64]);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) bf[ct] = __builtin_bit_cast(f16x8, sb[((8 + wr * 2 + ct) * kGK + kk) * 64]);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[rt], bf[ct], acc[rt][ct], 0, 0, 0);
+    }
+    if (kst == n_kst - 1) {  // the centroid block is complete: -N, then the epilogue over 2 x 64 values per lane
+      const int cb = cb0 + g / n_kst;
+      // (nbuf was requested n_kst stages ago and every barrier since waited for vmcnt(0))
+      const u32x4* nb = reinterpret_cast<const u32x4*>(nbuf) + lane;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const bf16x8 cf = __builtin_bit_cast(bf16x8, nb[(wc * 4 + rt) * 64]);
+        acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf, bones, acc[rt][0], 0, 0, 0);
+        acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf, bones, acc[rt][1], 0, 0, 0);
+      }
+      if (!CAND) {
+        const float before0 = b1[0], before1 = b1[1];
+        static_for<0, 4>([&](auto rt_c) {
+          constexpr int rt = decltype(rt_c)::value;
+          static_for<0, 16>([&](auto q_c) {  // 8 register pairs x 2 column tiles
+            constexpr int q = decltype(q_c)::value, ct = q & 1, pq = q >> 1;
+            top2_keys_pair(b1[ct], b2[ct], key6<16 * rt + 2 * pq>(acc[rt][ct][2 * pq]),
+                           key6<16 * rt + 2 * pq + 1>(acc[rt][ct][2 * pq + 1]));
+          });
+        });
+        bu[0] = b1[0] > before0 ? cb : bu[0];
+        bu[1] = b1[1] > before1 ? cb : bu[1];
+      } else {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            float mx = acc[rt][ct][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[rt][ct][r]);
+            if (__ballot(mx >= thr[ct]) == 0ull) continue;  // (nearly every tile)
+            const unsigned rowbits = (unsigned)(wr * 64 + ct * 32 + l31) << 22;
+            const int cbase = cb * 256 + wc * 128 + rt * 32 + 4 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const bool hit = acc[rt][ct][r] >= thr[ct];
+              const unsigned long long mk = __ballot(hit);
+              if (mk) {
+                const int leader = __ffsll((long long)mk) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&pl->n, __popcll(mk));  // LDS
+                base = __shfl(base, leader, 64);
+                const int slot = base + __popcll(mk & ((1ull << lane) - 1ull));
+                if (hit && slot < kPairList) pl->item[slot] = rowbits | (unsigned)(cbase + (r & 3) + 8 * (r >> 2));
+              }
+            }
+          }
+      }
+    }
+  }
+  if (CAND) {
+    __syncthreads();
+    flush_pairs(a, pl);
+    return;
+  }
+  // this wave's (best, second, index) of its 2 x 32 points over its centroid half of every block
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int tag = __float_as_int(b1[ct]) & 63, r0 = tag & 15;
+    int idx = bu[ct] * 256 + wc * 128 + (tag >> 4) * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * half;
+    const float m1 = b1[ct], m2 = b2[ct];
+    const float o1 = __shfl_xor(m1, 32, 64), o2 = __shfl_xor(m2, 32, 64);
+    const int oi = __shfl_xor(idx, 32, 64);
+    const float B1 = fmaxf(m1, o1);
+    const float B2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
+    if (o1 > m1 || (o1 == m1 && oi < idx)) idx = oi;
+    const int64_t row = (int64_t)blockIdx.x * 256 + wr * 64 + ct * 32 + l31;
+    if (half == 0 && row < rows) {
+      const int64_t slot = (int64_t)(blockIdx.y * 2 + wc) * a.rows + row;
+      a.part_b[slot] = make_float2(B1, B2);
+      a.part_i[slot] = idx;
+    }
+  }
+}
+
+// points -> fragment order: hi [T][KAp][64] x 16 B (k-steps beyond ceil(d / 16) zero), norms.  grid (ceil(T / 4))
+__global__ __launch_bounds__(256) void gsplit_points_kernel(const float* __restrict__ A, const float* __restrict__ mu,
+                                                           const float* __restrict__ scale, u32x4* __restrict__ hi,
+                                                           float4* __restrict__ norms, int d, int64_t m, int64_t T,
+                                                           int KAp) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  if (tile >= T) return;
+  const int64_t i = tile * 32 + l31;
+  const bool iv = i < m;
+  const float* Ap = A + (iv ? i : 0);
+  const float s = scale[0];
+  float n2c = 0.f, n2r = 0.f, n2m = 0.f;
+  for (int st = 0; st < KAp; ++st) {
+    f16x8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * st + 8 * half + j;
+      const float x = (iv && k < d) ? Ap[(int64_t)k * m] : 0.f;
+      const float v = (iv && k < d) ? (x - mu[k]) * s : 0.f;
+      const _Float16 hh = (_Float16)v;
+      const float r = v - (float)hh;  // exact: what the fast path drops of this element
+      h[j] = hh;
+      n2c = fmaf(v, v, n2c);
+      n2r = fmaf(x, x, n2r);
+      n2m = fmaf(r, r, n2m);
+    }
+    hi[(tile * KAp + st) * 64 + lane] = __builtin_bit_cast(u32x4, h);
+  }
+  n2c += __shfl_xor(n2c, 32, 64);
+  n2r += __shfl_xor(n2r, 32, 64);
+  n2m += __shfl_xor(n2m, 32, 64);
+  if (half == 0 && iv) norms[i] = make_float4(n2c, n2r, n2m, 0.f);
+}
+
+// centroids -> operand c1 [U][KAp][64] (hi piece of C = 2 c'; inner product: C = c'), -N fragments, max
+// norms, range flag.  grid (U), U = 8 x blocks of 256
+__global__ __launch_bounds__(64) void gprep_centroids_kernel(const float* __restrict__ B, const float* __restrict__ mu,
+                                                            const float* __restrict__ scale, u32x4* __restrict__ c1,
+                                                            u32x4* __restrict__ cnorm, unsigned* __restrict__ cmax2_bits,
+                                                            int* __restrict__ cflag, int d, int n, int KAp, int euclid) {
+  const int unit = blockIdx.x, lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+  const int c = unit * 32 + l31;
+  const float s = scale[0];
+  float N = 0.f, sraw = 0.f;
+  if (c < n) {  // |c'|^2 in double, rounded once: a chain of d fp32 roundings would be a term of the bound
+    double Nd = 0.0;
+    for (int k = 0; k < d; ++k) {
+      const float y = B[(int64_t)k * n + c];
+      const float cc = (y - mu[k]) * s;
+      Nd += (double)cc * (double)cc;
+      sraw = fmaf(y, y, sraw);
+    }
+    N = (float)Nd;
+  }
+  float c2m = 0.f;  // |C - Ch|^2: what the fast path drops of this centroid
+  int bad = 0;
+  {
+    bf16x8 f = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (half == 0) {
+      __bf16 p1, p2, p3;
+      split3_bf16(c < n ? (euclid ? -N : 0.f) : -3.0e38f, p1, p2, p3);  // inner product: no norm
+      f[0] = p1;
+      f[1] = p2;
+      f[2] = p3;
+    }
+    cnorm[(int64_t)unit * 64 + lane] = __builtin_bit_cast(u32x4, f);
+  }
+  if (c < n) {
+    bad |= !(N <= 3.0e38f) | !(sraw <= 3.0e38f);
+    if (half == 0 && !bad) {
+      atomicMax(cmax2_bits, __float_as_uint(N));
+      atomicMax(cmax2_bits + 1, __float_as_uint(sraw));
+    }
+  }
+  for (int st = 0; st < KAp; ++st) {
+    f16x8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * st + 8 * half + j;
+      const float C = (k < d && c < n) ? (euclid ? 2.f : 1.f) * ((B[(int64_t)k * n + c] - mu[k]) * s) : 0.f;
+      bad |= !(fabsf(C) <= 65000.f);
+      const _Float16 hh = (_Float16)C;
+      const float r = C - (float)hh;
+      h[j] = hh;
+      c2m = fmaf(r, r, c2m);
+    }
+    c1[((int64_t)unit * KAp + st) * 64 + lane] = __builtin_bit_cast(u32x4, h);
+  }
+  c2m += __shfl_xor(c2m, 32, 64);
+  if (half == 0 && c < n && !bad) atomicMax(cmax2_bits + 2, __float_as_uint(c2m));
+  if (bad) atomicOr(cflag, 1);
+}
+
+// pass 2's point operand: the listed points' hi fragments, compact: position pos of the list -> tile
+// pos / 32, row pos % 32.  grid (ceil(cap / 32)), one wave per compact tile
+__global__ __launch_bounds__(64) void ggather_kernel(const u32x4* __restrict__ hi, const int* __restrict__ list,
+                                                    const int* __restrict__ count, u32x4* __restrict__ out, int KAp,
+                                                    int cap) {
+  const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+  int cnt = *count;
+  cnt = cnt < cap ? cnt : cap;
+  const int64_t pos = (int64_t)blockIdx.x * 32 + l31;
+  if ((int64_t)blockIdx.x * 32 >= cnt) return;
+  const int p = pos < cnt ? list[pos] : -1;
+  const int64_t src = p >= 0 ? ((int64_t)(p >> 5) * KAp) * 64 + half * 32 + (p & 31) : 0;
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  u32x4* o = out + ((int64_t)blockIdx.x * KAp) * 64 + lane;
+  for (int st = 0; st < KAp; ++st) o[(int64_t)st * 64] = p >= 0 ? hi[src + (int64_t)st * 64] : z;
+}
+
+// fold the partial results of a point and decide; an undecided point is listed with its candidate
+// threshold.  grid (ceil(m / 256))
+struct GDecideArgs {
+  const float2* part_b;
+  const int* part_i;
+  int n_part;
+  int64_t rows;                // stride of the partial tables
+  const float4* norms;         // [m]: |a'|^2, |x|^2, |a' - ah|^2
+  const unsigned* cmax2_bits;  // max N, max |c|^2, max |C - Ch|^2
+  const float* scale;
+  const int* flag;
+  const int* cflag;
+  int64_t* inds;
+  float* vals;
+  int* list;
+  int* count;
+  float* thr;  // [cap]
+  int cap;
+  int m;
+  float eps, eps_exact, eta;  // eps: everything but the dropped pieces, relative to (|a'| + |c'|max)^2
+  int euclid;                 // 0: inner product (no centring, C = c', no norms: the bounds hold a fortiori)
+};
+// The bound (the derivation of the header comment, with the refinements that matter at d ~ 1000):
+//  * the dropped products are bounded by what was actually dropped -- |a' - ah| of the point (split kernel)
+//    and max |C - Ch| over the centroids (prep kernel):
+//        |sum (a C - ah Ch)| <= |a' - ah| (|Ch|max + |C - Ch|max) + |a'| |C - Ch|max,   |Ch| <= (1 + 2^-11) 2 |c'|
+//    -- about a third of the worst case 2^-11 (|a'| + |c'|max)^2;
+//  * accumulation: an MFMA adds 16 products and the accumulator, <= 17 roundings of <= 2^-23 (truncation
+//    allowed for) of the running magnitude, which is <= sum |a_k C_k| + N <= |a'| 2 |c'| + |c'|^2: at most
+//    (|a'| + |c'|)^2 / 2 for the products: (17 (KS + 1) + 8) 2^-24;
+//  * N = fl(|c'|^2) is summed in double and rounded once (2^-24 N);
+//  * pass 1 compares KEYS (2^-17 |v| off, |v| <= (.)^2), pass 2 the values themselves against the key of
+//    the best minus 2 delta: the exact winner's value is within delta of its exact value, the best key within
+//    delta of ITS exact value, so the winner is at or above the threshold (lowered by one more key error
+//    and a denormal: delta = 0 -- all-zero data -- must still list the best itself).
+__global__ __launch_bounds__(256) void gdecide_kernel(GDecideArgs a) {
+  const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = pos < a.m;
+  const int p = valid ? (int)pos : 0;
+  float B1 = -INFINITY, B2 = -INFINITY;
+  int idx = 0;
+  if (valid)
+    for (int c = 0; c < a.n_part; ++c) {
+      const float2 v = a.part_b[(int64_t)c * a.rows + pos];
+      const int i = a.part_i[(int64_t)c * a.rows + pos];
+      const float n2 = fmaxf(fminf(B1, v.x), fmaxf(B2, v.y));
+      idx = (v.x > B1 || (v.x == B1 && i < idx)) ? i : idx;
+      B1 = fmaxf(B1, v.x);
+      B2 = n2;
+    }
+  const float s = a.scale[0];
+  const float cn = sqrtf(__uint_as_float(a.cmax2_bits[0])), cnr = sqrtf(__uint_as_float(a.cmax2_bits[1]));
+  const float4 n2 = a.norms[p];
+  const float an = sqrtf(n2.x), anr = sqrtf(n2.y) * s;
+  const float t1 = an + cn, t2 = anr + cnr * s;
+  const float a2 = sqrtf(n2.z), c2 = sqrtf(__uint_as_float(a.cmax2_bits[2]));
+  const float cscale = a.euclid ? 2.002f : 1.001f;
+  const float dropped = a2 * (cscale * cn + c2) + 1.001f * an * c2;
+  float delta = 1.25f * (dropped + a.eps * t1 * t1 + a.eta * (2.f * cn + an) + a.eps_exact * t2 * t2);
+  if ((a.flag[0] | a.cflag[0]) != 0) delta = INFINITY;
+  if (valid) {
+    a.inds[p] = idx;
+    if (a.vals) a.vals[p] = (a.euclid ? B1 - n2.x : B1) * ((1.f / s) * (1.f / s));
+  }
+  const bool listed = valid && !(B1 - B2 > 2.f * delta);
+  const unsigned long long mk = __ballot(listed);
+  if (mk) {
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mk) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(a.count, __popcll(mk));
+    base = __shfl(base, leader, 64);
+    if (listed) {
+      const int slot = base + __popcll(mk & ((1ull << lane) - 1ull));
+      a.list[slot] = p;
+      if (slot < a.cap) a.thr[slot] = B1 - 2.f * delta - (fabsf(B1) * (1.0f / 65536.0f) + 1.0e-30f);
+    }
+  }
+}
+
+// pass 3: the exact kernel's value of every (listed point, candidate centroid) pair, folded into keys[point].
+// A wave takes 32 pairs: lane (pair i, half); half 0 streams the point's column of A, half 1 the centroid's
+// column of B -- each the ascending-k fma chain of its squared norm as max_sim_kernel forms it -- and per
+// pair of dimensions the halves swap what the other needs as MFMA operand (row i = centroid of pair i,
+// column i = point of pair i: the diagonal of the 32 x 32 tile holds the 32 results).
+__global__ __launch_bounds__(256) void pair_exact_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                        const uint2* __restrict__ pairs, const int* __restrict__ pair_count,
+                                                        int pair_cap, const int* __restrict__ list,
+                                                        unsigned long long* __restrict__ keys, int d, int64_t m, int n,
+                                                        int euclid) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+  int cnt = *pair_count;
+  cnt = cnt < pair_cap ? cnt : pair_cap;
+  const int tiles = (cnt + 31) >> 5;
+  for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
+    const int q = tile * 32 + l31;
+    const bool valid = q < cnt;
+    const uint2 pr = valid ? pairs[q] : make_uint2(0u, 0u);
+    const int p = valid ? list[pr.x] : 0;
+    const int c = (int)pr.y;
+    const float* src = half ? B + c : A + p;
+    const int64_t stride = half ? (int64_t)n : m;
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float chain = 0.f;  // half 0: |x|^2, half 1: |c|^2
+    for (int k0 = 0; k0 < d; k0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = (k0 + u < d) ? src[(int64_t)(k0 + u) * stride] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) chain = fmaf(v[u], v[u], chain);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        // lane (i, half) multiplies dimension 2 j + half: half 0 keeps x[2j] and sends x[2j+1], half 1
+        // keeps c[2j+1] and sends c[2j]
+        const float own = half ? v[2 * j + 1] : v[2 * j];
+        const float got = __shfl_xor(half ? v[2 * j] : v[2 * j + 1], 32, 64);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? own : got, half ? got : own, acc, 0, 0, 0);
+      }
+    }
+    const float other = __shfl_xor(chain, 32, 64);
+    const float x2 = half ? other : chain, c2 = half ? chain : other;
+    // D[row i][col i]: column = l31, row = (r & 3) + 8 (r >> 2) + 4 half
+    const int rsel = (l31 & 3) | ((l31 >> 3) << 2);
+    float dot = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dot = (r == rsel) ? acc[r] : dot;
+    float v = dot;
+    if (euclid) {
+      v = 2.f * v;
+      v = v - x2;
+      v = v - c2;
+    }
+    v = v + 0.f;  // (-0 -> +0: the key orders by bits)
+    if (valid && half == ((l31 >> 2) & 1)) {
+      const unsigned fb = __float_as_uint(v);
+      const unsigned ordered = (fb & 0x80000000u) ? ~fb : (fb | 0x80000000u);
+      atomicMax(keys + p, ((unsigned long long)ordered << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)c));
+    }
+  }
+}
+
+// labels / values of the listed points from their keys; then the fallback switch: the exact kernel runs
+// over the level-1 list iff pairs were dropped or the list outgrew the compact array.  grid (ceil(m / 256))
+__global__ __launch_bounds__(256) void gdecode_kernel(const int* __restrict__ list, const int* __restrict__ count,
+                                                     const unsigned long long* __restrict__ keys,
+                                                     float* __restrict__ vals, int64_t* __restrict__ inds, int m, int cap,
+                                                     const int* __restrict__ overflow, int* __restrict__ count_fb) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int cnt = *count < m ? *count : m;
+  if (p == 0) *count_fb = (*overflow != 0 || cnt > cap) ? cnt : 0;
+  if (p >= cnt) return;
+  const int i = list[p];
+  const unsigned long long key = keys[i];
+  if (key == 0ull) return;  // (beyond the compact array: the fallback's)
+  const unsigned ordered = (unsigned)(key >> 32);
+  const unsigned fb = (ordered & 0x80000000u) ? (ordered & 0x7FFFFFFFu) : ~ordered;
+  inds[i] = (int64_t)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+  if (vals) vals[i] = __uint_as_float(fb);
+}
+
+struct WideLayout {
+  int KS, KAp, U, ncb, ysplit, cap2, cap3, pair_cap;
+  int64_t T;
+  size_t mu_off, scale_off, flag_off, maxbits_off, cmax_off, cflag_off, count1_off, countfb_off, npairs_off, oflag_off,
+      phi_off, norms_off, c1_off, cnorm_off, p2_off, thr_off, pairs_off, partb_off, parti_off, list1_off, keys_off, ac_off,
+      total;
+};
+static WideLayout wide_layout(int d, int64_t m, int n) {
+  WideLayout L;
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  L.KS = (d + 15) / 16;
+  L.KAp = (L.KS + kGK - 1) / kGK * kGK;
+  L.ncb = (n + 255) / 256;
+  L.U = L.ncb * 8;
+  L.T = (m + 255) / 256 * 8;  // whole blocks of 256 points
+  const int64_t pblocks = L.T / 8;
+  L.ysplit = pblocks >= 384 ? 1 : (int)((512 + pblocks - 1) / pblocks);  // fill the chip when the points alone do not
+  if (L.ysplit > L.ncb) L.ysplit = L.ncb;
+  L.cap2 = (int)(((m / 2 > 8192 ? m / 2 : 8192) + 255) / 256 * 256);     // pass 2's compact array, in points
+  if (L.cap2 > L.T * 32) L.cap2 = (int)(L.T * 32);
+  L.pair_cap = 4 * L.cap2 > 65536 ? 4 * L.cap2 : 65536;
+  L.cap3 = (int)((m / 16 + 127) / 128 * 128);  // the fallback's compact copy
+  if (L.cap3 < 128) L.cap3 = 128;
+  L.mu_off = 0;
+  L.scale_off = up((size_t)(d > 128 ? d : 128) * 4);
+  L.flag_off = L.scale_off + 4;
+  L.maxbits_off = L.flag_off + 4;
+  L.cmax_off = L.maxbits_off + 4;
+  L.cflag_off = L.cmax_off + 12;
+  L.count1_off = L.cflag_off + 4;
+  L.countfb_off = L.count1_off + 4;
+  L.npairs_off = L.countfb_off + 4;
+  L.oflag_off = L.npairs_off + 4;
+  L.phi_off = up(L.oflag_off + 4);
+  L.norms_off = up(L.phi_off + (size_t)L.T * L.KAp * 1024);
+  L.c1_off = up(L.norms_off + (size_t)L.T * 32 * 16);
+  L.cnorm_off = up(L.c1_off + (size_t)L.U * L.KAp * 1024);
+  L.p2_off = up(L.cnorm_off + (size_t)L.U * 1024);
+  L.thr_off = up(L.p2_off + (size_t)(L.cap2 / 32) * L.KAp * 1024);
+  L.pairs_off = up(L.thr_off + (size_t)L.cap2 * 4);
+  L.partb_off = up(L.pairs_off + (size_t)L.pair_cap * 8);
+  L.parti_off = up(L.partb_off + (size_t)2 * L.ysplit * (size_t)(L.T * 32) * 8);
+  L.list1_off = up(L.parti_off + (size_t)2 * L.ysplit * (size_t)(L.T * 32) * 4);
+  L.keys_off = up(L.list1_off + (size_t)m * 4);
+  L.ac_off = up(L.keys_off + (size_t)m * 8);
+  L.total = up(L.ac_off + (size_t)d * L.cap3 * 4);
+  return L;
+}
+
+static int run_wide(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n, int euclid,
+                    char* ws, const WideLayout& L, hipStream_t st) {
+  float* mu = reinterpret_cast<float*>(ws + L.mu_off);
+  float* scale = reinterpret_cast<float*>(ws + L.scale_off);
+  int* flag = reinterpret_cast<int*>(ws + L.flag_off);
+  unsigned* maxbits = reinterpret_cast<unsigned*>(ws + L.maxbits_off);
+  unsigned* cmax = reinterpret_cast<unsigned*>(ws + L.cmax_off);
+  int* cflag = reinterpret_cast<int*>(ws + L.cflag_off);
+  int* count1 = reinterpret_cast<int*>(ws + L.count1_off);
+  int* count_fb = reinterpret_cast<int*>(ws + L.countfb_off);
+  int* n_pairs = reinterpret_cast<int*>(ws + L.npairs_off);
+  int* oflag = reinterpret_cast<int*>(ws + L.oflag_off);
+  u32x4* phi = reinterpret_cast<u32x4*>(ws + L.phi_off);
+  float4* norms = reinterpret_cast<float4*>(ws + L.norms_off);
+  u32x4* c1 = reinterpret_cast<u32x4*>(ws + L.c1_off);
+  u32x4* cnorm = reinterpret_cast<u32x4*>(ws + L.cnorm_off);
+  u32x4* p2 = reinterpret_cast<u32x4*>(ws + L.p2_off);
+  float* thr = reinterpret_cast<float*>(ws + L.thr_off);
+  uint2* pairs = reinterpret_cast<uint2*>(ws + L.pairs_off);
+  float2* part_b = reinterpret_cast<float2*>(ws + L.partb_off);
+  int* part_i = reinterpret_cast<int*>(ws + L.parti_off);
+  int* list1 = reinterpret_cast<int*>(ws + L.list1_off);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws + L.keys_off);
+  float* Ac = reinterpret_cast<float*>(ws + L.ac_off);
+  int rc = check_hip(hipMemsetAsync(ws, 0, L.phi_off, st), "coarse_assign (wide) memset");
+  if (rc) return rc;
+  rc = check_hip(hipMemsetAsync(keys, 0, (size_t)m * 8, st), "coarse_assign (wide) keys memset");
+  if (rc) return rc;
+  // (rows beyond m / beyond the list in the last block of 256: an MFMA column depends on its own point only,
+  // and those columns are never written out)
+  if (euclid) {  // (inner products are not shift invariant: mu stays 0)
+    hipLaunchKernelGGL(mu_kernel, dim3(d, 1), dim3(256), 0, st, B, mu, d, n);
+    TPQ_LAUNCH_CHECK("lloyd mu_kernel");
+  }
+  int chunks = (int)(8192 / (int64_t)d);
+  if (chunks < 1) chunks = 1;
+  if ((int64_t)chunks * 4096 > m) chunks = (int)((m + 4095) / 4096);
+  hipLaunchKernelGGL(maxabs_kernel, dim3(chunks, d, 1), dim3(256), 0, st, A, mu, maxbits, flag, d, m);
+  TPQ_LAUNCH_CHECK("lloyd maxabs_kernel");
+  hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(64), 0, st, maxbits, flag, scale, 1);
+  TPQ_LAUNCH_CHECK("lloyd scale_kernel");
+  hipLaunchKernelGGL(gsplit_points_kernel, dim3((unsigned)((L.T + 3) / 4)), dim3(256), 0, st, A, mu, scale, phi, norms,
+                     d, m, L.T, L.KAp);
+  TPQ_LAUNCH_CHECK("lloyd gsplit_points_kernel");
+  hipLaunchKernelGGL(gprep_centroids_kernel, dim3(L.U), dim3(64), 0, st, B, mu, scale, c1, cnorm, cmax, cflag, d, n,
+                     L.KAp, euclid);
+  TPQ_LAUNCH_CHECK("lloyd gprep_centroids_kernel");
+  const size_t lds = (size_t)2 * kGStage + 8 * 1024 + sizeof(PairList);
+  rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "lloyd gemm_kernel attr");
+  if (rc) return rc;
+  rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "lloyd gemm_kernel attr");
+  if (rc) return rc;
+  const int64_t rows1 = L.T * 32;
+  // (gdecide_kernel's comment) accumulation, N, shift rounding, 6-bit keys
+  const float eps = 1.001f * (float)(17 * (L.KS + 1) + 8) / 16777216.0f + 1.0f / 8388608.0f + 1.0f / 4194304.0f +
+                    1.0f / 131072.0f;
+  {  // pass 1
+    GemmArgs ga{c1, phi, cnorm, part_b, part_i, L.KAp, L.ncb, rows1, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+    hipLaunchKernelGGL(gemm_kernel<false>, dim3((unsigned)(L.T / 8), L.ysplit), dim3(kWaves * 64), lds, st, ga);
+    TPQ_LAUNCH_CHECK("lloyd gemm_kernel");
+    GDecideArgs da{part_b, part_i, 2 * L.ysplit, rows1, norms, cmax, scale, flag, cflag, inds, vals, list1, count1,
+                   thr, L.cap2, (int)m, eps, (float)(d + 4) / 16777216.0f, sqrtf((float)d) / 8192.0f, euclid};
+    hipLaunchKernelGGL(gdecide_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, da);
+    TPQ_LAUNCH_CHECK("lloyd gdecide_kernel");
+  }
+  {  // pass 2: the candidates of the undecided points
+    hipLaunchKernelGGL(ggather_kernel, dim3((unsigned)(L.cap2 / 32)), dim3(64), 0, st, phi, list1, count1, p2, L.KAp,
+                       L.cap2);
+    TPQ_LAUNCH_CHECK("lloyd ggather_kernel");
+    const int ys2 = L.ncb < 4 ? L.ncb : 4;  // (few point blocks: split the centroid blocks)
+    GemmArgs ga{c1, p2, cnorm, nullptr, nullptr, L.KAp, L.ncb, (int64_t)L.cap2, count1, thr, pairs, n_pairs, L.pair_cap,
+                oflag};
+    hipLaunchKernelGGL(gemm_kernel<true>, dim3((unsigned)(L.cap2 / 256), ys2), dim3(kWaves * 64), lds, st, ga);
+    TPQ_LAUNCH_CHECK("lloyd gemm_kernel (candidates)");
+  }
+  // pass 3: exact values of the pairs
+  hipLaunchKernelGGL(pair_exact_kernel, dim3(2048), dim3(256), 0, st, A, B, pairs, n_pairs, L.pair_cap, list1, keys, d,
+                     m, n, euclid);
+  TPQ_LAUNCH_CHECK("lloyd pair_exact_kernel");
+  hipLaunchKernelGGL(gdecode_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, list1, count1, keys, vals, inds,
+                     (int)m, L.cap2, oflag, count_fb);
+  TPQ_LAUNCH_CHECK("lloyd gdecode_kernel");
+  // (normally over zero points)
+  return launch_max_sim_list(A, B, vals, inds, 1, d, (int)m, n, euclid, list1, count_fb, keys, Ac, L.cap3, st);
+}
+
 }  // namespace lloyd
 
 // hooks for tpq_coarse_assign (assign_fast.hip): the cascade takes euclidean problems with d <= 128
@@ -1564,10 +2211,19 @@ int lloyd_assign_supported(int d, int64_t m, int n) {
   const lloyd::PrepLayout P = lloyd::prep_layout(1, d, m);
   return (P.T * ((P.KS + 1) / 2) * 2048 <= 0x7fffffffLL && (int64_t)d * m * 4 <= 0x7fffffffLL) ? 1 : 0;
 }
-size_t lloyd_assign_workspace_bytes(int d, int64_t m, int n) { return lloyd::assign_layout(d, m, n).total; }
-size_t lloyd_assign_count_offset(int d, int64_t m, int n) { return lloyd::assign_layout(d, m, n).count2_off; }
-int lloyd_assign(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n, char* ws,
-                 hipStream_t st) {
+// 128 < d <= 1024: the GEMM-shaped cascade (euclidean)
+int lloyd_wide_supported(int d, int64_t m, int n) {
+  return (d > 128 && d <= 1024 && n >= 1 && n <= (1 << 22) && m >= 1 && m < (1LL << 28)) ? 1 : 0;
+}
+size_t lloyd_assign_workspace_bytes(int d, int64_t m, int n) {
+  return d > 128 ? lloyd::wide_layout(d, m, n).total : lloyd::assign_layout(d, m, n).total;
+}
+size_t lloyd_assign_count_offset(int d, int64_t m, int n) {  // wide: the points with an exact step (candidates)
+  return d > 128 ? lloyd::wide_layout(d, m, n).count1_off : lloyd::assign_layout(d, m, n).count2_off;
+}
+int lloyd_assign(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n, int euclid,
+                 char* ws, hipStream_t st) {
+  if (d > 128) return lloyd::run_wide(A, B, vals, inds, d, m, n, euclid, ws, lloyd::wide_layout(d, m, n), st);
   const lloyd::AssignLayout L = lloyd::assign_layout(d, m, n);
   switch (L.KS) {
     case 1: return lloyd::run_assign<1>(A, B, vals, inds, d, m, n, ws, L, st);
