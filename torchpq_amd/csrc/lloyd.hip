@@ -1598,6 +1598,8 @@ struct GemmArgs {
   int* part_i;           // pass 1: [2 * ysplit][rows] centroid index
   int KA;                // k-steps of the operands (multiple of kGK)
   int n_cblocks;         // blocks of 256 centroids
+  int ysplit;            // 1, 2, 4 or 8 ranges of centroid blocks (see the block mapping in the kernel)
+  int pblocks;           // blocks of 256 points the grid covers
   int64_t rows;          // points (pass 1) / capacity of the compact array (pass 2)
   const int* count_in;   // pass 2: number of listed points on the device (rows = min(this, capacity))
   const float* thr;      // pass 2: [capacity] threshold of the listed point
@@ -1608,7 +1610,7 @@ struct GemmArgs {
 };
 
 // the block's staged pairs -> the global list.  Called by all threads, at points where nobody appends.
-__device__ __forceinline__ void flush_pairs(const GemmArgs& a, PairList* pl) {
+__device__ __forceinline__ void flush_pairs(const GemmArgs& a, PairList* pl, unsigned row0) {
   if (threadIdx.x == 0) {
     const int n = pl->n < kPairList ? pl->n : kPairList;
     if (pl->n > kPairList) atomicOr(a.overflow, 1);
@@ -1616,10 +1618,10 @@ __device__ __forceinline__ void flush_pairs(const GemmArgs& a, PairList* pl) {
   }
   __syncthreads();
   const int n = pl->n < kPairList ? pl->n : kPairList, base = pl->base;
-  for (int i = threadIdx.x; i < n; i += kWaves * 64) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const unsigned e = pl->item[i];
     if (base + i < a.pair_cap)
-      a.pairs[base + i] = make_uint2(blockIdx.x * 256u + (e >> 22), e & 0x3fffffu);
+      a.pairs[base + i] = make_uint2(row0 + (e >> 22), e & 0x3fffffu);
     else
       atomicOr(a.overflow, 1);
   }
@@ -1627,49 +1629,68 @@ __device__ __forceinline__ void flush_pairs(const GemmArgs& a, PairList* pl) {
   if (threadIdx.x == 0) pl->n = 0;
 }
 
-template <bool CAND>
-__global__ __launch_bounds__(kWaves * 64) void gemm_kernel(GemmArgs a) {
+// CT = point column tiles per wave: 2 -> 8 waves as 4 point slabs x 2 centroid halves (wave tile 128 x 64),
+// 4 -> 4 waves as 2 x 2 (wave tile 128 x 128, one wave per SIMD, 16 accumulators)
+template <bool CAND, int CT>
+__global__ __launch_bounds__(CT == 2 ? 512 : 256) void gemm_kernel(GemmArgs a) {
+  constexpr int NW = CT == 2 ? 8 : 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages, the block's -N fragments (8 KiB), PairList
   int64_t rows = a.rows;
   if (CAND) {
     const int c = *a.count_in;
     rows = c < a.rows ? c : a.rows;
   }
-  if ((int64_t)blockIdx.x * 256 >= rows) return;  // block-uniform
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // Block -> (point block pb, centroid range yi), XCD-aware.  A 256 x 256 tile streams 2 x 480 KiB at d = 960 and
+  // every point block meets every centroid block: with one point block per CU walking all centroids, the 32
+  // CUs of an XCD share the centroid stream but re-read 32 x 480 KiB = 15 MiB of point fragments per step --
+  // four times their 4-MiB L2, i.e. from the Infinity Cache every time.  So the 32 blocks an XCD runs
+  // side by side (the dispatcher deals block b to XCD b % 8, in order) are P = 32 / ysplit point blocks x
+  // ysplit centroid ranges: per step they stream P + ysplit tiles instead of 33 (ysplit = 8: 12).
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, ys = a.ysplit, P = 32 / ys;
+  const int pb = ((slot >> 5) * 8 + xcd) * P + (slot & 31) / ys, yi = (slot & 31) % ys;
+  if (pb >= a.pblocks || (int64_t)pb * 256 >= rows) return;  // block-uniform
+  // (the wave number as a SCALAR: everything derived from it -- the addresses of the LDS-DMA fills above all --
+  // is then SALU work; as a vector it was 6 VALU instructions per MFMA in the issue slots the MFMAs need)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int l31 = lane & 31, half = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;  // point slab (64 points), centroid half (128 centroids)
-  const int cb_per = (a.n_cblocks + gridDim.y - 1) / gridDim.y;
-  const int cb0 = blockIdx.y * cb_per, cb1 = (cb0 + cb_per) < a.n_cblocks ? (cb0 + cb_per) : a.n_cblocks;
+  const int cb_per = (a.n_cblocks + ys - 1) / ys;
+  const int cb0 = yi * cb_per, cb1 = (cb0 + cb_per) < a.n_cblocks ? (cb0 + cb_per) : a.n_cblocks;
   if (cb0 >= cb1) return;
   const int n_kst = a.KA / kGK;  // stages per centroid block (>= 3: d > 128)
   const int n_stage = (cb1 - cb0) * n_kst;
   char* nbuf = smem + 2 * kGStage;
   PairList* pl = reinterpret_cast<PairList*>(nbuf + 8 * 1024);
   if (CAND && threadIdx.x == 0) pl->n = 0;
-  // stage g = (centroid block cb0 + g / n_kst, k-steps [kGK (g % n_kst), + kGK)) -> buffer g & 1: units
-  // 0..7 then point tiles 0..7, each kGK consecutive 1-KiB fragments
-  auto stage = [&](int g) {
-    const int cb = cb0 + g / n_kst, k0 = (g % n_kst) * kGK;
-    char* dst = smem + (g & 1) * kGStage;
-    for (int f = wave; f < 16 * kGK; f += kWaves) {
-      const int who = f / kGK, kk = f % kGK;  // 0..7 centroid units, 8..15 point tiles
-      const char* src = who < 8 ? reinterpret_cast<const char*>(a.cfr) + (((size_t)(cb * 8 + who)) * a.KA + k0 + kk) * 1024
-                                : reinterpret_cast<const char*>(a.pfr) +
-                                      (((size_t)blockIdx.x * 8 + (who - 8)) * a.KA + k0 + kk) * 1024;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 16),
+  // stage (centroid block cb, k-steps [kGK kst, + kGK)) -> buffer buf: units 0..7 then point tiles 0..7, each
+  // kGK consecutive 1-KiB fragments
+  const unsigned lane16 = lane * 16;
+  auto stage = [&](int cb, int kst, int buf) {
+    char* dst = smem + buf * kGStage;
+    const char* csrc = reinterpret_cast<const char*>(a.cfr) + ((size_t)cb * 8 * a.KA + kst * kGK) * 1024;
+    const char* psrc = reinterpret_cast<const char*>(a.pfr) + ((size_t)pb * 8 * a.KA + kst * kGK) * 1024;
+#pragma unroll
+    for (int i = 0; i < 8 * kGK / NW; ++i) {  // this wave's share of the 8 kGK centroid fragments, then of the points'
+      const int f = wave + i * NW, who = f / kGK, kk = f % kGK;
+      const size_t off = ((size_t)who * a.KA + kk) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(csrc + off + lane16),
                                        (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(psrc + off + lane16),
+                                       (__attribute__((address_space(3))) void*)(dst + (8 * kGK + f) * 1024), 16, 0, 0);
     }
   };
-  stage(0);
-  f32x16 acc[4][2];  // [centroid row tile of this wave's half][point column tile of its slab]
-  float b1[2] = {-INFINITY, -INFINITY}, b2[2] = {-INFINITY, -INFINITY};
-  int bu[2] = {0, 0};
-  float thr[2] = {INFINITY, INFINITY};
-  if (CAND) {
+  stage(cb0, 0, 0);
+  f32x16 acc[4][CT];  // [centroid row tile of this wave's half][point column tile of its slab]
+  float b1[CT], b2[CT], thr[CT];
+  int bu[CT];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const int64_t row = (int64_t)blockIdx.x * 256 + wr * 64 + ct * 32 + l31;
+  for (int ct = 0; ct < CT; ++ct) {
+    b1[ct] = -INFINITY;
+    b2[ct] = -INFINITY;
+    bu[ct] = 0;
+    thr[ct] = INFINITY;
+    if (CAND) {
+      const int64_t row = (int64_t)pb * 256 + wr * (CT * 32) + ct * 32 + l31;
       if (row < rows) thr[ct] = a.thr[row];
     }
   }
@@ -1680,72 +1701,90 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_kernel(GemmArgs a) {
     bones[2] = (__bf16)1.0f;
   }
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int cb = cb0, kst = 0;
 #pragma unroll 1
-  for (int g = 0; g < n_stage; ++g) {
-    __syncthreads();  // stage g has landed; everyone is done with the other buffer (and with nbuf)
-    if (g + 1 < n_stage) stage(g + 1);
-    const int kst = g % n_kst;
-    if (kst == 0) {  // a new centroid block: its -N fragments (8 KiB; read after the K loop) and fresh accumulators
-      const int cb = cb0 + g / n_kst;
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(a.cnorm) +
-                                                         ((size_t)cb * 8 + wave) * 1024 + lane * 16),
-          (__attribute__((address_space(3))) void*)(nbuf + wave * 1024), 16, 0, 0);
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        acc[rt][0] = zero;
-        acc[rt][1] = zero;
-      }
-      // (pairs are appended in the epilogue of the previous centroid block, before the barrier above:
-      // pl->n is stable here, and the condition uniform)
-      if (CAND && pl->n >= kPairList / 2) flush_pairs(a, pl);
+  for (int g = 0; g < n_stage; ++g, ++kst) {
+    if (kst == n_kst) {
+      kst = 0;
+      ++cb;
     }
-    const u32x4* sb = reinterpret_cast<const u32x4*>(smem + (g & 1) * kGStage) + lane;
-#pragma unroll
-    for (int kk = 0; kk < kGK; ++kk) {
-      f16x8 af[4], bf[2];
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) af[rt] = __builtin_bit_cast(f16x8, sb[((wc * 4 + rt) * kGK + kk) * 64]);
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) bf[ct] = __builtin_bit_cast(f16x8, sb[((8 + wr * 2 + ct) * kGK + kk) * 64]);
+    __syncthreads();  // stage g has landed; everyone is done with the other buffer (and with nbuf)
+    if (g + 1 < n_stage) {
+      const bool wrap = kst + 1 == n_kst;
+      stage(wrap ? cb + 1 : cb, wrap ? 0 : kst + 1, (g + 1) & 1);
+    }
+    if (kst == 0) {  // a new centroid block: its -N fragments (8 KiB; read after the K loop) and fresh accumulators
+      for (int f = wave; f < 8; f += NW)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(a.cnorm) +
+                                                           ((size_t)cb * 8 + f) * 1024 + lane * 16),
+            (__attribute__((address_space(3))) void*)(nbuf + f * 1024), 16, 0, 0);
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-          acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[rt], bf[ct], acc[rt][ct], 0, 0, 0);
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = zero;
+      // (pairs are appended in the epilogue of the previous centroid block, before the barrier above:
+      // pl->n is stable here, and the condition uniform)
+      if (CAND && pl->n >= kPairList / 2) flush_pairs(a, pl, pb * 256u);
     }
-    if (kst == n_kst - 1) {  // the centroid block is complete: -N, then the epilogue over 2 x 64 values per lane
-      const int cb = cb0 + g / n_kst;
+    const u32x4* sb = reinterpret_cast<const u32x4*>(smem + (g & 1) * kGStage) + lane;
+    // software pipeline inside the stage: the 4 + CT fragments of k-step kk + 1 are read before the MFMAs of
+    // k-step kk issue (left to itself the compiler reads ONE A fragment, waits, issues its CT MFMAs, reads the next)
+    f16x8 af[2][4], bf[2][CT];
+    auto read_frags = [&](int kk, int set) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) af[set][rt] = __builtin_bit_cast(f16x8, sb[((wc * 4 + rt) * kGK + kk) * 64]);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+        bf[set][ct] = __builtin_bit_cast(f16x8, sb[((8 + wr * CT + ct) * kGK + kk) * 64]);
+    };
+    read_frags(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < kGK; ++kk) {
+      if (kk + 1 < kGK) read_frags(kk + 1, (kk + 1) & 1);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1][rt], bf[kk & 1][ct], acc[rt][ct], 0, 0, 0);
+      if (kk + 1 < kGK) __builtin_amdgcn_sched_group_barrier(0x100, 4 + CT, 0);  // DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * CT, 0);                      // MFMA
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kst == n_kst - 1) {  // the centroid block is complete: -N, then the epilogue over CT x 64 values per lane
       // (nbuf was requested n_kst stages ago and every barrier since waited for vmcnt(0))
       const u32x4* nb = reinterpret_cast<const u32x4*>(nbuf) + lane;
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         const bf16x8 cf = __builtin_bit_cast(bf16x8, nb[(wc * 4 + rt) * 64]);
-        acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf, bones, acc[rt][0], 0, 0, 0);
-        acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf, bones, acc[rt][1], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf, bones, acc[rt][ct], 0, 0, 0);
       }
       if (!CAND) {
-        const float before0 = b1[0], before1 = b1[1];
+        float before[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) before[ct] = b1[ct];
         static_for<0, 4>([&](auto rt_c) {
           constexpr int rt = decltype(rt_c)::value;
-          static_for<0, 16>([&](auto q_c) {  // 8 register pairs x 2 column tiles
-            constexpr int q = decltype(q_c)::value, ct = q & 1, pq = q >> 1;
+          static_for<0, 8 * CT>([&](auto q_c) {  // 8 register pairs x CT column tiles
+            constexpr int q = decltype(q_c)::value, ct = q % CT, pq = q / CT;
             top2_keys_pair(b1[ct], b2[ct], key6<16 * rt + 2 * pq>(acc[rt][ct][2 * pq]),
                            key6<16 * rt + 2 * pq + 1>(acc[rt][ct][2 * pq + 1]));
           });
         });
-        bu[0] = b1[0] > before0 ? cb : bu[0];
-        bu[1] = b1[1] > before1 ? cb : bu[1];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) bu[ct] = b1[ct] > before[ct] ? cb : bu[ct];
       } else {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) {
+          for (int ct = 0; ct < CT; ++ct) {
             float mx = acc[rt][ct][0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[rt][ct][r]);
             if (__ballot(mx >= thr[ct]) == 0ull) continue;  // (nearly every tile)
-            const unsigned rowbits = (unsigned)(wr * 64 + ct * 32 + l31) << 22;
+            const unsigned rowbits = (unsigned)(wr * (CT * 32) + ct * 32 + l31) << 22;
             const int cbase = cb * 256 + wc * 128 + rt * 32 + 4 * half;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1766,12 +1805,12 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_kernel(GemmArgs a) {
   }
   if (CAND) {
     __syncthreads();
-    flush_pairs(a, pl);
+    flush_pairs(a, pl, pb * 256u);
     return;
   }
   // this wave's (best, second, index) of its 2 x 32 points over its centroid half of every block
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
+  for (int ct = 0; ct < CT; ++ct) {
     const int tag = __float_as_int(b1[ct]) & 63, r0 = tag & 15;
     int idx = bu[ct] * 256 + wc * 128 + (tag >> 4) * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * half;
     const float m1 = b1[ct], m2 = b2[ct];
@@ -1780,9 +1819,9 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_kernel(GemmArgs a) {
     const float B1 = fmaxf(m1, o1);
     const float B2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
     if (o1 > m1 || (o1 == m1 && oi < idx)) idx = oi;
-    const int64_t row = (int64_t)blockIdx.x * 256 + wr * 64 + ct * 32 + l31;
+    const int64_t row = (int64_t)pb * 256 + wr * (CT * 32) + ct * 32 + l31;
     if (half == 0 && row < rows) {
-      const int64_t slot = (int64_t)(blockIdx.y * 2 + wc) * a.rows + row;
+      const int64_t slot = (int64_t)(yi * 2 + wc) * a.rows + row;
       a.part_b[slot] = make_float2(B1, B2);
       a.part_i[slot] = idx;
     }
@@ -1980,16 +2019,48 @@ __global__ __launch_bounds__(256) void gdecide_kernel(GDecideArgs a) {
   }
 }
 
+// pass 3 reads ROWS: a (point, centroid) pair needs one column of A [d][m] and one of B [d][n] -- 4 useful bytes
+// per 64-byte sector as they lie (7 ms for 400 000 pairs at d = 960).  rows_kernel copies the columns it is given
+// into rows out[j][dp] (dp = d rounded up to 16, zero padded): all centroids once per call (63 MB at 16 384 x
+// 960), and the listed points (their columns are ascending and ~5 apart: a few sectors per dimension).
+// grid (ceil(count / 32)), 64 lanes: lane (column i, half) gathers 16 consecutive dimensions, stores 64 B.
+__global__ __launch_bounds__(64) void rows_kernel(const float* __restrict__ M, int64_t cols, const int* __restrict__ list,
+                                                 const int* __restrict__ count, int cap, float* __restrict__ out, int d,
+                                                 int dp) {
+  const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+  int cnt = cap;
+  if (count) {
+    cnt = *count;
+    cnt = cnt < cap ? cnt : cap;
+  }
+  if ((int64_t)blockIdx.x * 32 >= cnt) return;
+  const int j = blockIdx.x * 32 + l31;
+  const bool valid = j < cnt;
+  const int64_t col = valid ? (list ? list[j] : j) : 0;
+  const float* src = M + col;
+  float* dst = out + (int64_t)j * dp;
+  for (int k0 = 16 * half; k0 < dp; k0 += 32) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = (k0 + u < d) ? src[(int64_t)(k0 + u) * cols] : 0.f;
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(dst + k0 + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+  }
+}
+
 // pass 3: the exact kernel's value of every (listed point, candidate centroid) pair, folded into keys[point].
-// A wave takes 32 pairs: lane (pair i, half); half 0 streams the point's column of A, half 1 the centroid's
-// column of B -- each the ascending-k fma chain of its squared norm as max_sim_kernel forms it -- and per
-// pair of dimensions the halves swap what the other needs as MFMA operand (row i = centroid of pair i,
-// column i = point of pair i: the diagonal of the 32 x 32 tile holds the 32 results).
-__global__ __launch_bounds__(256) void pair_exact_kernel(const float* __restrict__ A, const float* __restrict__ B,
+// A wave takes 32 pairs: lane (pair i, half); half 0 streams the point's row, half 1 the centroid's row -- each
+// the ascending-k fma chain of its squared norm as max_sim_kernel forms it -- and per pair of dimensions
+// the halves swap what the other needs as MFMA operand (row i = centroid of pair i, column i = point of pair
+// i: the diagonal of the 32 x 32 tile holds the 32 results).  The zero padding beyond d adds +0 to chains and
+// products alike.
+__global__ __launch_bounds__(256) void pair_exact_kernel(const float* __restrict__ Xt, const float* __restrict__ Bt,
                                                         const uint2* __restrict__ pairs, const int* __restrict__ pair_count,
                                                         int pair_cap, const int* __restrict__ list,
-                                                        unsigned long long* __restrict__ keys, int d, int64_t m, int n,
-                                                        int euclid) {
+                                                        unsigned long long* __restrict__ keys, int dp, int euclid) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
   int cnt = *pair_count;
   cnt = cnt < pair_cap ? cnt : pair_cap;
@@ -2000,14 +2071,19 @@ __global__ __launch_bounds__(256) void pair_exact_kernel(const float* __restrict
     const uint2 pr = valid ? pairs[q] : make_uint2(0u, 0u);
     const int p = valid ? list[pr.x] : 0;
     const int c = (int)pr.y;
-    const float* src = half ? B + c : A + p;
-    const int64_t stride = half ? (int64_t)n : m;
+    const float4* src = reinterpret_cast<const float4*>(half ? Bt + (int64_t)c * dp : Xt + (int64_t)pr.x * dp);
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float chain = 0.f;  // half 0: |x|^2, half 1: |c|^2
-    for (int k0 = 0; k0 < d; k0 += 16) {
+    for (int k0 = 0; k0 < dp; k0 += 16) {
       float v[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = (k0 + u < d) ? src[(int64_t)(k0 + u) * stride] : 0.f;
+      for (int u = 0; u < 4; ++u) {
+        const float4 t = src[(k0 >> 2) + u];
+        v[4 * u] = t.x;
+        v[4 * u + 1] = t.y;
+        v[4 * u + 2] = t.z;
+        v[4 * u + 3] = t.w;
+      }
 #pragma unroll
       for (int u = 0; u < 16; ++u) chain = fmaf(v[u], v[u], chain);
 #pragma unroll
@@ -2065,7 +2141,8 @@ struct WideLayout {
   int64_t T;
   size_t mu_off, scale_off, flag_off, maxbits_off, cmax_off, cflag_off, count1_off, countfb_off, npairs_off, oflag_off,
       phi_off, norms_off, c1_off, cnorm_off, p2_off, thr_off, pairs_off, partb_off, parti_off, list1_off, keys_off, ac_off,
-      total;
+      bt_off, xt_off, total;
+  int dp;
 };
 static WideLayout wide_layout(int d, int64_t m, int n) {
   WideLayout L;
@@ -2075,9 +2152,8 @@ static WideLayout wide_layout(int d, int64_t m, int n) {
   L.ncb = (n + 255) / 256;
   L.U = L.ncb * 8;
   L.T = (m + 255) / 256 * 8;  // whole blocks of 256 points
-  const int64_t pblocks = L.T / 8;
-  L.ysplit = pblocks >= 384 ? 1 : (int)((512 + pblocks - 1) / pblocks);  // fill the chip when the points alone do not
-  if (L.ysplit > L.ncb) L.ysplit = L.ncb;
+  L.ysplit = L.ncb >= 8 ? 8 : (L.ncb >= 4 ? 4 : (L.ncb >= 2 ? 2 : 1));  // (gemm_kernel's block mapping)
+  if (const char* e = getenv("TPQ_WIDE_YSPLIT")) L.ysplit = atoi(e);  // (A/B; 1, 2, 4, 8)
   L.cap2 = (int)(((m / 2 > 8192 ? m / 2 : 8192) + 255) / 256 * 256);     // pass 2's compact array, in points
   if (L.cap2 > L.T * 32) L.cap2 = (int)(L.T * 32);
   L.pair_cap = 4 * L.cap2 > 65536 ? 4 * L.cap2 : 65536;
@@ -2105,8 +2181,17 @@ static WideLayout wide_layout(int d, int64_t m, int n) {
   L.list1_off = up(L.parti_off + (size_t)2 * L.ysplit * (size_t)(L.T * 32) * 4);
   L.keys_off = up(L.list1_off + (size_t)m * 4);
   L.ac_off = up(L.keys_off + (size_t)m * 8);
-  L.total = up(L.ac_off + (size_t)d * L.cap3 * 4);
+  L.dp = (d + 15) / 16 * 16;
+  L.bt_off = up(L.ac_off + (size_t)d * L.cap3 * 4);            // [n][dp] f32: the centroids as rows
+  L.xt_off = up(L.bt_off + (size_t)n * L.dp * 4);              // [cap2][dp] f32: the listed points as rows
+  L.total = up(L.xt_off + (size_t)L.cap2 * L.dp * 4);
   return L;
+}
+
+// blocks of gemm_kernel: whole groups of 8 XCDs x 32 blocks (P point blocks x ysplit ranges each)
+static unsigned gemm_grid(int pblocks, int ysplit) {
+  const int per_group = 8 * (32 / ysplit);
+  return (unsigned)((pblocks + per_group - 1) / per_group) * 256u;
 }
 
 static int run_wide(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n, int euclid,
@@ -2133,6 +2218,8 @@ static int run_wide(const float* A, const float* B, float* vals, int64_t* inds, 
   int* list1 = reinterpret_cast<int*>(ws + L.list1_off);
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws + L.keys_off);
   float* Ac = reinterpret_cast<float*>(ws + L.ac_off);
+  float* Bt = reinterpret_cast<float*>(ws + L.bt_off);
+  float* Xt = reinterpret_cast<float*>(ws + L.xt_off);
   int rc = check_hip(hipMemsetAsync(ws, 0, L.phi_off, st), "coarse_assign (wide) memset");
   if (rc) return rc;
   rc = check_hip(hipMemsetAsync(keys, 0, (size_t)m * 8, st), "coarse_assign (wide) keys memset");
@@ -2157,21 +2244,29 @@ static int run_wide(const float* A, const float* B, float* vals, int64_t* inds, 
                      L.KAp, euclid);
   TPQ_LAUNCH_CHECK("lloyd gprep_centroids_kernel");
   const size_t lds = (size_t)2 * kGStage + 8 * 1024 + sizeof(PairList);
-  rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "lloyd gemm_kernel attr");
+  static const int tile_ct = getenv("TPQ_WIDE_CT") ? atoi(getenv("TPQ_WIDE_CT")) : 2;  // (A/B of the wave tile)
+  const auto k_top2 = tile_ct == 4 ? gemm_kernel<false, 4> : gemm_kernel<false, 2>;
+  const auto k_cand = tile_ct == 4 ? gemm_kernel<true, 4> : gemm_kernel<true, 2>;
+  const int gemm_threads = tile_ct == 4 ? 256 : 512;
+  rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(k_top2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds), "lloyd gemm_kernel attr");
   if (rc) return rc;
-  rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "lloyd gemm_kernel attr");
+  rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cand), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds), "lloyd gemm_kernel attr");
   if (rc) return rc;
   const int64_t rows1 = L.T * 32;
   // (gdecide_kernel's comment) accumulation, N, shift rounding, 6-bit keys
   const float eps = 1.001f * (float)(17 * (L.KS + 1) + 8) / 16777216.0f + 1.0f / 8388608.0f + 1.0f / 4194304.0f +
                     1.0f / 131072.0f;
   {  // pass 1
-    GemmArgs ga{c1, phi, cnorm, part_b, part_i, L.KAp, L.ncb, rows1, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
-    hipLaunchKernelGGL(gemm_kernel<false>, dim3((unsigned)(L.T / 8), L.ysplit), dim3(kWaves * 64), lds, st, ga);
+    const int pblocks = (int)(L.T / 8);
+    GemmArgs ga{c1, phi, cnorm, part_b, part_i, L.KAp, L.ncb, L.ysplit, pblocks, rows1, nullptr, nullptr, nullptr, nullptr,
+                0, nullptr};
+    hipLaunchKernelGGL(k_top2, dim3(gemm_grid(pblocks, L.ysplit)), dim3(gemm_threads), lds, st, ga);
     TPQ_LAUNCH_CHECK("lloyd gemm_kernel");
-    GDecideArgs da{part_b, part_i, 2 * L.ysplit, rows1, norms, cmax, scale, flag, cflag, inds, vals, list1, count1,
+    // (ranges of ceil(ncb / ysplit) centroid blocks: the last ones may be empty and write nothing)
+    const int cb_per = (L.ncb + L.ysplit - 1) / L.ysplit, yused = (L.ncb + cb_per - 1) / cb_per;
+    GDecideArgs da{part_b, part_i, 2 * yused, rows1, norms, cmax, scale, flag, cflag, inds, vals, list1, count1,
                    thr, L.cap2, (int)m, eps, (float)(d + 4) / 16777216.0f, sqrtf((float)d) / 8192.0f, euclid};
     hipLaunchKernelGGL(gdecide_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, da);
     TPQ_LAUNCH_CHECK("lloyd gdecide_kernel");
@@ -2180,15 +2275,19 @@ static int run_wide(const float* A, const float* B, float* vals, int64_t* inds, 
     hipLaunchKernelGGL(ggather_kernel, dim3((unsigned)(L.cap2 / 32)), dim3(64), 0, st, phi, list1, count1, p2, L.KAp,
                        L.cap2);
     TPQ_LAUNCH_CHECK("lloyd ggather_kernel");
-    const int ys2 = L.ncb < 4 ? L.ncb : 4;  // (few point blocks: split the centroid blocks)
-    GemmArgs ga{c1, p2, cnorm, nullptr, nullptr, L.KAp, L.ncb, (int64_t)L.cap2, count1, thr, pairs, n_pairs, L.pair_cap,
-                oflag};
-    hipLaunchKernelGGL(gemm_kernel<true>, dim3((unsigned)(L.cap2 / 256), ys2), dim3(kWaves * 64), lds, st, ga);
+    GemmArgs ga{c1, p2, cnorm, nullptr, nullptr, L.KAp, L.ncb, L.ysplit, L.cap2 / 256, (int64_t)L.cap2, count1, thr, pairs,
+                n_pairs, L.pair_cap, oflag};
+    hipLaunchKernelGGL(k_cand, dim3(gemm_grid(L.cap2 / 256, L.ysplit)), dim3(gemm_threads), lds, st, ga);
     TPQ_LAUNCH_CHECK("lloyd gemm_kernel (candidates)");
   }
   // pass 3: exact values of the pairs
-  hipLaunchKernelGGL(pair_exact_kernel, dim3(2048), dim3(256), 0, st, A, B, pairs, n_pairs, L.pair_cap, list1, keys, d,
-                     m, n, euclid);
+  hipLaunchKernelGGL(rows_kernel, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, st, B, (int64_t)n,
+                     static_cast<const int*>(nullptr), static_cast<const int*>(nullptr), n, Bt, d, L.dp);
+  TPQ_LAUNCH_CHECK("lloyd rows_kernel");
+  hipLaunchKernelGGL(rows_kernel, dim3((unsigned)(L.cap2 / 32)), dim3(64), 0, st, A, m, list1, count1, L.cap2, Xt, d, L.dp);
+  TPQ_LAUNCH_CHECK("lloyd rows_kernel");
+  hipLaunchKernelGGL(pair_exact_kernel, dim3(2048), dim3(256), 0, st, Xt, Bt, pairs, n_pairs, L.pair_cap, list1, keys,
+                     L.dp, euclid);
   TPQ_LAUNCH_CHECK("lloyd pair_exact_kernel");
   hipLaunchKernelGGL(gdecode_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, list1, count1, keys, vals, inds,
                      (int)m, L.cap2, oflag, count_fb);
