@@ -757,11 +757,12 @@ def test_coarse_assign_labels_equal_the_exact_kernel_and_the_oracle(K, d, m, n, 
 def test_coarse_assign_argument_errors(K):
     from torchpq_amd import _lib
     lib = _lib.load()
-    assert not K.CoarseAssignHip.supported(129, 1000, 256)
-    A, B = T(np.zeros((129, 8), np.float32)), T(np.zeros((129, 4), np.float32))
+    assert K.CoarseAssignHip.supported(129, 1000, 256)      # (wide vectors: tests/test_gpu_wide_assign.py)
+    assert not K.CoarseAssignHip.supported(1025, 1000, 256)
+    A, B = T(np.zeros((1025, 8), np.float32)), T(np.zeros((1025, 4), np.float32))
     out = torch.empty(8, device=DEV, dtype=torch.int64)
     ws = torch.empty(1 << 20, device=DEV, dtype=torch.uint8)
-    rc = lib.tpq_coarse_assign(_lib.ptr(A), _lib.ptr(B), None, _lib.ptr(out), 129, 8, 4, _lib.METRIC_NEG_SQ_L2,
+    rc = lib.tpq_coarse_assign(_lib.ptr(A), _lib.ptr(B), None, _lib.ptr(out), 1025, 8, 4, _lib.METRIC_NEG_SQ_L2,
                                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(DEV))
     assert rc == _lib.ERR_UNSUPPORTED and b"coarse_assign" in lib.tpq_last_error()
     A, B = T(np.zeros((64, 800), np.float32)), T(np.zeros((64, 400), np.float32))

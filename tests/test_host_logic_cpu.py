@@ -168,7 +168,8 @@ def test_assign_path_policy_and_host_side_shape_functions():
     assert mk._assign_path(120, 8, 100_000, 256, training=True) == "fp32"      # GIST's d_sub = 8
     # one problem, many centroids: coarse assign; batched with > 256 centroids: split kernel
     assert mk._assign_path(1, 128, 1_000_000, 16384, training=True) == "coarse"
-    assert mk._assign_path(1, 960, 500_000, 1024, training=True) == "fp32"     # d > 128
+    assert mk._assign_path(1, 960, 500_000, 1024, training=True) == "coarse"   # wide vectors: the GEMM-shaped cascade
+    assert mk._assign_path(1, 1025, 500_000, 1024, training=True) == "fp32"    # d > 1024
     assert mk._assign_path(4, 64, 100_000, 512, training=True) == "bf16x3"
     assert MultiKMeans(n_clusters=256, assign_precision="fp32")._assign_path(64, 64, 10 ** 6, 256, True) == "fp32"
     # shape functions
@@ -178,7 +179,10 @@ def test_assign_path_policy_and_host_side_shape_functions():
     ws = lib.tpq_max_sim_select_workspace_bytes(64, 64, 1_000_000, 256)
     assert 64 * 1_000_000 * 4 <= ws <= 64 * 1_000_000 * 4 + (8 << 20)         # the lists dominate
     assert lib.tpq_coarse_assign_supported(128, 1 << 20, 16384) == 1
-    assert lib.tpq_coarse_assign_supported(129, 1000, 16) == 0
+    assert lib.tpq_coarse_assign_supported(129, 1000, 16) == 1 and lib.tpq_coarse_assign_supported(960, 10 ** 6, 16384) == 1
+    assert lib.tpq_coarse_assign_supported(1025, 1000, 16) == 0 and lib.tpq_coarse_assign_supported(960, 1 << 28, 16) == 0
+    ws960 = lib.tpq_coarse_assign_workspace_bytes(960, 10 ** 6, 16384)
+    assert 2 * 960 * 10 ** 6 <= ws960 <= 4 * 4 * 960 * 10 ** 6                # fp16 pieces + the listed points' copies
     assert lib.tpq_coarse_assign_supported(128, 1 << 23, 16) == 0              # padded slice >= 2 GiB
     ws = lib.tpq_coarse_assign_workspace_bytes(128, 1 << 20, 16384)
     off = lib.tpq_coarse_assign_count_offset(128, 1 << 20, 16384)

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--n-probe", type=int, default=32)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--fused", action="store_true")
+    ap.add_argument("--n-split", type=int, help="workgroups per query (default: the wrapper's heuristic)")
     args = ap.parse_args()
     from torchpq_amd import kernels as K
     from torchpq_amd import _lib
@@ -51,10 +52,12 @@ def main():
     if args.fused:
         cb = torch.randn(m, 2, 256, generator=g, device=dev) * 20
         q = torch.randn(2 * m, nq, generator=g, device=dev) * 20
-        run = lambda: scan.topk_fused(storage, q, cb, None, cs, sz, npl, n_candidates=args.k, packed=packed)
+        run = lambda: scan.topk_fused(storage, q, cb, None, cs, sz, npl, n_candidates=args.k, packed=packed,
+                                      n_split=args.n_split)
     else:
         lut = torch.randn(m, nq, 256, generator=g, device=dev) * 50 - 300
-        run = lambda: scan.topk(storage, lut, None, cs, sz, npl, n_candidates=args.k, packed=packed)
+        run = lambda: scan.topk(storage, lut, None, cs, sz, npl, n_candidates=args.k, packed=packed,
+                                n_split=args.n_split)
     for _ in range(2):
         run()
     prof = torch.zeros(nq * 64 * 16, device=dev, dtype=torch.int64)
@@ -62,7 +65,7 @@ def main():
     run()
     torch.cuda.synchronize()
     raw.tpq_debug_set_scan_profile(None)
-    n_blocks = nq * scan._n_split(nq, dev)
+    n_blocks = nq * scan.last_n_split
     t = prof.view(-1, 16)[:n_blocks, :10].double().cpu() * 10.0  # ns
     d = (t[:, 1:] - t[:, :-1]) / 1e3  # us
     total = (t[:, 9] - t[:, 0]) / 1e3

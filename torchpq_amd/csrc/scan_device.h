@@ -420,14 +420,13 @@ __device__ __forceinline__ void stage_lut_blocked(const ScanArgs& a, int q, floa
   constexpr int JS = (m & 15) == 0 ? 4 : ((m & 7) == 0 ? 3 : 2);
   constexpr int JB = 1 << JS, CB = 64 >> JS;
   constexpr int jblocks = m >> JS;
-  for (int i = threadIdx.x; i < m * 64; i += n_threads) {
+  auto place = [&](int i, int& j, int& c4) {
     const int g = i >> 6, r = i & 63;
     const int jb = g % jblocks, cb4 = g / jblocks;
-    const int j = jb * JB + (r & (JB - 1));
-    const int c4 = cb4 * CB + (r >> JS);
-    const float4 x = part1 ? reinterpret_cast<const float4*>(part1)[((int64_t)q * m + j) * 64 + c4]
-                     : a.lut ? src[((int64_t)j * a.nq + q) * 64 + c4]
-                             : fused_lut4(a, j, c4, xq);
+    j = jb * JB + (r & (JB - 1));
+    c4 = cb4 * CB + (r >> JS);
+  };
+  auto put = [&](int j, int c4, const float4& x) {
     const int c = c4 * 4;
     lut[scan_layout::lut_dword(m, j, c + 0)] = x.x;
     lut[scan_layout::lut_dword(m, j, c + 1)] = x.y;
@@ -435,6 +434,60 @@ __device__ __forceinline__ void stage_lut_blocked(const ScanArgs& a, int q, floa
     lut[scan_layout::lut_dword(m, j, c + 3)] = x.w;
     const float mx = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
     atomicMax(&jmax[j], __float_as_uint(mx));
+  };
+  if (!part1 && !a.lut && a.ds <= 2) {
+    // fused table, short sub-vectors: a thread's entries come from 2 ds codebook loads each, and a plain loop
+    // pays one L2 round trip per entry (8 entries per thread at m = 64: 4.6 of the 23 us a single-query
+    // workgroup lives; 8.5 us when 512 workgroups stage at once).  All loads of U entries are issued first.
+    constexpr int U = 4;
+    const int ds = a.ds;
+    for (int i0 = threadIdx.x; i0 < m * 64; i0 += U * n_threads) {
+      float4 y[U][2];
+      int j[U], c4[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * n_threads;
+        place(i < m * 64 ? i : i0, j[u], c4[u]);
+        const float4* __restrict__ cb = reinterpret_cast<const float4*>(a.codebook) + (int64_t)j[u] * ds * 64 + c4[u];
+        y[u][0] = cb[0];
+        y[u][1] = ds > 1 ? cb[64] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (i0 + u * n_threads >= m * 64) break;
+        float4 dot = make_float4(0.f, 0.f, 0.f, 0.f), c2 = dot;
+        float q2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          if (e >= ds) break;
+          const float4 yy = y[u][e];
+          const float x = xq[j[u] * ds + e];
+          q2 = fmaf(x, x, q2);
+          dot.x = fmaf(x, yy.x, dot.x); dot.y = fmaf(x, yy.y, dot.y);
+          dot.z = fmaf(x, yy.z, dot.z); dot.w = fmaf(x, yy.w, dot.w);
+          c2.x = fmaf(yy.x, yy.x, c2.x); c2.y = fmaf(yy.y, yy.y, c2.y);
+          c2.z = fmaf(yy.z, yy.z, c2.z); c2.w = fmaf(yy.w, yy.w, c2.w);
+        }
+        float4 v = dot;  // (fused_lut4's arithmetic, operation for operation)
+        if (a.euclid) {
+          v.x = 2.f * dot.x; v.y = 2.f * dot.y; v.z = 2.f * dot.z; v.w = 2.f * dot.w;
+          if (a.euclid != 2) {
+            v.x = v.x - q2; v.y = v.y - q2; v.z = v.z - q2; v.w = v.w - q2;
+            v.x = v.x - c2.x; v.y = v.y - c2.y; v.z = v.z - c2.z; v.w = v.w - c2.w;
+          }
+        }
+        put(j[u], c4[u], v);
+      }
+    }
+    return;
+  }
+  for (int i = threadIdx.x; i < m * 64; i += n_threads) {
+    int j, c4;
+    place(i, j, c4);
+    const float4 x = part1 ? reinterpret_cast<const float4*>(part1)[((int64_t)q * m + j) * 64 + c4]
+                     : a.lut ? src[((int64_t)j * a.nq + q) * 64 + c4]
+                             : fused_lut4(a, j, c4, xq);
+    put(j, c4, x);
   }
 }
 
