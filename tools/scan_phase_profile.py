@@ -18,6 +18,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 PHASES = ["start->probe table", "LUT staged (+barrier)", "error bound", "scan loop", "final flush+publish",
           "barrier (wait slowest wave)", "counting rounds", "exact refinement + sort", "store lists"]
+FUSED_PHASES = PHASES[:8] + ["workgroup tree merge", "store + release + ticket", "(last) fold the splits + tree",
+                             "(last) write + overflow test"]
 
 
 def main():
@@ -66,7 +68,22 @@ def main():
     torch.cuda.synchronize()
     raw.tpq_debug_set_scan_profile(None)
     n_blocks = nq * scan.last_n_split
-    t = prof.view(-1, 16)[:n_blocks, :10].double().cpu() * 10.0  # ns
+    raw_t = prof.view(-1, 16)[:n_blocks].double().cpu() * 10.0  # ns
+    fused = bool((raw_t[:, 12] > 0).any())  # (the fused finish stamps slots 9-12; 11, 12 in the finishing workgroup only)
+    if fused:
+        fin = raw_t[:, 12] > 0
+        t = raw_t[:, :11]
+        d = (t[:, 1:] - t[:, :-1]) / 1e3
+        total = (t[:, 10] - t[:, 0]) / 1e3
+        print(f"m={m} nq={nq} n_probe={args.n_probe} blocks={n_blocks} (fused finish)  mean block lifetime to the ticket {total.mean():.1f} us")
+        for i, name in enumerate(FUSED_PHASES[:10]):
+            print(f"  {name:32s} {d[:, i].mean():7.2f} us")
+        tf = raw_t[fin]
+        print(f"  {FUSED_PHASES[10]:32s} {((tf[:, 11] - tf[:, 10]) / 1e3).mean():7.2f} us  (finishing workgroups: {int(fin.sum())})")
+        print(f"  {FUSED_PHASES[11]:32s} {((tf[:, 12] - tf[:, 11]) / 1e3).mean():7.2f} us")
+        print(f"  kernel span {(raw_t[:, :13].max() - raw_t[:, 0].min()) / 1e3:.1f} us")
+        return
+    t = raw_t[:, :10]
     d = (t[:, 1:] - t[:, :-1]) / 1e3  # us
     total = (t[:, 9] - t[:, 0]) / 1e3
     print(f"m={m} nq={nq} n_probe={args.n_probe} blocks={n_blocks}  mean block lifetime {total.mean():.1f} us")

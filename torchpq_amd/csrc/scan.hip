@@ -28,6 +28,7 @@
 //                        list; scan_merge_refine_kernel (one wave per query) merges the lists.
 //                        Results are bit-identical to scan_ref_kernel.
 #include <atomic>
+#include <mutex>
 
 #include "scan_device.h"
 
@@ -92,6 +93,63 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
 static unsigned long long* g_scan_prof = nullptr;
 extern "C" void tpq_debug_set_scan_profile(void* buf) { g_scan_prof = (unsigned long long*)buf; }
 #endif
+// ---- tickets of the fused finish ---------------------------------------------------------------------
+// A query split over several workgroups is finished by the last one to arrive: one int32 ticket per query,
+// ZERO when the kernel starts and zero again when it ends (the finisher resets it).  The caller's workspace
+// arrives uninitialised and zeroing it would be a launch of its own, so the library owns a zeroed ring per
+// device (4 MiB, allocated and cleared on first use) and hands every call a fresh stretch of it: calls in
+// flight on different streams never share tickets unless a million queries are in flight at once.
+// During stream capture a stretch is taken from the top of the ring for good (the graph replays with it);
+// a ring that cannot be allocated now (first use inside a capture) means: no fused finish for this call.
+static bool fuse_enabled() {
+  static const bool v = [] {
+    const char* e = getenv("TPQ_SCAN_FUSE");  // (A/B: TPQ_SCAN_FUSE=0 runs the three-launch path)
+    return !(e && atoi(e) == 0);
+  }();
+  return v;
+}
+static int* acquire_tickets(int nq, hipStream_t st) {
+  constexpr size_t kRing = 1u << 20;
+  struct Ring {
+    int* base = nullptr;
+    size_t next = 0, top = kRing;
+    bool failed = false;
+  };
+  static Ring rings[16];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  const bool capturing = cap != hipStreamCaptureStatusNone;
+  std::lock_guard<std::mutex> lock(mu);
+  Ring& r = rings[dev];
+  if (!r.base) {
+    if (r.failed || capturing) return nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&r.base), kRing * sizeof(int)) != hipSuccess ||
+        hipMemset(r.base, 0, kRing * sizeof(int)) != hipSuccess) {
+      (void)hipGetLastError();
+      r.base = nullptr;
+      r.failed = true;
+      return nullptr;
+    }
+  }
+  const size_t n = (size_t)nq;
+  if (capturing) {
+    if (r.top < n + kRing / 2) return nullptr;  // (half of the ring stays with the eager calls)
+    r.top -= n;
+    return r.base + r.top;
+  }
+  if (n > r.top) return nullptr;
+  if (r.next + n > r.top) r.next = 0;
+  int* p = r.base + r.next;
+  r.next += n;
+  return p;
+}
+
 static bool has_packed_kernel(int m) {
 #define TPQ_IS_M(M) if (m == M) return true;
   TPQ_PACKED_M_LIST(TPQ_IS_M)
@@ -204,6 +262,14 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
   // flags: raised == equal to this call's epoch; no zeroing pass (it was a launch of its own)
   static std::atomic<unsigned> g_epoch{0x5eed0001u};
   a.epoch = (int)(g_epoch.fetch_add(0x9e3779b1u) | 1u);
+  // the scan workgroups finish the query themselves (merge, write, exact redo): one launch instead of three.
+  // (k <= 248, plain PQ; a query split over several workgroups needs a ticket from the library's ring)
+  a.tickets = nullptr;
+  a.fuse = 0;
+  if (!ra && fuse_enabled() && fuse_fits(m, R) && packed_waves(m) * RL >= R) {
+    if (n_split > 1) a.tickets = acquire_tickets(nq, st);
+    a.fuse = (n_split == 1 || a.tickets) ? 1 : 0;
+  }
   switch (m) {
 #define TPQ_CASE_M(M) case M: rc = dispatch_packed_##M(a, ra, RL, R, st); break;
     TPQ_PACKED_M_LIST(TPQ_CASE_M)
@@ -211,6 +277,7 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
     default: rc = TPQ_ERR_UNSUPPORTED; break;
   }
   if (rc) return rc;
+  if (a.fuse) return TPQ_OK;  // (the fused finish redoes them itself)
   // exact redo of the (normally zero) queries whose candidate band overflowed
   ScanArgs b = a;
   b.n_split = 1;

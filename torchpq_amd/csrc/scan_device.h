@@ -36,6 +36,8 @@ struct ScanArgs {
   unsigned long long* prof;  // -DTPQ_SCAN_PROFILE builds: [nq][16] phase timestamps (10 ns ticks)
   int small_lists;           // packed path, large k: per-wave lists hold fewer than k + 8 entries
   int epoch;                 // value that marks a raised flag in this call (non-zero)
+  int* tickets;              // fused finish, n_split > 1: [nq] zero on entry, zero on exit
+  int fuse;                  // fused finish (scan_packed_kernel RM > 0): the scan workgroups write the result
 };
 
 #ifdef TPQ_SCAN_PROFILE
@@ -565,6 +567,76 @@ __device__ __forceinline__ void finalize_and_write(const ScanArgs& a, int q, con
   }
 }
 
+// Merge of L sorted lists (best first) of LEN keys each, lying in LDS as hi[l * LEN + i], lo[...], BY RANK:
+// the position of an entry in the merged order is its own position plus, for every other list, the number of
+// that list's entries that precede it -- a fixed-step binary search per list, eight lists' searches in
+// flight per lane.  Equal keys (a slot scanned twice) rank by list: no two entries share a position.  Entries
+// that land below `cap` are scattered into ohi / olo (pre-filled with pads by the caller); one barrier on
+// either side instead of the 2 log2(L) of a tree of pairwise merges, and no serial chain of bitonic networks
+// (the workgroup's 8 x 64: 4.6 -> 3.9 us, and 4 % of the C2 batch).
+template <int LEN>
+__device__ __forceinline__ void rank_merge(const unsigned* __restrict__ hi, const unsigned* __restrict__ lo, int L,
+                                           unsigned* __restrict__ ohi, unsigned* __restrict__ olo, int cap, int tid,
+                                           int n_threads) {
+  static_assert((LEN & (LEN - 1)) == 0, "power of two");
+  for (int e = tid; e < L * LEN; e += n_threads) {
+    const int l = e / LEN;
+    const Key x{hi[e], lo[e]};
+    if (key_index(x) == kPadIdx) continue;
+    const unsigned long long xu = key_u64(x);
+    int rank = e - l * LEN;
+    for (int l0 = 0; l0 < L; l0 += 8) {
+      int cnt[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cnt[j] = 0;
+      // y precedes x: y > x, or y == x in an earlier list
+      // (branch-free: a list beyond L or the entry's own list is searched like the others -- in bounds -- and
+      // its count dropped; with a branch per list the eight searches ran one after the other, 90 cycles a read)
+      int base[8];
+      bool use[8], tie[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int l2 = l0 + j;
+        use[j] = l2 < L && l2 != l;
+        tie[j] = l2 < l;
+        base[j] = (l2 < L ? l2 : L - 1) * LEN;
+      }
+#pragma unroll
+      for (int s = LEN / 2; s >= 1; s >>= 1) {
+        unsigned yh[8], yl[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          yh[j] = hi[base[j] + cnt[j] + s - 1];
+          yl[j] = lo[base[j] + cnt[j] + s - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned long long yu = ((unsigned long long)yh[j] << 32) | yl[j];
+          cnt[j] += (yu > xu || (yu == xu && tie[j])) ? s : 0;
+        }
+      }
+      {
+        unsigned yh[8], yl[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          yh[j] = hi[base[j] + cnt[j]];
+          yl[j] = lo[base[j] + cnt[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned long long yu = ((unsigned long long)yh[j] << 32) | yl[j];
+          const int c = cnt[j] + ((yu > xu || (yu == xu && tie[j])) ? 1 : 0);
+          rank += use[j] ? c : 0;
+        }
+      }
+    }
+    if (rank < cap) {
+      ohi[rank] = x.hi;
+      olo[rank] = x.lo;
+    }
+  }
+}
+
 // waves per workgroup: 8 while two workgroups share a CU (LUT <= 64 KiB); 16 when the LUT is so
 // large that only one workgroup fits (m > 64, e.g. GIST m=120: 120 KiB) -- same 16 waves per CU.
 // Short codes (m <= 32, LUT <= 32 KiB): 4 waves, FOUR workgroups per CU -- a query is then a
@@ -612,7 +684,13 @@ constexpr int packed_aux_bytes(int /*R*/, int M) {
 //   f(s) = sum_j part1[j][code_j] (permuted order) + (base_p + slot_term[s]).
 // f is again a selection key only (|f - e| <= delta with the bound below); survivors are
 // re-evaluated with the reference's arithmetic: v = base_p; v += fl(part1 + part2) ascending j.
-template <int R, int M, bool RES>
+//
+// RM > 0 ("fused finish", small batches): the workgroup also FINISHES -- its waves' exact lists are
+// tree-merged through LDS, a query split over several workgroups meets in the last one to arrive (a ticket
+// per query), which writes the result; an overflowing candidate band is redone, exactly, by that same
+// workgroup.  One launch instead of three (scan, scan_merge_refine_kernel, the flagged redo): at one query
+// the two extra launches were 25 of 64 us.  RM = registers of the merged list (list_regs_packed(k)).
+template <int R, int M, bool RES, int RM = 0>
 __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(ScanArgs a,
                                                                                     ResidualArgs ra,
                                                                                     float delta_rel) {
@@ -1058,6 +1136,147 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
       ex.insert_unsorted(want ? make_key(e, idx) : pad_key());
     }
     TPQ_PROF(a, blockIdx.x, 8);
+    if constexpr (RM > 0 && !RES) {
+      static_assert(RM >= R, "merged list shorter than the per-wave lists");
+      // ---- fused finish ----
+      WaveTopK<RM> mt;
+      mt.init();
+#pragma unroll
+      for (int r = 0; r < R; ++r) mt.k[r] = ex.k[r];  // (sorted; the pads of init() rank last)
+      float* lv = reinterpret_cast<float*>(smem);     // [NW][RM 64] x 2: over the LUT, the rows and the queues
+      int* li = reinterpret_cast<int*>(smem + (size_t)NW * RM * 64 * 4);
+      int* s_flag = tile_ctr;                         // (dead: m > 64 hands tiles out of it during the scan only)
+      auto tree = [&]() {  // NW lists -> wave 0
+        for (int stride = 1; stride < NW; stride <<= 1) {
+          if ((wave & (2 * stride - 1)) == stride) store_list<RM>(mt, lv + wave * RM * 64, li + wave * RM * 64);
+          __syncthreads();
+          if ((wave & (2 * stride - 1)) == 0)
+            merge_list<RM>(mt, lv + (wave + stride) * RM * 64, li + (wave + stride) * RM * 64);
+          __syncthreads();
+        }
+      };
+      // (merge area: over the LUT, the rows and the queues -- everything below the probe table)
+      constexpr int region = lut_bytes + aux_bytes + NW * 512;
+      unsigned* mhi = reinterpret_cast<unsigned*>(smem);
+      auto load_merged = [&](const unsigned* ohi, const unsigned* olo) {
+#pragma unroll
+        for (int r = 0; r < RM; ++r) mt.k[r] = Key{ohi[r * 64 + lane], olo[r * 64 + lane]};
+      };
+      __syncthreads();  // every wave is done with the LUT and its rows
+      {  // the workgroup's NW lists -> one, by rank (rank_merge)
+        constexpr int LEN = 64 * R;
+        unsigned* mlo = mhi + NW * LEN;
+        unsigned* ohi = mlo + NW * LEN;
+        unsigned* olo = ohi + RM * 64;
+        store_list<R>(ex, reinterpret_cast<float*>(mhi + wave * LEN), reinterpret_cast<int*>(mlo + wave * LEN));
+        const Key pad = pad_key();
+        for (int i = threadIdx.x; i < RM * 64; i += NW * 64) {
+          ohi[i] = pad.hi;
+          olo[i] = pad.lo;
+        }
+        __syncthreads();
+        rank_merge<LEN>(mhi, mlo, NW, ohi, olo, RM * 64, (int)threadIdx.x, NW * 64);
+        __syncthreads();
+        if (wave == 0) load_merged(ohi, olo);
+      }
+      TPQ_PROF(a, blockIdx.x, 9);
+      bool last = true;
+      if (a.n_split > 1) {
+        // the workgroup's list -> workspace; release; ticket.  (G16 of the CDNA guide: plain stores, wait,
+        // agent-scope release by one lane, relaxed agent-scope ticket; the last arriver acquires)
+        if (wave == 0) {
+          const int64_t o = ((int64_t)q * a.n_split + part) * (RM * 64);
+          store_list<RM>(mt, a.ws_vals + o, a.ws_idx + o);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int t = __hip_atomic_fetch_add(a.tickets + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int is_last = t == a.n_split - 1;
+            if (is_last) {
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+              a.tickets[q] = 0;  // (zero on exit: the next call's workgroups start from it)
+            }
+            *s_flag = is_last;
+          }
+        }
+        __syncthreads();
+        last = *s_flag != 0;
+        TPQ_PROF(a, blockIdx.x, 10);
+        if (last) {  // block-uniform
+          // (plain loads: the acquire above invalidated this CU's view; the lists were written back by their
+          // producers' releases)
+          // (wave w folds the lists of splits w, w + NW, ...; then the tree.  Ranking 16 x 128 entries against
+          // each other in LDS, as the workgroup's own lists are merged above, measured 26 us against 7)
+          mt.init();
+          for (int pp = wave; pp < a.n_split; pp += NW) {
+            const int64_t o = ((int64_t)q * a.n_split + pp) * (RM * 64);
+            merge_list<RM>(mt, a.ws_vals + o, a.ws_idx + o);
+          }
+          __syncthreads();
+          tree();
+        }
+      } else {
+        TPQ_PROF(a, blockIdx.x, 10);
+      }
+      if (!last) return;
+      TPQ_PROF(a, blockIdx.x, 11);
+      // wave 0 holds the query's list, exact values: write, and decide whether the band overflowed
+      if (wave == 0) {
+        const float ek = mt.kth_value(a.k);
+        const Key klast = readlane_key(mt.k[RM - 1], 63);
+        bool overflow = (key_index(klast) != kPadIdx) && !(key_value(klast) < ek - delta2);
+        if (a.small_lists) overflow = overflow || (__hip_atomic_load(a.flags + q, __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_AGENT) == a.epoch);
+        write_final<RM>(a, q, mt);
+        if (lane == 0) {
+          a.flags[q] = overflow ? a.epoch : 0;  // (diagnostics: the redo below has already happened when read)
+          *s_flag = overflow;
+        }
+      }
+      __syncthreads();
+      TPQ_PROF(a, blockIdx.x, 12);
+      if (*s_flag == 0) return;
+      // ---- the exact redo (normally never): this workgroup rescans the query's probed cells with the
+      // reference's arithmetic (ascending j, from the packed bytes) and overwrites the result ----
+      __syncthreads();
+      if (threadIdx.x < M) jmax[threadIdx.x] = 0u;
+      __syncthreads();
+      stage_lut_blocked<M>(a, q, lut, NW * 64, jmax, xq, nullptr);  // (the merge buffers lay over it)
+      __syncthreads();
+      if (wave == 0 && lane == 0) *tau_key = f2key(-INFINITY);
+      __syncthreads();
+      WaveSelector<RM> xs;
+      xs.init(qv_all + wave * 64, qi_all + wave * 64, a.k);
+      for (int pp = 0; pp < n_probe; ++pp) {
+        const int size = tab.size[pp], start = tab.start[pp];
+        for (int off0 = wave * 64; off0 < size; off0 += NW * 64) {
+          const int off = off0 + lane;
+          const bool valid = off < size;
+          const int sidx = start + (valid ? off : 0);
+          float e = -INFINITY;
+#pragma unroll 1
+          for (int pass = 0; pass < 64 / RR; ++pass) {
+            const bool mine = valid && ((lane / RR) == pass);
+            const float ep = exact_from_packed<M>(a.packed, a.n_slots, sidx, mine, scratch, lane % RR, LdsLut<M>{lut});
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            e = mine ? ep : e;
+          }
+          bool live = valid;
+          if (valid && a.is_empty) live = (a.is_empty[sidx] == 0);
+          xs.tau = fmaxf(xs.tau, key2f(*reinterpret_cast<volatile unsigned*>(tau_key)));
+          const float tau_before = xs.tau;
+          xs.push(live && (e >= xs.tau), e, sidx);
+          if (xs.tau > tau_before && lane == 0) atomicMax(tau_key, f2key(xs.tau));
+        }
+      }
+      xs.flush();
+      mt = xs.top;
+      __syncthreads();  // every wave is done with the LUT
+      tree();
+      if (wave == 0) write_final<RM>(a, q, mt);
+      return;
+    }
     const int64_t o = (((int64_t)q * a.n_split + part) * NW + wave) * (R * 64);
     store_list<R>(ex, a.ws_vals + o, a.ws_idx + o);
     TPQ_PROF(a, blockIdx.x, 9);
@@ -1176,6 +1395,14 @@ static size_t scan_lds_bytes_packed(int m, int R, int max_nprobe, int fused_floa
   return (b + 15) & ~(size_t)15;
 }
 static int fused_floats_of(const ScanArgs& a) { return a.lut ? 0 : a.m * a.ds + a.m; }
+// fused finish (scan_packed_kernel RM > 0): instantiated for merged lists of up to kFuseMaxR registers
+// (k <= 248); its merge buffers -- waves x 64 RM keys -- lie over the LUT, the un-permute rows and the queues
+constexpr int kFuseMaxR = 4;
+static bool fuse_fits(int m, int RM) {
+  const int nw = packed_waves(m);
+  return RM <= kFuseMaxR &&
+         (size_t)(nw + 1) * RM * 64 * 8 <= (size_t)m * 1024 + packed_aux_bytes(RM, m) + (size_t)nw * 512;
+}
 
 // per-M translation units (scan_packed.hip compiled with -DTPQ_PACKED_M=<M>)
 // (keep the list in sync with build.sh and torchpq_amd/kernels PACKED_M)

@@ -15,6 +15,17 @@ static int launch_packed(ScanArgs a, ResidualArgs ra, hipStream_t st) {
 #ifdef TPQ_EXTRA_LDS  // experiment: force fewer workgroups per CU
   lds += TPQ_EXTRA_LDS;
 #endif
+  if constexpr (!RES && R <= kFuseMaxR) {
+    if (a.fuse) {  // fused finish: one launch (scan.hip decides)
+      int rc = set_lds(scan_packed_kernel<RL, M, false, R>, lds, "scan_packed_kernel (fused finish)");
+      if (rc) return rc;
+      const float delta_rel = 1.05f * 2.0f * 5.9604645e-8f * (float)(M - 1);
+      hipLaunchKernelGGL((scan_packed_kernel<RL, M, false, R>), dim3((unsigned)a.nq * a.n_split),
+                         dim3(packed_waves(M) * 64), lds, st, a, ra, delta_rel);
+      TPQ_LAUNCH_CHECK("scan_packed_kernel (fused finish)");
+      return TPQ_OK;
+    }
+  }
   int rc = set_lds(scan_packed_kernel<RL, M, RES>, lds, "scan_packed_kernel");
   if (rc) return rc;
   // delta = 1.05 * 2 (M-1) u * sum_j max|LUT_j|,  u = 2^-24   (residual: M+1 roundings, see kernel)

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kSelWaves * 64) void topk_select_kernel(const float
 // - |C|^2: the arithmetic of coarse_sims_kernel and oracle_coarse_sims, bit for bit.  The chains are
 // sequential in k, the loads are not: 16 in flight per thread.
 constexpr int kProbeSmallThreads = 1024;
-constexpr int kProbeSmallMaxQ = 64;
+constexpr int kProbeSmallMaxQ = 256;
 constexpr int kProbeSmallMaxCells = 8192;   // sims row in LDS (32 KiB)
 constexpr int kProbeSmallMaxD = 1024;       // query in LDS
 
