@@ -1155,8 +1155,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
           __syncthreads();
         }
       };
-      // (merge area: over the LUT, the rows and the queues -- everything below the probe table)
-      constexpr int region = lut_bytes + aux_bytes + NW * 512;
+      // (merge area: over the LUT, the rows and the queues -- everything below the probe table: fuse_fits())
       unsigned* mhi = reinterpret_cast<unsigned*>(smem);
       auto load_merged = [&](const unsigned* ohi, const unsigned* olo) {
 #pragma unroll
@@ -1186,11 +1185,16 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
         // agent-scope release by one lane, relaxed agent-scope ticket; the last arriver acquires)
         if (wave == 0) {
           const int64_t o = ((int64_t)q * a.n_split + part) * (RM * 64);
-          store_list<RM>(mt, a.ws_vals + o, a.ws_idx + o);
+          // (write-through stores -- relaxed, agent scope: sc1 -- need no cache write-back before the ticket)
+#pragma unroll
+          for (int r = 0; r < RM; ++r) {
+            __hip_atomic_store(reinterpret_cast<unsigned*>(a.ws_vals) + o + r * 64 + lane, mt.k[r].hi, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned*>(a.ws_idx) + o + r * 64 + lane, mt.k[r].lo, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int t = __hip_atomic_fetch_add(a.tickets + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int is_last = t == a.n_split - 1;
             if (is_last) {
