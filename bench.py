@@ -477,6 +477,54 @@ def secondary_c5(device, stream_peak, iters=3):
     return out
 
 
+def secondary_wide(device, stream_peak, iters=3):
+    """the coarse assign of a GIST-width index: 1 M points x 16 384 centroids x 960 dimensions through
+    tpq_coarse_assign (fp16 selection on the matrix cores + candidate pairs evaluated exactly), with the
+    bit-exact fp32 kernel beside it"""
+    from torchpq_amd import kernels as K
+    d, m, n = 960, 1_000_000, 16384
+    g = torch.Generator(device=device)
+    g.manual_seed(4321)
+    A = torch.randn(d, m, generator=g, device=device)
+    B = A[:, torch.randperm(m, generator=g, device=device)[:n]].contiguous()
+
+    def timeit(fn, reps=iters):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    op = K.CoarseAssignHip(distance="euclidean")
+    lab = op(A, B)
+    undecided = op.last_rechecked() / m
+    fp32 = K.MaxSimHip(distance="euclidean")
+    _, l32 = fp32(A[None], B[None], dim=2, mode="tn")
+    agree = float((lab == l32[0]).double().mean().item())
+    t = timeit(lambda: op(A, B))
+    t32 = timeit(lambda: fp32(A[None], B[None], dim=2, mode="tn"), 1)
+    flop = 2.0 * m * n * d
+    issue_ratio = 1.0 + undecided  # one fp16 product over every point + one more over the undecided ones
+    tf = flop / t / 1e9
+    peak_equiv = MFMA_BF16_PEAK_TFLOPS / issue_ratio
+    return {"workload": f"tpq_coarse_assign d={d} points={m} centroids={n} (KMeans.predict / IVFPQIndex.add at GIST width)",
+            "ms": round(t, 3), "fp32_kernel_ms": round(t32, 3), "speedup_vs_fp32_kernel": round(t32 / t, 2),
+            "labels_equal_to_fp32_kernel": round(agree, 6), "share_of_points_with_an_exact_step": round(undecided, 5),
+            "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": round(peak_equiv, 1), "unit": "TFLOP/s",
+                         "frac": round(tf / peak_equiv, 4), "traffic": None,
+                         "kernel": "gemm_kernel<false> (fp16 hi pieces, key top-2) + gemm_kernel<true> (candidates of "
+                                   "the undecided points) + pair_exact_kernel",
+                         "kernel_ms": round(t, 3), "algorithmic_flops_per_launch": flop,
+                         "issued_f16_TFLOPs": round(tf * issue_ratio, 1), "bf16_dense_peak": MFMA_BF16_PEAK_TFLOPS,
+                         "peak_note": f"fp32-equivalent: fp16 dense peak / {issue_ratio:.2f} MFMA flops issued per "
+                                      "algorithmic flop; the whole call (preparation of the points, candidate pass, "
+                                      "exact pairs) is in the time"}}
+
+
 def secondary_pass(device, budget_s, only=None):
     out = {}
     t_start = time.time()
@@ -487,7 +535,7 @@ def secondary_pass(device, budget_s, only=None):
     except Exception as e:
         sp = None
         out["stream_peak"] = {"error": repr(e)[:300]}
-    for name, fn in (("c4", secondary_c4), ("c3", secondary_c3), ("c5", secondary_c5)):
+    for name, fn in (("c4", secondary_c4), ("c3", secondary_c3), ("c5", secondary_c5), ("wide", secondary_wide)):
         if only and name not in only:
             continue
         if time.time() - t_start > budget_s:
@@ -559,7 +607,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--secondary-only", default=None, help="comma list of c3,c4,c5 (profiling)")
+    ap.add_argument("--secondary-only", default=None, help="comma list of c3,c4,c5,wide (profiling)")
     ap.add_argument("--secondary-budget", type=float, default=60.0)
     args = ap.parse_args(argv)
     c4 = args.workload == "c4"

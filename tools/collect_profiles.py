@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Copy the judged artefacts of tools/profile_bench.sh from gpurun_out/<tag>/<W>/ (scratch) into
 profiles/ (tracked):  <tag>_<name>_bench.json, <tag>_<name>_kernel_stats.csv, <tag>_<name>.json
-with <name> = bench_scan_packed for the headline (c2) and c3 / c4 / c5 otherwise."""
+with <name> = bench_scan_packed for the headline (c2) and c3 / c4 / c5 / wide otherwise."""
 import glob
 import os
 import shutil
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
-    for w in ("c2", "c3", "c4", "c5"):
+    for w in ("c2", "c3", "c4", "c5", "wide"):
         src = os.path.join(ROOT, "gpurun_out", tag, w)
         if not os.path.isdir(src):
             continue

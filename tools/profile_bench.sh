@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile of bench.py on the GPU box (run through gpurun from the repo root):
-#   bash tools/profile_bench.sh r03 [c2 c3 c4 c5]
-# per workload W (c2 = the headline bench line; c3/c4/c5 = `bench.py --secondary-only W`):
+#   bash tools/profile_bench.sh r03 [c2 c3 c4 c5 wide]
+# per workload W (c2 = the headline bench line; c3/c4/c5/wide = `bench.py --secondary-only W`):
 #   1. plain run                                 -> gpurun_out/<tag>/<W>/bench.json
 #   2. rocprofv3 --kernel-trace --stats          -> gpurun_out/<tag>/<W>/stats/
 #   3. separate --pmc passes (HBM-side fetch, TCC, SQ/LDS) -> gpurun_out/<tag>/<W>/pmc_*/
@@ -22,6 +22,7 @@ for W in $WORKLOADS; do
     c3) BENCH="python ${ROOT}/bench.py --secondary-only c3"; KERNEL="scan_packed_kernel";;
     c4) BENCH="python ${ROOT}/bench.py --secondary-only c4"; KERNEL="scan_packed_kernel";;
     c5) BENCH="python ${ROOT}/bench.py --secondary-only c5"; KERNEL="coarse_kernel";;
+    wide) BENCH="python ${ROOT}/bench.py --secondary-only wide"; KERNEL="gemm_kernel";;
   esac
   $BENCH > "$OUT/bench.json" 2> "$OUT/bench.err"
   tail -c 600 "$OUT/bench.json"; echo
@@ -37,7 +38,7 @@ PY
   PASSES=("FETCH_SIZE TCC_EA0_RDREQ_sum")   # c3/c4/c5: HBM-side bytes only (each pass re-builds the workload)
   [[ "$W" == "c2" ]] && PASSES+=("TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE")
   # the k-means kernels (VERDICT r2 #1/#7a): matrix-pipe / VALU / wait shares and the effective clock, per kernel
-  [[ "$W" == "c5" ]] && PASSES+=("GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" \
+  [[ "$W" == "c5" || "$W" == "wide" ]] && PASSES+=("GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" \
                                   "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
                                   "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM")
   for ctrs in "${PASSES[@]}"; do

@@ -44,7 +44,8 @@ def main():
             per = collections.defaultdict(lambda: collections.defaultdict(list))
             for r in csv.DictReader(open(f)):
                 for tag in ("coarse_kernel", "refine_kernel", "update_kernel", "max_sim_kernel",
-                            "select_resident_kernel", "centroid_accum_mfma_kernel", "max_sim_codebook_kernel"):
+                            "select_resident_kernel", "centroid_accum_mfma_kernel", "max_sim_codebook_kernel",
+                            "gemm_kernel<false", "gemm_kernel<true", "pair_exact_kernel", "gsplit_points_kernel"):
                     if tag in r["Kernel_Name"]:
                         per[tag][r["Counter_Name"]].append(float(r["Counter_Value"]))
             for tag, ctrs in per.items():

@@ -181,6 +181,22 @@ __global__ void scale_kernel(const unsigned* __restrict__ maxbits, int* __restri
   scale[b] = s;
 }
 
+// norms[point] = (|a'|^2, packed): the second word carries two quantities that only ever enter BOUNDS, each
+// rounded UP to bf16: |x|^2 (the exact kernel's own rounding scales with it) in the high half, and
+// |a' - ah|^2 -- what level 1 drops of this point -- in the low half.
+__device__ __forceinline__ unsigned bf16_up(float x) {  // x >= 0 (an overflow to inf just lists the point)
+  return (__float_as_uint(x) + 0xffffu) >> 16;
+}
+__device__ __forceinline__ float pack_bound_norms(float n2r, float n2m) {
+  return __uint_as_float((bf16_up(n2r) << 16) | bf16_up(n2m));
+}
+__device__ __forceinline__ void unpack_bound_norms(float y, float& n2r, float& n2m) {
+  const unsigned u = __float_as_uint(y);
+  n2r = __uint_as_float(u & 0xffff0000u);
+  n2m = __uint_as_float(u << 16);
+}
+constexpr int kCm = 4;  // words per sub-problem in cmax2_bits: max N, max |c|^2, max |C - Ch|^2, -
+
 // pieces + norms.  grid (ceil(T / 4), l), 4 waves; wave -> tile of 32 points, lane (point l31, half)
 // holds dimensions 16 st + 8 half + j of its point: the B operand of v_mfma_f32_32x32x16_f16.
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ A, const float* __restrict__ mu,
@@ -197,7 +213,7 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ A,
   const float s = scale[b];
   const int Q = (KS + 1) / 2;
   const int64_t fo = ((int64_t)b * T + tile) * Q * 128 + l31 * 4 + half;  // in 16-byte chunks
-  float n2c = 0.f, n2r = 0.f;
+  float n2c = 0.f, n2r = 0.f, n2m = 0.f;
   for (int st = 0; st < KS; ++st) {
     float x[8];
 #pragma unroll
@@ -216,6 +232,7 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ A,
       mm[j] = (_Float16)r;
       n2c = fmaf(a, a, n2c);
       n2r = fmaf(x[j], x[j], n2r);
+      n2m = fmaf(r, r, n2m);
     }
     hi[fo + (st >> 1) * 128 + (st & 1) * 2] = __builtin_bit_cast(u32x4, h);
     mid[fo + (st >> 1) * 128 + (st & 1) * 2] = __builtin_bit_cast(u32x4, mm);
@@ -226,7 +243,8 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ A,
   }
   n2c += __shfl_xor(n2c, 32, 64);
   n2r += __shfl_xor(n2r, 32, 64);
-  if (half == 0) norms[(int64_t)b * T * 32 + tile * 32 + l31] = make_float2(n2c, n2r);
+  n2m += __shfl_xor(n2m, 32, 64);
+  if (half == 0) norms[(int64_t)b * T * 32 + tile * 32 + l31] = make_float2(n2c, pack_bound_norms(n2r, n2m));
 }
 
 // ---- per iteration: centroid fragments -----------------------------------------------------------
@@ -275,10 +293,11 @@ __global__ __launch_bounds__(64) void cprep_kernel(const float* __restrict__ B, 
   if (c < n) {
     bad |= !(N <= 3.0e38f) | !(sraw <= 3.0e38f);
     if (half == 0 && !bad) {
-      atomicMax(cmax2_bits + b * 2, __float_as_uint(N));
-      atomicMax(cmax2_bits + b * 2 + 1, __float_as_uint(sraw));
+      atomicMax(cmax2_bits + b * kCm, __float_as_uint(N));
+      atomicMax(cmax2_bits + b * kCm + 1, __float_as_uint(sraw));
     }
   }
+  float c2m = 0.f;  // |C - Ch|^2: what level 1 drops of this centroid
   for (int st = 0; st < KS; ++st) {
     f16x8 h, mm;
 #pragma unroll
@@ -290,10 +309,13 @@ __global__ __launch_bounds__(64) void cprep_kernel(const float* __restrict__ B, 
       const float r = C - (float)hh;
       h[j] = hh;
       mm[j] = (_Float16)r;
+      c2m = fmaf(r, r, c2m);
     }
     out[(1 + 2 * st) * 64] = __builtin_bit_cast(u32x4, h);
     out[(2 + 2 * st) * 64] = __builtin_bit_cast(u32x4, mm);
   }
+  c2m += __shfl_xor(c2m, 32, 64);
+  if (half == 0 && c < n && !bad) atomicMax(cmax2_bits + b * kCm + 2, __float_as_uint(c2m));
   if (bad) atomicOr(cflag + b, 1);
 }
 
@@ -403,7 +425,7 @@ struct StepArgs {
   const u32x4* mid;            // likewise
   const float2* norms;         // [l][T * 32]: (|a'|^2, |x|^2)
   const u32x4* frags;          // [l][8][2 KS + 1][64]
-  const unsigned* cmax2_bits;  // [l][2]: max N, max |c|^2
+  const unsigned* cmax2_bits;  // [l][kCm]: max N, max |c|^2, max |C - Ch|^2
   const float* scale;          // [l]
   const int* flag;             // [l] data not finite / out of range (prepare)
   const int* cflag;            // [l] centroids out of fp16 range (this iteration)
@@ -416,6 +438,7 @@ struct StepArgs {
   int m;
   int64_t T;
   float eps, eps_exact, eta;   // eps: this level's fast-path bound, relative to (|a'| + |c'|max)^2; eta times sqrt(d)
+  int level;                   // 1: the dropped pieces are bounded per point (emit), on top of eps
   // more than 256 centroids (tpq_coarse_assign): blockIdx.y = CHUNK of 256 centroids (all chunks in one
   // launch: one chunk's blocks alone fill half the chip); a chunk's (best, second) and in-chunk index of
   // every point go to part_*[chunk][point or list position], decide_kernel folds the chunks and decides
@@ -447,9 +470,20 @@ __device__ __forceinline__ void emit(const StepArgs& a, BlockListT<CAP>* bl, int
     return;
   }
   // (v_sqrt_f32: 1 ulp; the norms only scale the bound, whose 1.25 covers it)
-  const float an = __builtin_amdgcn_sqrtf(n2.x), anr = __builtin_amdgcn_sqrtf(n2.y) * s;
+  float n2r, n2m;
+  unpack_bound_norms(n2.y, n2r, n2m);
+  const float an = __builtin_amdgcn_sqrtf(n2.x), anr = __builtin_amdgcn_sqrtf(n2r) * s;
   const float t1 = an + cn, t2 = anr + cnr * s;
-  float delta = 1.25f * (a.eps * t1 * t1 + a.eta * (2.f * cn + an) + a.eps_exact * t2 * t2);
+  // Level 1 drops the products with the mid pieces: |sum (a C - ah Ch)| <= |a' - ah| (|Ch|max + |C - Ch|max) +
+  // |a'| |C - Ch|max with what was ACTUALLY dropped of this point and of the worst centroid (|Ch| <= (1 + 2^-11)
+  // 2 |c'|) -- about 0.4 of the worst case 2^-11 (|a'| + |c'|max)^2, and 7.5 % undecided points become 3 %.
+  float dropped = 0.f;
+  if (a.level == 1) {
+    const float a2 = __builtin_amdgcn_sqrtf(n2m);
+    const float c2 = __builtin_amdgcn_sqrtf(__uint_as_float(a.cmax2_bits[b * kCm + 2]));
+    dropped = a2 * (2.002f * cn + c2) + 1.001f * an * c2;
+  }
+  float delta = 1.25f * (dropped + a.eps * t1 * t1 + a.eta * (2.f * cn + an) + a.eps_exact * t2 * t2);
   if (exact_all) delta = INFINITY;
   if (valid) {
     a.inds[(int64_t)b * a.m + fi] = idx;
@@ -563,7 +597,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
     bones[2] = (__bf16)1.0f;
   }
   const float s = a.scale[b];
-  const float cn = sqrtf(__uint_as_float(a.cmax2_bits[b * 2])), cnr = sqrtf(__uint_as_float(a.cmax2_bits[b * 2 + 1]));
+  const float cn = sqrtf(__uint_as_float(a.cmax2_bits[b * kCm])), cnr = sqrtf(__uint_as_float(a.cmax2_bits[b * kCm + 1]));
   const bool exact_all = (a.flag[b] | a.cflag[b]) != 0;
   const float inv_s2 = (1.f / s) * (1.f / s);
 
@@ -733,7 +767,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
     bones[2] = (__bf16)1.0f;
   }
   const float s = a.scale[b];
-  const float cn = sqrtf(__uint_as_float(a.cmax2_bits[b * 2])), cnr = sqrtf(__uint_as_float(a.cmax2_bits[b * 2 + 1]));
+  const float cn = sqrtf(__uint_as_float(a.cmax2_bits[b * kCm])), cnr = sqrtf(__uint_as_float(a.cmax2_bits[b * kCm + 1]));
   const bool exact_all = (a.flag[b] | a.cflag[b]) != 0;
   const float inv_s2 = (1.f / s) * (1.f / s);
 
@@ -1073,9 +1107,16 @@ __global__ __launch_bounds__(256) void decide_kernel(StepArgs a, int n_chunks) {
   const float s = a.scale[0];
   const float cn = sqrtf(__uint_as_float(a.cmax2_bits[0])), cnr = sqrtf(__uint_as_float(a.cmax2_bits[1]));
   const float2 n2 = a.norms[p];
-  const float an = sqrtf(n2.x), anr = sqrtf(n2.y) * s;
+  float n2r, n2m;
+  unpack_bound_norms(n2.y, n2r, n2m);
+  const float an = sqrtf(n2.x), anr = sqrtf(n2r) * s;
   const float t1 = an + cn, t2 = anr + cnr * s;
-  float delta = 1.25f * (a.eps * t1 * t1 + a.eta * (2.f * cn + an) + a.eps_exact * t2 * t2);
+  float dropped = 0.f;
+  if (LEVEL == 1) {  // (emit())
+    const float a2 = sqrtf(n2m), c2 = sqrtf(__uint_as_float(a.cmax2_bits[2]));
+    dropped = a2 * (2.002f * cn + c2) + 1.001f * an * c2;
+  }
+  float delta = 1.25f * (dropped + a.eps * t1 * t1 + a.eta * (2.f * cn + an) + a.eps_exact * t2 * t2);
   if ((a.flag[0] | a.cflag[0]) != 0) delta = INFINITY;
   if (valid) {
     a.inds[p] = idx;
@@ -1364,8 +1405,8 @@ static StepLayout step_layout(int l, int d, int64_t m, int n) {
   StepLayout L;
   const int KS = ks_of(d);
   L.frags_off = 0;
-  L.cmax_off = (size_t)l * 8 * (2 * KS + 1) * 1024;   // [l][2] u32
-  L.count_off = L.cmax_off + (size_t)l * 8;            // [l] i32: left undecided by level 1
+  L.cmax_off = (size_t)l * 8 * (2 * KS + 1) * 1024;   // [l][kCm] u32
+  L.count_off = L.cmax_off + (size_t)l * 4 * kCm;      // [l] i32: left undecided by level 1
   L.cflag_off = L.count_off + (size_t)l * 4;           // [l] i32
   L.count2_off = L.cflag_off + (size_t)l * 4;          // [l] i32: left undecided by level 2
   L.list_off = (L.count2_off + (size_t)l * 4 + 255) / 256 * 256;   // [l][m] i32
@@ -1380,7 +1421,7 @@ static float level_eps(int KS, int d, int level) {
   const int terms = KS * 16 + 2 + 3;
   const float common = (float)(terms + 8) / 8388608.0f + (float)(d + 1) / 16777216.0f + 1.0f / 4194304.0f +
                        1.0f / 524288.0f;  // accumulation, norm chain, shift rounding, key bits
-  return level == 1 ? 1.001f / 2048.0f + common + 1.0f / 131072.0f  // hi pieces only; 6-bit keys: 2^-17
+  return level == 1 ? common + 1.0f / 131072.0f  // (the dropped pieces: per point, emit()); 6-bit keys: 2^-17
                     : 3.03f / 4194304.0f + common;
 }
 
@@ -1394,6 +1435,7 @@ static int run_levels(StepArgs sa, int l, int d, int* list2, int* count2, hipStr
                        "lloyd coarse_kernel attr");
     if (rc) return rc;
     sa.eps = level_eps(KS, d, 1);
+    sa.level = 1;
     const int64_t wide = (sa.T + 1) / 2, per_block = (int64_t)kWaves * kWide;
     hipLaunchKernelGGL(kernel, dim3((unsigned)((wide + per_block - 1) / per_block), l), dim3(kWaves * 64), lds, st, sa);
     TPQ_LAUNCH_CHECK("lloyd coarse_kernel");
@@ -1406,6 +1448,7 @@ static int run_levels(StepArgs sa, int l, int d, int* list2, int* count2, hipStr
                        "lloyd refine_kernel attr");
     if (rc) return rc;
     sa.eps = level_eps(KS, d, 2);
+    sa.level = 2;
     sa.list_in = sa.list;
     sa.count_in = sa.count;
     sa.list = list2;
@@ -1442,7 +1485,7 @@ static AssignLayout assign_layout(int d, int64_t m, int n) {
   L.prep_off = 0;
   L.frags_off = up(L.P.total);
   L.cmax_off = up(L.frags_off + (size_t)L.chunks * 8 * (2 * L.KS + 1) * 1024);
-  L.cflag_off = L.cmax_off + 8;
+  L.cflag_off = L.cmax_off + 4 * kCm;
   L.count1_off = L.cflag_off + 4;
   L.count2_off = L.count1_off + 4;
   L.partb_off = up(L.count2_off + 4);                               // [chunks][m] float2
@@ -1502,7 +1545,7 @@ static int run_assign(const float* A, const float* B, float* vals, int64_t* inds
   StepArgs sa{reinterpret_cast<const u32x4*>(p + P.hi_off), reinterpret_cast<const u32x4*>(p + P.mid_off),
               reinterpret_cast<const float2*>(p + P.norms_off), frags, cmax, scale, flag, cflag, inds, vals,
               nullptr, nullptr, list1, count1, (int)m, P.T,
-              level_eps(KS, d, 1), (float)(d + 4) / 16777216.0f, sqrtf((float)d) / 8192.0f,
+              level_eps(KS, d, 1), (float)(d + 4) / 16777216.0f, sqrtf((float)d) / 8192.0f, 1,
               chunked ? part_b : nullptr, chunked ? part_i : nullptr, chunk_stride};
   {
     const size_t lds = (size_t)8 * (KS + 1) * 1024 + sizeof(BlockListT<kCoarseList>);
@@ -1526,6 +1569,7 @@ static int run_assign(const float* A, const float* B, float* vals, int64_t* inds
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "lloyd refine_kernel attr");
     if (rc) return rc;
     sa.eps = level_eps(KS, d, 2);
+    sa.level = 2;
     sa.list_in = list1;
     sa.count_in = count1;
     sa.list = list2;
@@ -2430,7 +2474,7 @@ extern "C" int tpq_lloyd_step(const float* data, const void* prepared, const flo
                      reinterpret_cast<const float2*>(p + P.norms_off),
                      frags, cmax, scale, reinterpret_cast<const int*>(p + P.flag_off), cflag, inds, vals,
                      nullptr, nullptr, list, count, (int)m, P.T,
-                     0.f, (float)(d + 4) / 16777216.0f, sqrtf((float)d) / 8192.0f,
+                     0.f, (float)(d + 4) / 16777216.0f, sqrtf((float)d) / 8192.0f, 1,
                      nullptr, nullptr, 0};
   switch (KS) {
     case 1: rc = lloyd::run_levels<1>(sa, l, d, list2, count2, st); break;
