@@ -83,7 +83,13 @@ int tpq_ivfpq_scan_topk(const uint8_t* codes, const float* lut, const uint8_t* i
  * tpq_ivfpq_pack_codes (re)builds slots [slot_begin, slot_end) of `packed` from `codes`.
  * tpq_ivfpq_scan_topk_packed has the contract of tpq_ivfpq_scan_topk (bit-identical
  * results) but streams `packed`; `codes` is still needed for the exact re-evaluation of
- * the few candidates that pass the threshold filter. */
+ * the few candidates that pass the threshold filter.
+ * Launches: ONE for plain PQ with k <= 248 -- the scan workgroups merge their lists, a query split over
+ * n_split workgroups is written by the last of them to finish (a ticket per query), and a candidate
+ * band that overflowed is redone exactly by that workgroup -- otherwise three (scan, merge, the
+ * exact redo of flagged queries).  The tickets live in a zeroed 4-MiB device buffer the LIBRARY
+ * allocates per device on first use (hipMalloc; never during stream capture, where a call
+ * without a ring falls back to the three launches); the workspace stays caller-owned scratch. */
 int tpq_ivfpq_pack_codes(const uint8_t* codes, uint8_t* packed, int64_t n_slots, int m,
                          int64_t slot_begin, int64_t slot_end, tpq_stream_t stream);
 
@@ -259,12 +265,18 @@ int tpq_max_sim_split(const float* A, const float* B, float* vals, int64_t* inds
  * vals (optional, f32 [m]): the maximum itself -- the FAST value (within the bound, ~1e-5 of the
  * scale) for points decided by the selection, the exact one for re-checked points: good for an
  * inertia, not for bit comparisons.
- * Shapes: d <= 128, m < 2^31, padded slice 16 ceil(d/16) m floats < 2 GiB; otherwise
- * TPQ_ERR_UNSUPPORTED (use tpq_max_sim).  workspace: tpq_coarse_assign_workspace_bytes(d, m, n). */
+ * Wide vectors, 128 < d <= 1024 (GIST: 960), both metrics: fp16 selection GEMM-shaped (256 x 256 tiles,
+ * both operands through LDS), and the exact step runs on CANDIDATES -- for every undecided point the (2-3)
+ * centroids within twice the bound of its best get the exact kernel's own value (same instruction
+ * sequence), never all n of them; candidate lists that overflow (degenerate data) fall back to the
+ * exact kernel.  Problems below 2^33 multiply-adds go to tpq_max_sim directly (same labels).
+ * Shapes: d <= 128: m < 2^31, padded slice 16 ceil(d/16) m floats < 2 GiB; 128 < d <= 1024: m < 2^28,
+ * n <= 2^22 (workspace ~1.4 x the points); otherwise TPQ_ERR_UNSUPPORTED (use tpq_max_sim).
+ * workspace: tpq_coarse_assign_workspace_bytes(d, m, n). */
 int tpq_coarse_assign_supported(int d, int64_t m, int n);
 size_t tpq_coarse_assign_workspace_bytes(int d, int64_t m, int n);
 /* diagnostics: byte offset inside the workspace of the int32 count of points the last call
- * re-checked exactly */
+ * re-checked exactly (d > 128: points that got an exact step on their candidates) */
 size_t tpq_coarse_assign_count_offset(int d, int64_t m, int n);
 int tpq_coarse_assign(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n,
                       int metric, void* workspace, size_t workspace_bytes, tpq_stream_t stream);

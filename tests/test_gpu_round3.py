@@ -345,3 +345,60 @@ def test_assign_precision_fp32_opts_out_of_the_selection_kernels(monkeypatch):
         codes[prec] = pq.encode(x)
         assert ("MaxSimSelectHip" in calls) == (prec == "bf16x3"), (prec, calls)
     assert torch.equal(codes["bf16x3"], codes["fp32"])
+
+
+# ---------------------------------------------------------------------------------------------
+# fused finish of the packed scan (scan_packed_kernel RM > 0): one launch, the last workgroup of a query
+# writes it; tickets from the library's ring
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,k,n_split", [(64, 100, 16), (16, 10, 7), (8, 120, 3), (128, 100, 5), (32, 248, 2)])
+def test_fused_finish_over_many_calls_and_two_streams(K, m, k, n_split):
+    """a query split over n_split workgroups is finished by the last of them: many back-to-back calls on two
+    streams at once (fresh ticket stretches, reset by the finisher) all return the oracle's result"""
+    from test_gpu_kernels import _random_index
+    rng = np.random.default_rng(m * 131 + k)
+    n_cells, nq, n_probe = 40, 9, 12
+    storage, is_empty, start, sizes, a2i = _random_index(rng, m, n_cells, 400)
+    scan = K.IVFPQTopkHip(m=m)
+    st = T(storage)
+    packed = K.PackCodesHip()(st)
+    cases = []
+    for _ in range(3):
+        lut = (rng.standard_normal((m, nq, 256)) * 100).astype(np.float32)
+        cells = np.stack([rng.permutation(n_cells)[:n_probe] for _ in range(nq)])
+        npl = np.full(nq, n_probe, np.int64)
+        cs, sz = start[cells], sizes[cells]
+        ev, ea = c_oracle.scan_topk(storage, lut, is_empty, cs, sz, npl, k)
+        cases.append((T(lut), T(cs), T(sz), T(npl), ev, ea))
+    emp = T(is_empty)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    torch.cuda.synchronize()
+    for it in range(40):
+        lut, cs, sz, npl, ev, ea = cases[it % 3]
+        with torch.cuda.stream(streams[it % 2]):
+            v, a = scan.topk(st, lut, emp, cs, sz, npl, n_candidates=k, packed=packed, n_split=n_split)
+        outs.append((v, a, ev, ea))
+    torch.cuda.synchronize()
+    for v, a, ev, ea in outs:
+        assert np.array_equal(N(v), ev) and np.array_equal(N(a), ea)
+
+
+def test_graphed_search_replays_with_its_own_tickets():
+    """GraphedSearch captures the two-launch search; replays interleaved with eager calls (which draw other
+    ticket stretches) keep returning search()'s result"""
+    from torchpq_amd.index import IVFPQIndex
+    rng = np.random.default_rng(3)
+    d, n = 64, 20000
+    x = T(rng.standard_normal((d, n)).astype(np.float32))
+    idx = IVFPQIndex(d_vector=d, n_subvectors=16, n_cells=64, initial_size=512, device=DEV, verbose=0)
+    idx.train(x[:, :8000])
+    idx.add(x)
+    idx.n_probe = 8
+    q = T(rng.standard_normal((d, 4)).astype(np.float32))
+    ev, ei = idx.search(q, k=10)
+    g = idx.graphed_search(4, k=10)
+    for _ in range(5):
+        gv, gi = g(q)
+        v2, i2 = idx.search(q, k=10)
+        assert torch.equal(gv, ev) and torch.equal(gi, ei) and torch.equal(v2, ev) and torch.equal(i2, ei)

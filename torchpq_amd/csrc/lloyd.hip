@@ -461,7 +461,7 @@ struct BlockListT {
 template <int CAP>
 __device__ __forceinline__ void emit(const StepArgs& a, BlockListT<CAP>* bl, int b, int lane, bool valid, int64_t fi,
                                      int idx, float B1, float B2, float2 n2, float s, float cn, float cnr,
-                                     float inv_s2, bool exact_all, int64_t part_slot = -1) {
+                                     float inv_s2, bool exact_all, float c2, int64_t part_slot = -1) {
   if (a.part_b != nullptr) {  // chunked: this chunk's result of the point; decide_kernel does the rest
     if (valid) {
       a.part_b[part_slot] = make_float2(B1, B2);
@@ -477,10 +477,11 @@ __device__ __forceinline__ void emit(const StepArgs& a, BlockListT<CAP>* bl, int
   // Level 1 drops the products with the mid pieces: |sum (a C - ah Ch)| <= |a' - ah| (|Ch|max + |C - Ch|max) +
   // |a'| |C - Ch|max with what was ACTUALLY dropped of this point and of the worst centroid (|Ch| <= (1 + 2^-11)
   // 2 |c'|) -- about 0.4 of the worst case 2^-11 (|a'| + |c'|max)^2, and 7.5 % undecided points become 3 %.
+  // (c2 = max |C - Ch|, read ONCE by the caller: a load here, in the tile loop, sits behind the prefetched pieces
+  // on the in-order vmcnt and cost level 1 18 % -- or < 0 at level 2, which drops nothing)
   float dropped = 0.f;
-  if (a.level == 1) {
+  if (c2 >= 0.f) {
     const float a2 = __builtin_amdgcn_sqrtf(n2m);
-    const float c2 = __builtin_amdgcn_sqrtf(__uint_as_float(a.cmax2_bits[b * kCm + 2]));
     dropped = a2 * (2.002f * cn + c2) + 1.001f * an * c2;
   }
   float delta = 1.25f * (dropped + a.eps * t1 * t1 + a.eta * (2.f * cn + an) + a.eps_exact * t2 * t2);
@@ -598,6 +599,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
   }
   const float s = a.scale[b];
   const float cn = sqrtf(__uint_as_float(a.cmax2_bits[b * kCm])), cnr = sqrtf(__uint_as_float(a.cmax2_bits[b * kCm + 1]));
+  const float c2n = a.level == 1 ? sqrtf(__uint_as_float(a.cmax2_bits[b * kCm + 2])) : -1.f;
   const bool exact_all = (a.flag[b] | a.cflag[b]) != 0;
   const float inv_s2 = (1.f / s) * (1.f / s);
 
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void coarse_kernel(StepArgs a) {
     const float B2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
     if (o1 > m1 || (o1 == m1 && oi < idx)) idx = oi;
     const int64_t fi = tile * 32 + l31;
-    emit(a, bl, b, lane, half == 0 && fi < m, fi, idx, B1, B2, n2, s, cn, cnr, inv_s2, exact_all,
+    emit(a, bl, b, lane, half == 0 && fi < m, fi, idx, B1, B2, n2, s, cn, cnr, inv_s2, exact_all, c2n,
          (int64_t)chunk * m + fi);
   };
   using std::integral_constant;
@@ -768,6 +770,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
   }
   const float s = a.scale[b];
   const float cn = sqrtf(__uint_as_float(a.cmax2_bits[b * kCm])), cnr = sqrtf(__uint_as_float(a.cmax2_bits[b * kCm + 1]));
+  const float c2n = a.level == 1 ? sqrtf(__uint_as_float(a.cmax2_bits[b * kCm + 2])) : -1.f;
   const bool exact_all = (a.flag[b] | a.cflag[b]) != 0;
   const float inv_s2 = (1.f / s) * (1.f / s);
 
@@ -784,7 +787,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_kernel(StepArgs a) {
     const float B1 = fmaxf(m1, o1);
     const float B2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
     if (o1 > m1 || (o1 == m1 && oi < idx)) idx = oi;
-    emit(a, bl, b, lane, half == 0 && p >= 0, p, idx, B1, B2, n2, s, cn, cnr, inv_s2, exact_all,
+    emit(a, bl, b, lane, half == 0 && p >= 0, p, idx, B1, B2, n2, s, cn, cnr, inv_s2, exact_all, c2n,
          (int64_t)chunk * m + pos);
   };
 
@@ -1057,6 +1060,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_stream_kernel(StepArgs 
   }
   const float s = a.scale[0];
   const float cn = sqrtf(__uint_as_float(a.cmax2_bits[0])), cnr = sqrtf(__uint_as_float(a.cmax2_bits[1]));
+  const float c2n = -1.f;  // (level 2)
   const bool exact_all = (a.flag[0] | a.cflag[0]) != 0;
   const float inv_s2 = (1.f / s) * (1.f / s);
   {
@@ -1072,7 +1076,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void refine_stream_kernel(StepArgs 
     const float B1 = fmaxf(m1, o1);
     const float B2 = fmaxf(fminf(m1, o1), fmaxf(m2, o2));
     if (o1 > m1 || (o1 == m1 && oi < idx)) idx = oi;
-    emit(a, bl, 0, lane, half == 0 && p >= 0, p, idx, B1, B2, n2, s, cn, cnr, inv_s2, exact_all);
+    emit(a, bl, 0, lane, half == 0 && p >= 0, p, idx, B1, B2, n2, s, cn, cnr, inv_s2, exact_all, c2n);
   }
   flush_list(a, bl, 0);
 }
