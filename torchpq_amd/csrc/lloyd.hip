@@ -1757,10 +1757,18 @@ __global__ __launch_bounds__(CT == 2 ? 512 : 256) void gemm_kernel(GemmArgs a) {
       ++cb;
     }
     __syncthreads();  // stage g has landed; everyone is done with the other buffer (and with nbuf)
+#ifndef TPQ_EXP_NODMA  // (experiment: the K loop without its LDS-DMA fills, garbage results: 22.6 instead of 28.7 ms.
+                       // Two restructurings that were built and measured, neither kept: the points' fragments global ->
+                       // registers instead (half the fills, a third fewer LDS reads): 30.4 ms -- fragment-shaped
+                       // loads cost more on the vector memory path than they save in LDS; a ring of four 2-k-step
+                       // stages with inline-asm fills and a barrier that leaves the newest stage in flight
+                       // (`s_waitcnt vmcnt(4)`), next stage's first fragments read before the barrier: 31.0 ms --
+                       // twice the barriers cost more than the refill bubble they remove)
     if (g + 1 < n_stage) {
       const bool wrap = kst + 1 == n_kst;
       stage(wrap ? cb + 1 : cb, wrap ? 0 : kst + 1, (g + 1) & 1);
     }
+#endif
     if (kst == 0) {  // a new centroid block: its -N fragments (8 KiB; read after the K loop) and fresh accumulators
       for (int f = wave; f < 8; f += NW)
         __builtin_amdgcn_global_load_lds(
