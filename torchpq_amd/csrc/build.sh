@@ -31,5 +31,5 @@ for src in api.cpp scan.hip pack.hip select.hip lut.hip kmeans.hip kmeans_split.
   fi
 done
 for p in "${pids[@]:-}"; do [[ -n "$p" ]] && { wait "$p" || { echo "compile failed" >&2; exit 1; }; }; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${HERE}"/build/*.o
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -Wl,-z,defs -o "$OUT" "${HERE}"/build/*.o
 echo "built $OUT"
