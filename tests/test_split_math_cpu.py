@@ -88,3 +88,61 @@ def test_recheck_key_orders_like_value_desc_then_index_asc():
     back = np.where(ordered & 0x80000000, ordered & 0x7FFFFFFF, ~ordered & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
     assert np.array_equal(back.view(np.uint32), fb)
     assert np.array_equal((np.uint64(0xFFFFFFFF) - (key & np.uint64(0xFFFFFFFF))).astype(np.uint32), idx)
+
+
+# ---- round 3: the fp16 cascade (csrc/lloyd.hip) and the rank merge (scan_device.h) ----------
+def test_level_1_dropped_piece_bound_holds_with_the_measured_norms():
+    """|sum_k (a_k C_k - ah_k Ch_k)| <= |a - ah| (|Ch| + |C - Ch|) + |a| |C - Ch| for fp16 hi pieces (what emit()
+    and gdecide_kernel bound level 1 with), and it is well below the worst case 2^-11 (|a| + |c|)^2"""
+    rng = np.random.default_rng(7)
+    worst = []
+    for d in (16, 64, 128, 960):
+        a = (rng.standard_normal((200, d)) * rng.uniform(0.1, 4000, (200, 1))).astype(np.float32)
+        c = (rng.standard_normal((200, d)) * rng.uniform(0.1, 4000, (200, 1))).astype(np.float32)
+        C = (2 * c).astype(np.float32)
+        ah, Ch = a.astype(np.float16).astype(np.float32), C.astype(np.float16).astype(np.float32)
+        ra, rC = (a - ah).astype(np.float32), (C - Ch).astype(np.float32)
+        assert np.array_equal(ra.astype(np.float64), a.astype(np.float64) - ah), "a - ah is exact in fp32"
+        a64, C64, ah64, Ch64 = (v.astype(np.float64) for v in (a, C, ah, Ch))
+        dropped = np.abs((a64 * C64).sum(1) - (ah64 * Ch64).sum(1))
+        n = np.linalg.norm
+        bound = n(ra.astype(np.float64), axis=1) * (n(Ch64, axis=1) + n(rC.astype(np.float64), axis=1)) \
+            + n(a64, axis=1) * n(rC.astype(np.float64), axis=1)
+        assert (dropped <= bound * (1 + 1e-12)).all()
+        assert (n(Ch64, axis=1) <= (1 + 2.0 ** -11) * n(C64, axis=1)).all()
+        worst_case = 2.0 ** -11 * (n(a64, axis=1) + n(c.astype(np.float64), axis=1)) ** 2
+        worst.append(float(np.median(bound / worst_case)))
+    assert max(worst) < 0.6, worst   # "about 0.4 of the worst case"
+
+
+def test_bound_norms_travel_as_bf16_rounded_up():
+    """pack_bound_norms / unpack_bound_norms: each half is >= the fp32 value and within 2^-7 of it"""
+    rng = np.random.default_rng(8)
+    x = np.abs(np.concatenate([rng.standard_normal(1000) * 10.0 ** rng.uniform(-30, 30, 1000), [0.0, 1.0, 3.0e38]]))
+    x = x.astype(np.float32)
+    up = (((x.view(np.uint32).astype(np.uint64) + 0xFFFF) >> 16) << 16).astype(np.uint32).view(np.float32)
+    finite = np.isfinite(up)
+    assert (up[finite] >= x[finite]).all() and (up[finite] <= x[finite] * (1 + 2.0 ** -7)).all()
+    assert np.isinf(up[~finite]).all()   # an overflow only ever widens the bound (the point is listed)
+
+
+def test_rank_merge_places_every_entry_once_with_duplicates_ranked_by_list():
+    """scan_device.h rank_merge: position = own position + per other list the entries that precede it (strictly
+    better, or equal in an earlier list) -- a permutation of the merged order even with equal keys"""
+    rng = np.random.default_rng(9)
+    for L, LEN in ((8, 64), (4, 128), (3, 64)):
+        pool = rng.integers(0, 50, size=L * LEN).astype(np.uint64)       # many equal keys
+        lists = [np.sort(pool[l * LEN:(l + 1) * LEN])[::-1] for l in range(L)]   # best (largest) first
+        out = np.full(L * LEN, -1, np.int64)
+        for l in range(L):
+            for i, x in enumerate(lists[l]):
+                rank = i
+                for l2 in range(L):
+                    if l2 == l:
+                        continue
+                    y = lists[l2]
+                    rank += int(((y > x) | ((y == x) & (l2 < l))).sum())
+                assert out[rank] == -1, "two entries at one position"
+                out[rank] = int(x)
+        assert (out >= 0).all() and (np.diff(out) <= 0).all()
+        assert np.array_equal(out, np.sort(pool)[::-1].astype(np.int64))
