@@ -439,6 +439,8 @@ struct StepArgs {
   int64_t T;
   float eps, eps_exact, eta;   // eps: this level's fast-path bound, relative to (|a'| + |c'|max)^2; eta times sqrt(d)
   int level;                   // 1: the dropped pieces are bounded per point (emit), on top of eps
+  float* thr;                  // chunked level 1, candidate route: [thr_cap] threshold of the listed point (or null)
+  int thr_cap;
   // more than 256 centroids (tpq_coarse_assign): blockIdx.y = CHUNK of 256 centroids (all chunks in one
   // launch: one chunk's blocks alone fill half the chip); a chunk's (best, second) and in-chunk index of
   // every point go to part_*[chunk][point or list position], decide_kernel folds the chunks and decides
@@ -1134,7 +1136,13 @@ __global__ __launch_bounds__(256) void decide_kernel(StepArgs a, int n_chunks) {
     int base = 0;
     if (lane == leader) base = atomicAdd(a.count, __popcll(mk));
     base = __shfl(base, leader, 64);
-    if (listed) a.list[base + __popcll(mk & ((1ull << lane) - 1ull))] = p;
+    if (listed) {
+      const int slot = base + __popcll(mk & ((1ull << lane) - 1ull));
+      a.list[slot] = p;
+      // candidate route (cand_stream_kernel): every centroid at or above this may be the exact winner
+      if (LEVEL == 1 && a.thr && slot < a.thr_cap)
+        a.thr[slot] = B1 - 2.f * delta - (fabsf(B1) * (1.0f / 65536.0f) + 1.0e-30f);
+    }
   }
 }
 
@@ -1477,6 +1485,9 @@ struct AssignLayout {
   int KS, chunks, cap;
   size_t prep_off, frags_off, cmax_off, cflag_off, count1_off, count2_off, partb_off, parti_off, list1_off, list2_off,
       keys_off, ac_off, total;
+  // candidate route (chunked problems): thresholds, pairs, row copies
+  int cap2, pair_cap, dp;
+  size_t npairs_off, oflag_off, countfb_off, thr_off, pairs_off, bt_off, xt_off;
 };
 static AssignLayout assign_layout(int d, int64_t m, int n) {
   AssignLayout L;
@@ -1492,15 +1503,34 @@ static AssignLayout assign_layout(int d, int64_t m, int n) {
   L.cflag_off = L.cmax_off + 4 * kCm;
   L.count1_off = L.cflag_off + 4;
   L.count2_off = L.count1_off + 4;
-  L.partb_off = up(L.count2_off + 4);                               // [chunks][m] float2
+  L.npairs_off = L.count2_off + 4;
+  L.oflag_off = L.npairs_off + 4;
+  L.countfb_off = L.oflag_off + 4;
+  L.partb_off = up(L.countfb_off + 4);                              // [chunks][m] float2
   L.parti_off = up(L.partb_off + (size_t)L.chunks * m * 8);         // [chunks][m] u8
   L.list1_off = up(L.parti_off + (size_t)L.chunks * m);
   L.list2_off = up(L.list1_off + (size_t)m * 4);
   L.keys_off = up(L.list2_off + (size_t)m * 4);        // [m] u64 (level 3: zeroed)
   L.ac_off = up(L.keys_off + (size_t)m * 8);           // [d][cap] f32
   L.total = up(L.ac_off + (size_t)d * L.cap * 4);
+  // candidate route: the listed points' thresholds and row copies (a quarter of the points), the pairs, the
+  // centroids as rows
+  L.cap2 = (int)(((m / 4 > 8192 ? m / 4 : 8192) + 511) / 512 * 512);
+  if ((int64_t)L.cap2 > (m + 511) / 512 * 512) L.cap2 = (int)((m + 511) / 512 * 512);
+  L.pair_cap = 4 * L.cap2 > 65536 ? 4 * L.cap2 : 65536;
+  L.dp = (d + 15) / 16 * 16;
+  L.thr_off = L.total;
+  L.pairs_off = up(L.thr_off + (size_t)L.cap2 * 4);
+  L.bt_off = up(L.pairs_off + (size_t)L.pair_cap * 8);
+  L.xt_off = up(L.bt_off + (size_t)n * L.dp * 4);
+  L.total = up(L.xt_off + (size_t)L.cap2 * L.dp * 4);
   return L;
 }
+
+// the candidate route of a chunked problem (defined behind the wide path, whose pair machinery it shares)
+template <int KS>
+static int run_cand_tail(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n, char* ws,
+                         const AssignLayout& L, const u32x4* hi, const u32x4* frags, hipStream_t st);
 
 template <int KS>
 static int run_assign(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n, char* ws,
@@ -1549,7 +1579,7 @@ static int run_assign(const float* A, const float* B, float* vals, int64_t* inds
   StepArgs sa{reinterpret_cast<const u32x4*>(p + P.hi_off), reinterpret_cast<const u32x4*>(p + P.mid_off),
               reinterpret_cast<const float2*>(p + P.norms_off), frags, cmax, scale, flag, cflag, inds, vals,
               nullptr, nullptr, list1, count1, (int)m, P.T,
-              level_eps(KS, d, 1), (float)(d + 4) / 16777216.0f, sqrtf((float)d) / 8192.0f, 1,
+              level_eps(KS, d, 1), (float)(d + 4) / 16777216.0f, sqrtf((float)d) / 8192.0f, 1, nullptr, 0,
               chunked ? part_b : nullptr, chunked ? part_i : nullptr, chunk_stride};
   {
     const size_t lds = (size_t)8 * (KS + 1) * 1024 + sizeof(BlockListT<kCoarseList>);
@@ -1561,9 +1591,20 @@ static int run_assign(const float* A, const float* B, float* vals, int64_t* inds
     hipLaunchKernelGGL(kernel, dim3((unsigned)((wide + per_block - 1) / per_block), L.chunks), dim3(kWaves * 64), lds,
                        st, sa);
     TPQ_LAUNCH_CHECK("lloyd coarse_kernel");
+    // chunked problems: the undecided points do not go through levels 2 and 3 -- their CANDIDATES (the centroids
+    // within twice level 1's bound of the best: ~2 per point) get the exact kernel's value (the wide path's
+    // machinery).  TPQ_COARSE_ASSIGN_CAND=0: levels 2 and 3 (A/B)
+    static const bool cand_route = !(getenv("TPQ_COARSE_ASSIGN_CAND") && atoi(getenv("TPQ_COARSE_ASSIGN_CAND")) == 0);
     if (chunked) {
+      const bool cand = cand_route && n <= (1 << 22);  // (a pair entry carries the centroid in 22 bits)
+      if (cand) {
+        sa.thr = reinterpret_cast<float*>(ws + L.thr_off);
+        sa.thr_cap = L.cap2;
+      }
       hipLaunchKernelGGL(decide_kernel<1>, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, sa, L.chunks);
       TPQ_LAUNCH_CHECK("lloyd decide_kernel");
+      if (cand)
+        return run_cand_tail<KS>(A, B, vals, inds, d, m, n, ws, L, reinterpret_cast<const u32x4*>(p + P.hi_off), frags, st);
     }
   }
   {
@@ -2352,6 +2393,165 @@ static int run_wide(const float* A, const float* B, float* vals, int64_t* inds, 
   return launch_max_sim_list(A, B, vals, inds, 1, d, (int)m, n, euclid, list1, count_fb, keys, Ac, L.cap3, st);
 }
 
+
+// ---- the candidate route of the narrow path (d <= 128, many centroids) ---------------------------------------
+// Level 1 of a chunked problem leaves 3-10 % of the points undecided.  Levels 2 and 3 (refine_stream_kernel:
+// three products against every chunk; then the exact kernel over ALL centroids for what is left) cost 0.8 +
+// 1.8 of the 7.4 ms at 1 M x 16 384 x 128.  Instead: the listed points' hi pieces stay in registers (64 points
+// per wave: two column tiles share every centroid fragment), the hi fragments and -N of all chunks stream
+// through a double-buffered LDS ring, and every value at or above the point's threshold (level 1's best key
+// minus twice ITS bound, decide_kernel) is a candidate pair for pair_exact_kernel.  One product, no top-2.
+struct CandStreamArgs {
+  const u32x4* hi;       // [T][Q][32][64 B] (the points' hi pieces, prep layout)
+  const u32x4* frags;    // [units][2 KS + 1][64]
+  const int* list_in;
+  const int* count_in;
+  const float* thr;      // [cap]
+  int cap;               // listed positions handled here: < min(count, cap)
+  int n_half;            // half chunks (4 units each)
+  int n;                 // centroids (units beyond are padding)
+  int64_t T;
+};
+constexpr int kCandPoints = kWaves * 64;  // listed positions per block
+
+template <int KS>
+__global__ __launch_bounds__(kWaves * 64) void cand_stream_kernel(CandStreamArgs c, GemmArgs ga) {
+  constexpr int FPU = 2 * KS + 1, FL = KS + 1, HB = 4 * FL * 1024, Q = (KS + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 half chunks (-N + hi fragments), PairList
+  int cnt = *c.count_in;
+  cnt = cnt < c.cap ? cnt : c.cap;
+  if ((int64_t)blockIdx.x * kCandPoints >= cnt) return;  // block-uniform
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int l31 = lane & 31, half = lane >> 5;
+  PairList* pl = reinterpret_cast<PairList*>(smem + 2 * HB);
+  if (threadIdx.x == 0) pl->n = 0;
+  auto stage = [&](int h) {  // half chunk h -> buffer h & 1: per unit -N, then the hi piece of every k-step
+    const char* src = reinterpret_cast<const char*>(c.frags) + (size_t)h * 4 * FPU * 1024;
+    char* dst = smem + (h & 1) * HB;
+    for (int f = wave; f < 4 * FL; f += kWaves) {
+      const int unit = f / FL, j = f % FL;
+      const int sf = unit * FPU + (j ? 2 * j - 1 : 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + sf * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
+    }
+  };
+  stage(0);
+  const int64_t slice = c.T * Q * 2048;
+  const __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(c.hi)), 0, (int)slice, 0x00020000);
+  f16x8 xs[KS][2];
+  float thr[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int64_t pos = (int64_t)blockIdx.x * kCandPoints + wave * 64 + ct * 32 + l31;
+    const int p = pos < cnt ? c.list_in[pos] : -1;
+    thr[ct] = p >= 0 ? c.thr[pos] : INFINITY;
+    const int voff = p >= 0 ? (p >> 5) * (Q * 2048) + (p & 31) * 64 + half * 16 : 0x7ffffff0;
+    static_for<0, KS>([&](auto s_c) {
+      constexpr int st = decltype(s_c)::value;
+      xs[st][ct] = __builtin_bit_cast(
+          f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_hi, voff, (st >> 1) * 2048 + (st & 1) * 32, 0));
+    });
+  }
+  bf16x8 bones = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (half == 0) {
+    bones[0] = (__bf16)1.0f;
+    bones[1] = (__bf16)1.0f;
+    bones[2] = (__bf16)1.0f;
+  }
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int h = 0; h < c.n_half; ++h) {
+    __syncthreads();  // half chunk h has landed (vmcnt(0) + barrier); everyone is done with the other buffer
+    if (h + 1 < c.n_half) stage(h + 1);
+    // (pairs are appended in every stage, so pl->n is not stable anywhere: the decision to flush is an OR over
+    // the block, taken every eighth stage -- ~70 appends per block in between against 2 048 spare entries)
+    if ((h & 7) == 7 && __syncthreads_or(pl->n >= kPairList / 2)) flush_pairs(ga, pl, blockIdx.x * (unsigned)kCandPoints);
+    const u32x4* base = reinterpret_cast<const u32x4*>(smem + (h & 1) * HB) + lane;
+#pragma unroll
+    for (int U = 0; U < 4; ++U) {
+      const u32x4* up = base + U * FL * 64;
+      f32x16 acc[2] = {zero, zero};
+      static_for<0, KS>([&](auto s_c) {
+        constexpr int st = decltype(s_c)::value;
+        const f16x8 cf = __builtin_bit_cast(f16x8, up[(1 + st) * 64]);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cf, xs[st][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cf, xs[st][1], acc[1], 0, 0, 0);
+      });
+      const bf16x8 nf = __builtin_bit_cast(bf16x8, up[0]);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nf, bones, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(nf, bones, acc[1], 0, 0, 0);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        float mx = acc[ct][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[ct][r]);
+        if (__ballot(mx >= thr[ct]) == 0ull) continue;  // (nearly every tile)
+        const unsigned rowbits = (unsigned)(wave * 64 + ct * 32 + l31) << 22;
+        const int cbase = (4 * h + U) * 32 + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int cen = cbase + (r & 3) + 8 * (r >> 2);
+          const bool hit = acc[ct][r] >= thr[ct] && cen < c.n;
+          const unsigned long long mk = __ballot(hit);
+          if (mk) {
+            const int leader = __ffsll((long long)mk) - 1;
+            int b0 = 0;
+            if (lane == leader) b0 = atomicAdd(&pl->n, __popcll(mk));  // LDS
+            b0 = __shfl(b0, leader, 64);
+            const int slot = b0 + __popcll(mk & ((1ull << lane) - 1ull));
+            if (hit && slot < kPairList) pl->item[slot] = rowbits | (unsigned)cen;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  flush_pairs(ga, pl, blockIdx.x * (unsigned)kCandPoints);
+}
+
+template <int KS>
+static int run_cand_tail(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n, char* ws,
+                         const AssignLayout& L, const u32x4* hi, const u32x4* frags, hipStream_t st) {
+  int* count1 = reinterpret_cast<int*>(ws + L.count1_off);
+  int* n_pairs = reinterpret_cast<int*>(ws + L.npairs_off);
+  int* oflag = reinterpret_cast<int*>(ws + L.oflag_off);
+  int* count_fb = reinterpret_cast<int*>(ws + L.countfb_off);
+  int* list1 = reinterpret_cast<int*>(ws + L.list1_off);
+  float* thr = reinterpret_cast<float*>(ws + L.thr_off);
+  uint2* pairs = reinterpret_cast<uint2*>(ws + L.pairs_off);
+  float* Bt = reinterpret_cast<float*>(ws + L.bt_off);
+  float* Xt = reinterpret_cast<float*>(ws + L.xt_off);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws + L.keys_off);
+  float* Ac = reinterpret_cast<float*>(ws + L.ac_off);
+  const size_t lds = (size_t)2 * 4 * (KS + 1) * 1024 + sizeof(PairList);
+  auto kernel = cand_stream_kernel<KS>;
+  int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds), "lloyd cand_stream_kernel attr");
+  if (rc) return rc;
+  CandStreamArgs ca{hi, frags, list1, count1, thr, L.cap2, 2 * L.chunks, n, L.P.T};
+  GemmArgs ga{};
+  ga.pairs = pairs;
+  ga.pair_count = n_pairs;
+  ga.pair_cap = L.pair_cap;
+  ga.overflow = oflag;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)(L.cap2 / kCandPoints)), dim3(kWaves * 64), lds, st, ca, ga);
+  TPQ_LAUNCH_CHECK("lloyd cand_stream_kernel");
+  hipLaunchKernelGGL(rows_kernel, dim3((unsigned)((n + 31) / 32)), dim3(64), 0, st, B, (int64_t)n,
+                     static_cast<const int*>(nullptr), static_cast<const int*>(nullptr), n, Bt, d, L.dp);
+  TPQ_LAUNCH_CHECK("lloyd rows_kernel");
+  hipLaunchKernelGGL(rows_kernel, dim3((unsigned)(L.cap2 / 32)), dim3(64), 0, st, A, m, list1, count1, L.cap2, Xt, d, L.dp);
+  TPQ_LAUNCH_CHECK("lloyd rows_kernel");
+  hipLaunchKernelGGL(pair_exact_kernel, dim3(2048), dim3(256), 0, st, Xt, Bt, pairs, n_pairs, L.pair_cap, list1, keys,
+                     L.dp, 1);
+  TPQ_LAUNCH_CHECK("lloyd pair_exact_kernel");
+  hipLaunchKernelGGL(gdecode_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, list1, count1, keys, vals, inds,
+                     (int)m, L.cap2, oflag, count_fb);
+  TPQ_LAUNCH_CHECK("lloyd gdecode_kernel");
+  // (normally over zero points: pair lists that overflowed, or more listed points than the row copies hold)
+  return launch_max_sim_list(A, B, vals, inds, 1, d, (int)m, n, 1, list1, count_fb, keys, Ac, L.cap, st);
+}
+
 }  // namespace lloyd
 
 // hooks for tpq_coarse_assign (assign_fast.hip): the cascade takes euclidean problems with d <= 128
@@ -2374,7 +2574,12 @@ size_t lloyd_assign_workspace_bytes(int d, int64_t m, int n) {
   return d > 128 ? lloyd::wide_layout(d, m, n).total : lloyd::assign_layout(d, m, n).total;
 }
 size_t lloyd_assign_count_offset(int d, int64_t m, int n) {  // wide: the points with an exact step (candidates)
-  return d > 128 ? lloyd::wide_layout(d, m, n).count1_off : lloyd::assign_layout(d, m, n).count2_off;
+  if (d > 128) return lloyd::wide_layout(d, m, n).count1_off;
+  const lloyd::AssignLayout L = lloyd::assign_layout(d, m, n);
+  // (chunked problems on the candidate route: the points that got an exact step on their candidates)
+  const bool cand = L.chunks > 1 && n <= (1 << 22) &&
+                    !(getenv("TPQ_COARSE_ASSIGN_CAND") && atoi(getenv("TPQ_COARSE_ASSIGN_CAND")) == 0);
+  return cand ? L.count1_off : L.count2_off;
 }
 int lloyd_assign(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n, int euclid,
                  char* ws, hipStream_t st) {
@@ -2486,7 +2691,7 @@ extern "C" int tpq_lloyd_step(const float* data, const void* prepared, const flo
                      reinterpret_cast<const float2*>(p + P.norms_off),
                      frags, cmax, scale, reinterpret_cast<const int*>(p + P.flag_off), cflag, inds, vals,
                      nullptr, nullptr, list, count, (int)m, P.T,
-                     0.f, (float)(d + 4) / 16777216.0f, sqrtf((float)d) / 8192.0f, 1,
+                     0.f, (float)(d + 4) / 16777216.0f, sqrtf((float)d) / 8192.0f, 1, nullptr, 0,
                      nullptr, nullptr, 0};
   switch (KS) {
     case 1: rc = lloyd::run_levels<1>(sa, l, d, list2, count2, st); break;
