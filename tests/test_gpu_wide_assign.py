@@ -120,3 +120,23 @@ def test_wide_small_problems_take_the_fp32_kernel_and_predict_uses_the_path():
     fast = km.predict(q)
     _, ref = km.get_labels(q, km.centroids)
     assert torch.equal(fast, ref)
+
+
+@pytest.mark.parametrize("shape", [(64, 5644, 1905), (200, 3000, 600), (128, 4000, 300), (960, 1500, 520)])
+def test_centroids_beyond_the_fp16_range_of_the_data_scale_go_exact(shape, monkeypatch):
+    """data with a spread of 1 around 1000, centroids with a spread of 50: the fp16 scale is set by the data, EVERY
+    centroid overflows it (keys inf / NaN, threshold undefined) -- the problem is flagged and the whole list must
+    go to the exact kernel, on the candidate routes of the narrow (chunked) and the wide path alike
+    (found by tools/selection_soak.py --mode cascade: the candidate pass emitted nothing and no fallback ran)"""
+    import torchpq_amd.kernels as K
+    monkeypatch.setenv("TPQ_COARSE_ASSIGN_WIDE_MIN_WORK", "1")
+    monkeypatch.setenv("TPQ_COARSE_ASSIGN_CASCADE_MIN_N", "1")
+    d, m, n = shape
+    rng = np.random.default_rng(d + m)
+    x = (1000.0 + rng.standard_normal((d, m))).astype(np.float32)
+    cent = (x[:, rng.integers(0, m, n)] + 50.0 * rng.standard_normal((d, n))).astype(np.float32)
+    op = K.CoarseAssignHip(distance="euclidean")
+    lab = op(T(x), T(cent))
+    _, l32 = K.MaxSimHip(distance="euclidean")(T(x), T(cent), dim=1)
+    assert torch.equal(lab, l32) and int(lab.max()) < n
+    assert op.last_rechecked() == m

@@ -1,7 +1,12 @@
 #!/usr/bin/env python
-"""Randomised soak of the two selection kernels: labels must equal the bit-exact fp32 kernel's on
+"""Randomised soak of the selection kernels: labels must equal the bit-exact fp32 kernel's on
 every case.  Shapes and data kinds are drawn at random (Gaussian, SIFT-like integers, heavy-tailed,
-tight clusters, large common offset, tiny and huge magnitudes, duplicated centroids)."""
+tight clusters, large common offset, tiny and huge magnitudes, duplicated centroids).
+
+    python tools/selection_soak.py [--cases 60] [--seed 0]           tpq_coarse_assign (d <= 128) + tpq_max_sim_select
+    python tools/selection_soak.py --mode cascade --cases 200        the fp16 cascades, forced on every shape:
+        tpq_coarse_assign narrow (candidate route from 2 chunks on) and wide (128 < d <= 1024), tpq_lloyd_step
+(the cascade mode sets TPQ_COARSE_ASSIGN_CASCADE_MIN_N=1 / TPQ_COARSE_ASSIGN_WIDE_MIN_WORK=1 itself)"""
 import argparse
 import json
 import os
@@ -10,6 +15,9 @@ import sys
 import numpy as np
 import torch
 
+if "--mode" in sys.argv and sys.argv[sys.argv.index("--mode") + 1] == "cascade":
+    os.environ.setdefault("TPQ_COARSE_ASSIGN_CASCADE_MIN_N", "1")   # (read once by the library)
+    os.environ.setdefault("TPQ_COARSE_ASSIGN_WIDE_MIN_WORK", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from torchpq_amd import kernels as K  # noqa: E402
 
@@ -42,9 +50,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--mode", default="selection", choices=["selection", "cascade"])
+    ap.add_argument("--trace", action="store_true", help="print every case before it runs and synchronise after it")
+    ap.add_argument("--only-case", type=int, default=-1, help="cascade mode: run this case alone (same random stream)")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     dev = "cuda:0"
+    if a.mode == "cascade":
+        return cascade_soak(a, rng, dev)
     bad, log = [], {"coarse": 0, "select": 0, "rechecked_share_max": 0.0}
     for c in range(a.cases):
         kind = KINDS[c % len(KINDS)]
@@ -70,6 +83,62 @@ def main():
         log["select"] += 1
         if not torch.equal(got, want):
             bad.append(("select", kind, l, d2, m, n2, dist, int((got != want).sum())))
+    log["mismatching_cases"] = bad
+    print(json.dumps(log))
+    sys.exit(1 if bad else 0)
+
+
+def cascade_soak(a, rng, dev):
+    bad = []
+    log = {"narrow": 0, "wide": 0, "lloyd": 0, "exact_step_share_max": {"narrow": 0.0, "wide": 0.0}}
+    for c in range(a.cases):
+        kind = KINDS[c % len(KINDS)]
+        dist = "euclidean" if rng.random() < 0.7 else "inner"
+        # narrow: d <= 128; euclidean problems take the cascade (chunked from 257 centroids on: candidate route)
+        d, m, n = int(rng.integers(1, 129)), int(rng.integers(1, 30000)), int(rng.integers(1, 6000))
+        A, B = make(rng, kind, d, m, n, dev)
+        run = a.only_case < 0 or a.only_case == c
+        if a.trace and run:
+            print("case", c, "narrow", kind, d, m, n, dist, flush=True)
+        if run:
+            op = K.CoarseAssignHip(distance=dist)
+            got = op(A, B)
+            if a.trace:
+                torch.cuda.synchronize()
+            want = K.MaxSimHip(distance=dist)(A, B, dim=1)[1]
+            log["narrow"] += 1
+            log["exact_step_share_max"]["narrow"] = max(log["exact_step_share_max"]["narrow"], op.last_rechecked() / m)
+            if not torch.equal(got, want):
+                bad.append(("narrow", kind, d, m, n, dist, int((got != want).sum())))
+        # wide: 128 < d <= 1024, both metrics
+        d, m, n = int(rng.integers(129, 1025)), int(rng.integers(1, 12000)), int(rng.integers(1, 3000))
+        A, B = make(rng, kind, d, m, n, dev)
+        if a.trace and run:
+            print("case", c, "wide", kind, d, m, n, dist, flush=True)
+        if run:
+            op = K.CoarseAssignHip(distance=dist)
+            got = op(A, B)
+            if a.trace:
+                torch.cuda.synchronize()
+                print("  exact-step share", op.last_rechecked() / m, flush=True)
+            want = K.MaxSimHip(distance=dist)(A, B, dim=1)[1]
+            log["wide"] += 1
+            log["exact_step_share_max"]["wide"] = max(log["exact_step_share_max"]["wide"], op.last_rechecked() / m)
+            if not torch.equal(got, want):
+                bad.append(("wide", kind, d, m, n, dist, int((got != want).sum())))
+        # one Lloyd step on prepared data (euclidean, d <= 64, k <= 256)
+        l, d2, n2 = int(rng.integers(1, 5)), int(rng.integers(1, 65)), int(rng.integers(1, 257))
+        As, Bs = zip(*[make(rng, kind, d2, m, n2, dev) for _ in range(l)])
+        A3, B3 = torch.stack(As).contiguous(), torch.stack(Bs).contiguous()
+        if a.trace and run:
+            print("case", c, "lloyd", kind, l, d2, m, n2, flush=True)
+        if run and K.LloydStepHip.supported(l, d2, m, n2):
+            step = K.LloydStepHip(A3, B3)
+            _, got, _ = step(B3, update=False)
+            want = K.MaxSimHip(distance="euclidean")(A3, B3, dim=2)[1]
+            log["lloyd"] += 1
+            if not torch.equal(got, want):
+                bad.append(("lloyd", kind, l, d2, m, n2, int((got != want).sum())))
     log["mismatching_cases"] = bad
     print(json.dumps(log))
     sys.exit(1 if bad else 0)

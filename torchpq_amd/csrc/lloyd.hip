@@ -1140,8 +1140,12 @@ __global__ __launch_bounds__(256) void decide_kernel(StepArgs a, int n_chunks) {
       const int slot = base + __popcll(mk & ((1ull << lane) - 1ull));
       a.list[slot] = p;
       // candidate route (cand_stream_kernel): every centroid at or above this may be the exact winner
+      // (a flagged problem -- non-finite data, centroids beyond fp16's range: delta = inf, the keys may be inf or
+      // NaN -- emits no candidates at all: gdecode_kernel sends its whole list to the exact kernel)
       if (LEVEL == 1 && a.thr && slot < a.thr_cap)
-        a.thr[slot] = B1 - 2.f * delta - (fabsf(B1) * (1.0f / 65536.0f) + 1.0e-30f);
+        a.thr[slot] = (a.flag[0] | a.cflag[0]) != 0
+                          ? __builtin_nanf("")  // (no value compares >= NaN, not even inf)
+                          : B1 - 2.f * delta - (fabsf(B1) * (1.0f / 65536.0f) + 1.0e-30f);
     }
   }
 }
@@ -1696,6 +1700,7 @@ struct GemmArgs {
   int* pair_count;
   int pair_cap;
   int* overflow;         // pass 2: set when a pair was dropped
+  int n_centroids;       // pass 2: centroids beyond are padding (never a pair, whatever their value)
 };
 
 // the block's staged pairs -> the global list.  Called by all threads, at points where nobody appends.
@@ -1777,7 +1782,10 @@ __global__ __launch_bounds__(CT == 2 ? 512 : 256) void gemm_kernel(GemmArgs a) {
     b1[ct] = -INFINITY;
     b2[ct] = -INFINITY;
     bu[ct] = 0;
-    thr[ct] = INFINITY;
+    // (NaN: no value compares >= it.  With +inf a column of garbage fragments -- the rows of the last block beyond
+    // the list are never gathered -- that happened to hold an inf passed the test: a pair of a list position
+    // beyond the count, an address from an unwritten list entry, a memory fault: tools/selection_soak.py seed 11)
+    thr[ct] = __builtin_nanf("");
     if (CAND) {
       const int64_t row = (int64_t)pb * 256 + wr * (CT * 32) + ct * 32 + l31;
       if (row < rows) thr[ct] = a.thr[row];
@@ -1885,7 +1893,7 @@ __global__ __launch_bounds__(CT == 2 ? 512 : 256) void gemm_kernel(GemmArgs a) {
             const int cbase = cb * 256 + wc * 128 + rt * 32 + 4 * half;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const bool hit = acc[rt][ct][r] >= thr[ct];
+              const bool hit = acc[rt][ct][r] >= thr[ct] && cbase + (r & 3) + 8 * (r >> 2) < a.n_centroids;
               const unsigned long long mk = __ballot(hit);
               if (mk) {
                 const int leader = __ffsll((long long)mk) - 1;
@@ -2111,7 +2119,11 @@ __global__ __launch_bounds__(256) void gdecide_kernel(GDecideArgs a) {
     if (listed) {
       const int slot = base + __popcll(mk & ((1ull << lane) - 1ull));
       a.list[slot] = p;
-      if (slot < a.cap) a.thr[slot] = B1 - 2.f * delta - (fabsf(B1) * (1.0f / 65536.0f) + 1.0e-30f);
+      // (a flagged problem -- delta = inf, keys possibly inf / NaN -- emits no candidates: gdecode_kernel sends
+      // its whole list to the exact kernel)
+      if (slot < a.cap)
+        a.thr[slot] = (a.flag[0] | a.cflag[0]) != 0 ? __builtin_nanf("")  // (no value compares >= NaN, not even inf)
+                                                    : B1 - 2.f * delta - (fabsf(B1) * (1.0f / 65536.0f) + 1.0e-30f);
     }
   }
 }
@@ -2219,10 +2231,11 @@ __global__ __launch_bounds__(256) void pair_exact_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void gdecode_kernel(const int* __restrict__ list, const int* __restrict__ count,
                                                      const unsigned long long* __restrict__ keys,
                                                      float* __restrict__ vals, int64_t* __restrict__ inds, int m, int cap,
-                                                     const int* __restrict__ overflow, int* __restrict__ count_fb) {
+                                                     const int* __restrict__ overflow, const int* __restrict__ flag,
+                                                     const int* __restrict__ cflag, int* __restrict__ count_fb) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   const int cnt = *count < m ? *count : m;
-  if (p == 0) *count_fb = (*overflow != 0 || cnt > cap) ? cnt : 0;
+  if (p == 0) *count_fb = (*overflow != 0 || cnt > cap || (flag[0] | cflag[0]) != 0) ? cnt : 0;
   if (p >= cnt) return;
   const int i = list[p];
   const unsigned long long key = keys[i];
@@ -2358,7 +2371,7 @@ static int run_wide(const float* A, const float* B, float* vals, int64_t* inds, 
   {  // pass 1
     const int pblocks = (int)(L.T / 8);
     GemmArgs ga{c1, phi, cnorm, part_b, part_i, L.KAp, L.ncb, L.ysplit, pblocks, rows1, nullptr, nullptr, nullptr, nullptr,
-                0, nullptr};
+                0, nullptr, n};
     hipLaunchKernelGGL(k_top2, dim3(gemm_grid(pblocks, L.ysplit)), dim3(gemm_threads), lds, st, ga);
     TPQ_LAUNCH_CHECK("lloyd gemm_kernel");
     // (ranges of ceil(ncb / ysplit) centroid blocks: the last ones may be empty and write nothing)
@@ -2373,7 +2386,7 @@ static int run_wide(const float* A, const float* B, float* vals, int64_t* inds, 
                        L.cap2);
     TPQ_LAUNCH_CHECK("lloyd ggather_kernel");
     GemmArgs ga{c1, p2, cnorm, nullptr, nullptr, L.KAp, L.ncb, L.ysplit, L.cap2 / 256, (int64_t)L.cap2, count1, thr, pairs,
-                n_pairs, L.pair_cap, oflag};
+                n_pairs, L.pair_cap, oflag, n};
     hipLaunchKernelGGL(k_cand, dim3(gemm_grid(L.cap2 / 256, L.ysplit)), dim3(gemm_threads), lds, st, ga);
     TPQ_LAUNCH_CHECK("lloyd gemm_kernel (candidates)");
   }
@@ -2387,7 +2400,7 @@ static int run_wide(const float* A, const float* B, float* vals, int64_t* inds, 
                      L.dp, euclid);
   TPQ_LAUNCH_CHECK("lloyd pair_exact_kernel");
   hipLaunchKernelGGL(gdecode_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, list1, count1, keys, vals, inds,
-                     (int)m, L.cap2, oflag, count_fb);
+                     (int)m, L.cap2, oflag, flag, cflag, count_fb);
   TPQ_LAUNCH_CHECK("lloyd gdecode_kernel");
   // (normally over zero points)
   return launch_max_sim_list(A, B, vals, inds, 1, d, (int)m, n, euclid, list1, count_fb, keys, Ac, L.cap3, st);
@@ -2445,7 +2458,7 @@ __global__ __launch_bounds__(kWaves * 64) void cand_stream_kernel(CandStreamArgs
   for (int ct = 0; ct < 2; ++ct) {
     const int64_t pos = (int64_t)blockIdx.x * kCandPoints + wave * 64 + ct * 32 + l31;
     const int p = pos < cnt ? c.list_in[pos] : -1;
-    thr[ct] = p >= 0 ? c.thr[pos] : INFINITY;
+    thr[ct] = p >= 0 ? c.thr[pos] : __builtin_nanf("");  // (NaN: no value compares >= it, not even an inf)
     const int voff = p >= 0 ? (p >> 5) * (Q * 2048) + (p & 31) * 64 + half * 16 : 0x7ffffff0;
     static_for<0, KS>([&](auto s_c) {
       constexpr int st = decltype(s_c)::value;
@@ -2546,9 +2559,11 @@ static int run_cand_tail(const float* A, const float* B, float* vals, int64_t* i
                      L.dp, 1);
   TPQ_LAUNCH_CHECK("lloyd pair_exact_kernel");
   hipLaunchKernelGGL(gdecode_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, list1, count1, keys, vals, inds,
-                     (int)m, L.cap2, oflag, count_fb);
+                     (int)m, L.cap2, oflag, reinterpret_cast<const int*>(ws + L.prep_off + L.P.flag_off),
+                     reinterpret_cast<const int*>(ws + L.cflag_off), count_fb);
   TPQ_LAUNCH_CHECK("lloyd gdecode_kernel");
-  // (normally over zero points: pair lists that overflowed, or more listed points than the row copies hold)
+  // (normally over zero points: pair lists that overflowed, more listed points than the row copies hold, or a
+  // flagged problem)
   return launch_max_sim_list(A, B, vals, inds, 1, d, (int)m, n, 1, list1, count_fb, keys, Ac, L.cap, st);
 }
 
