@@ -114,23 +114,12 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
   auto a_row = [&](int k) -> const float* { return Ab + (int64_t)(k < d ? k : d - 1) * a_cols; };
   auto b_row = [&](int k) -> const float* { return Bb + (int64_t)(k < d ? k : d - 1) * n; };
 
-  // |a|^2, one ascending-k fma chain per point; 16 loads in flight per step (a plain loop waits
-  // out one memory latency per dimension)
+  // |a|^2, one ascending-k fma chain per point -- formed from the MFMA operands of the FIRST centroid chunk's
+  // slabs (a lane holds the dimensions of its parity; one half-swap per pair hands every lane both), not by a
+  // pass of its own: that pass read every point's column a second and (both half-waves) a third time, and for
+  // listed points every one of those reads is a cache line of its own -- level 3 of the Lloyd step (0.3 % of
+  // 64 M points scattered over 16 GB) spent 0.55 ms mostly there.
   float a2 = 0.f;
-  if (euclidean) {
-    int k = 0;
-    for (; k + 16 <= d; k += 16) {
-      float x[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) x[u] = a_row(k + u)[xoff];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) a2 = fmaf(x[u], x[u], a2);
-    }
-    for (; k < d; ++k) {
-      const float x = a_row(k)[xoff];
-      a2 = fmaf(x, x, a2);
-    }
-  }
 
   float best = -INFINITY;
   int besti = 0;
@@ -220,6 +209,16 @@ __global__ __launch_bounds__(256, 2) void max_sim_kernel(const float* __restrict
 #pragma unroll
         for (int t = 0; t < 8; ++t)
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t], xc[j], acc[t], 0, 0, 0);
+        if (euclidean && c0 == c_lo) {  // (block-uniform) the two squares of this pair of dimensions, ascending
+          float xe = xc[j], xo = xc[j];
+          // (inline asm, hazard wait states inside the string: max_sim_codebook_kernel's note)
+          asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(xe), "+v"(xo));
+          const int k = sb * kMsKC + 2 * j;  // rows past d hold a clamped row: they are not part of |a|^2
+          xe = k < d ? xe : 0.f;
+          xo = k + 1 < d ? xo : 0.f;
+          a2 = fmaf(xe, xe, a2);
+          a2 = fmaf(xo, xo, a2);
+        }
         // order inside the k-step: the next k-step's LDS reads first, then the 8 MFMAs (left to
         // itself the scheduler sinks the reads behind six of the MFMAs and the next k-step starts
         // by waiting for them); the barrier keeps later k-steps' reads from being hoisted here
