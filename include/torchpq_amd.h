@@ -260,8 +260,10 @@ int tpq_max_sim_split(const float* A, const float* B, float* vals, int64_t* inds
  * centroids of the oracle's fp32 arithmetic (ascending-k fmaf chains; ties -> smallest index).
  * An error-bounded top-2 selection decides every point whose two best fast values differ by more
  * than twice the bound; the others are re-evaluated exactly on the device.  Euclidean problems with
- * >= 4 096 centroids take the three-level fp16 cascade of tpq_lloyd_step (points prepared per call,
- * the centroids in chunks of 256); the others the two-piece bf16 selection.
+ * >= 4 096 centroids: the points are prepared per call as tpq_lloyd_prepare does, one fp16 product
+ * against the centroids in chunks of 256 decides 90-95 % of them, and the rest get the exact kernel's
+ * own value for each of their CANDIDATES (the 2-3 centroids within twice the bound of the best);
+ * the others the two-piece bf16 selection with the exact kernel over what it leaves.
  * vals (optional, f32 [m]): the maximum itself -- the FAST value (within the bound, ~1e-5 of the
  * scale) for points decided by the selection, the exact one for re-checked points: good for an
  * inertia, not for bit comparisons.
