@@ -1088,7 +1088,10 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
       // it evicted was worse still.)
       const Key kl = readlane_key(sel.top.k[R - 1], 63);
 #ifndef TPQ_EXP_NO_OVERFLOW_FLAG  // knock-out for tests/test_gpu_kernels.py's adversarial case
-      if (key_index(kl) != kPadIdx && key_value(kl) >= cut && lane == 0) a.flags[q] = a.epoch;
+      // (write-through, agent scope: with the fused finish the reader is the query's LAST workgroup, possibly on
+      // another XCD, inside this launch -- a plain store could still sit in this XCD's L2 when it looks)
+      if (key_index(kl) != kPadIdx && key_value(kl) >= cut && lane == 0)
+        __hip_atomic_store(a.flags + q, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
     }
     constexpr int RR = refine_rows(M);
