@@ -528,9 +528,10 @@ class MaxSimHip:
 class CoarseAssignHip:
     """Labels of MaxSimHip (fp32), bit for bit, for ONE problem with many centroids -- the coarse
     assign of IVFPQIndex.add / VQCodec.encode (kernels/MaxSimCuda.py:296-340 as called from
-    clustering/KMeans.py:440-452): A [d, m], B [d, n] -> labels [m] int64.  Error-bounded top-2
-    selection on the bf16 matrix cores + exact re-check of the ambiguous points on the device
-    (tpq_coarse_assign)."""
+    clustering/KMeans.py:440-452): A [d, m], B [d, n] -> labels [m] int64, d <= 1024.  Error-bounded
+    top-2 selection on the matrix cores; the points it leaves undecided get the exact kernel's own
+    value -- over all centroids, or (from 4 096 centroids on, and for d > 128) for each of their
+    candidates, the 2-3 centroids within twice the bound of the best (tpq_coarse_assign)."""
 
     def __init__(self, distance="euclidean", **_):
         assert distance in ("euclidean", "inner", "cosine")
@@ -567,7 +568,8 @@ class CoarseAssignHip:
         return (vals, inds) if return_vals else inds
 
     def last_rechecked(self):
-        """diagnostics (synchronises): points of the last call that went to the exact re-check"""
+        """diagnostics (synchronises): points of the last call that took an exact step (the exact kernel, or
+        exact values of their candidates)"""
         if self._last is None:
             return 0
         ws, off = self._last
