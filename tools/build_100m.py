@@ -6,7 +6,7 @@ to cell c sits at cell_start[c] + i, input order -- CellContainer.py:313-367, ge
 get_write_address_v2.cu:9-41) on sampled cells, and the stored codes against encode() on sampled
 chunks.
 
-    python tools/build_100m.py [--n 100000000] [--chunk 1048576] [--out profiles/r02_build_100m.json]
+    python tools/build_100m.py [--n 100000000] [--chunk 1048576] [--out profiles/r03_build_100m.json]
 """
 import argparse
 import json
