@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--mode", default="selection", choices=["selection", "cascade"])
     ap.add_argument("--trace", action="store_true", help="print every case before it runs and synchronise after it")
     ap.add_argument("--only-case", type=int, default=-1, help="cascade mode: run this case alone (same random stream)")
+    ap.add_argument("--big", action="store_true", help="cascade mode: up to 200 000 points x 20 000 centroids")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     dev = "cuda:0"
@@ -95,7 +96,8 @@ def cascade_soak(a, rng, dev):
         kind = KINDS[c % len(KINDS)]
         dist = "euclidean" if rng.random() < 0.7 else "inner"
         # narrow: d <= 128; euclidean problems take the cascade (chunked from 257 centroids on: candidate route)
-        d, m, n = int(rng.integers(1, 129)), int(rng.integers(1, 30000)), int(rng.integers(1, 6000))
+        mmax, nmax = (200000, 20000) if a.big else (30000, 6000)
+        d, m, n = int(rng.integers(1, 129)), int(rng.integers(1, mmax)), int(rng.integers(1, nmax))
         A, B = make(rng, kind, d, m, n, dev)
         run = a.only_case < 0 or a.only_case == c
         if a.trace and run:
@@ -111,7 +113,8 @@ def cascade_soak(a, rng, dev):
             if not torch.equal(got, want):
                 bad.append(("narrow", kind, d, m, n, dist, int((got != want).sum())))
         # wide: 128 < d <= 1024, both metrics
-        d, m, n = int(rng.integers(129, 1025)), int(rng.integers(1, 12000)), int(rng.integers(1, 3000))
+        d, m, n = int(rng.integers(129, 1025)), int(rng.integers(1, 60000 if a.big else 12000)), \
+            int(rng.integers(1, 8000 if a.big else 3000))
         A, B = make(rng, kind, d, m, n, dev)
         if a.trace and run:
             print("case", c, "wide", kind, d, m, n, dist, flush=True)
