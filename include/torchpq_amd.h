@@ -8,7 +8,8 @@
  * Conventions (same contract as the reference wrappers):
  *   - all pointers are DEVICE pointers owned by the caller (torch's caching
  *     allocator in the Python host); the library never allocates, frees or
- *     keeps device memory between calls, and holds no global state;
+ *     keeps device memory between calls, holds no state between calls and
+ *     reads no environment variable (every entry point is re-entrant);
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*;
  *     NULL = the null stream) and never synchronises;
  *   - tensors are dense, row-major, in the reference's layouts;
@@ -25,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TPQ_VERSION 300 /* 0.3.0 */
+#define TPQ_VERSION 400 /* 0.4.0 */
 
 #define TPQ_OK 0
 #define TPQ_ERR_INVALID_ARGUMENT (-1)
@@ -84,12 +85,18 @@ int tpq_ivfpq_scan_topk(const uint8_t* codes, const float* lut, const uint8_t* i
  * tpq_ivfpq_scan_topk_packed has the contract of tpq_ivfpq_scan_topk (bit-identical
  * results) but streams `packed`; `codes` is still needed for the exact re-evaluation of
  * the few candidates that pass the threshold filter.
- * Launches: ONE for plain PQ with k <= 248 -- the scan workgroups merge their lists, a query split over
+ * Launches: ONE for plain PQ with k <= 248 when the query is not split (n_split == 1) or the caller
+ * passes tickets (the *_tickets entry points) -- the scan workgroups merge their lists, a query split over
  * n_split workgroups is written by the last of them to finish (a ticket per query), and a candidate
  * band that overflowed is redone exactly by that workgroup -- otherwise three (scan, merge, the
- * exact redo of flagged queries).  The tickets live in a zeroed 4-MiB device buffer the LIBRARY
- * allocates per device on first use (hipMalloc; never during stream capture, where a call
- * without a ring falls back to the three launches); the workspace stays caller-owned scratch. */
+ * exact redo of flagged queries).
+ * tickets  i32 [nq] (tpq_ivfpq_scan_tickets_bytes(nq) bytes), owned by the CALLER like every other
+ *          buffer: all zero before the first call that uses them; every call leaves them all zero
+ *          again, so one zeroing serves any number of calls.  Calls that share a ticket buffer must
+ *          be ordered (same stream, or otherwise serialised): one buffer per stream in flight.  After
+ *          a failed launch or a device fault zero the buffer again.  A graph captured with a ticket
+ *          buffer replays with it: it must outlive the graph.  tickets == NULL (and the entry points
+ *          without the argument): split queries take the three launches. */
 int tpq_ivfpq_pack_codes(const uint8_t* codes, uint8_t* packed, int64_t n_slots, int m,
                          int64_t slot_begin, int64_t slot_end, tpq_stream_t stream);
 
@@ -100,6 +107,14 @@ int tpq_ivfpq_scan_topk_packed(const uint8_t* packed, const uint8_t* codes, cons
                                int64_t* out_ids, int64_t n_slots, int nq, int max_nprobe, int m,
                                int k, int n_split, void* workspace, size_t workspace_bytes,
                                tpq_stream_t stream);
+size_t tpq_ivfpq_scan_tickets_bytes(int nq);
+int tpq_ivfpq_scan_topk_packed_tickets(const uint8_t* packed, const uint8_t* codes, const float* lut,
+                                       const uint8_t* is_empty, const int64_t* cell_start,
+                                       const int64_t* cell_size, const int64_t* n_probe_list,
+                                       float* out_vals, int64_t* out_addr, const int64_t* address2id,
+                                       int64_t* out_ids, int64_t n_slots, int nq, int max_nprobe,
+                                       int m, int k, int n_split, void* workspace,
+                                       size_t workspace_bytes, int32_t* tickets, tpq_stream_t stream);
 
 /* Fused a-3 + a-1: the scan workgroup builds its query's LUT itself from the query and the PQ
  * codebook (bit-identical entries to tpq_adc_lut: same fma chains), so the [m][nq][256] table is
@@ -114,6 +129,13 @@ int tpq_ivfpq_search_fused(const uint8_t* packed, const uint8_t* codes, const fl
                            const int64_t* address2id, int64_t* out_ids, int64_t n_slots, int nq,
                            int max_nprobe, int m, int k, int n_split, void* workspace,
                            size_t workspace_bytes, tpq_stream_t stream);
+int tpq_ivfpq_search_fused_tickets(const uint8_t* packed, const uint8_t* codes, const float* query,
+                                   const float* codebook, int ds, int metric, const uint8_t* is_empty,
+                                   const int64_t* cell_start, const int64_t* cell_size,
+                                   const int64_t* n_probe_list, float* out_vals, int64_t* out_addr,
+                                   const int64_t* address2id, int64_t* out_ids, int64_t n_slots,
+                                   int nq, int max_nprobe, int m, int k, int n_split, void* workspace,
+                                   size_t workspace_bytes, int32_t* tickets, tpq_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * SURVEY 8(f)-3  residual-PQ list scan (pq_use_residual=True)
@@ -274,7 +296,14 @@ int tpq_max_sim_split(const float* A, const float* B, float* vals, int64_t* inds
  * exact kernel.  Problems below 2^33 multiply-adds go to tpq_max_sim directly (same labels).
  * Shapes: d <= 128: m < 2^31, padded slice 16 ceil(d/16) m floats < 2 GiB; 128 < d <= 1024: m < 2^28,
  * n <= 2^22 (workspace ~1.4 x the points); otherwise TPQ_ERR_UNSUPPORTED (use tpq_max_sim).
- * workspace: tpq_coarse_assign_workspace_bytes(d, m, n). */
+ * workspace: tpq_coarse_assign_workspace_bytes(d, m, n).
+ * tpq_coarse_assign_route: the same call with the choice between the paths made by the caller instead of
+ * the size thresholds above -- TPQ_ASSIGN_ROUTE_AUTO (what tpq_coarse_assign does) or
+ * TPQ_ASSIGN_ROUTE_CASCADE (the fp16 cascade for every shape it supports, however small: the parity tests
+ * drive it over ragged and degenerate shapes this way).  Labels are the same on every route.
+ * workspace: tpq_coarse_assign_route_workspace_bytes(d, m, n, route). */
+#define TPQ_ASSIGN_ROUTE_AUTO 0
+#define TPQ_ASSIGN_ROUTE_CASCADE 1
 int tpq_coarse_assign_supported(int d, int64_t m, int n);
 size_t tpq_coarse_assign_workspace_bytes(int d, int64_t m, int n);
 /* diagnostics: byte offset inside the workspace of the int32 count of points the last call
@@ -282,6 +311,9 @@ size_t tpq_coarse_assign_workspace_bytes(int d, int64_t m, int n);
 size_t tpq_coarse_assign_count_offset(int d, int64_t m, int n);
 int tpq_coarse_assign(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n,
                       int metric, void* workspace, size_t workspace_bytes, tpq_stream_t stream);
+size_t tpq_coarse_assign_route_workspace_bytes(int d, int64_t m, int n, int route);
+int tpq_coarse_assign_route(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n,
+                            int metric, int route, void* workspace, size_t workspace_bytes, tpq_stream_t stream);
 
 /* a-8 (training path, batched)  the labels of tpq_max_sim, bit for bit, for l codebook-sized problems
  * replaces the max_sim call of the Lloyd loop, torchpq/clustering/MultiKMeans.py:415-453

@@ -11,13 +11,49 @@ from conftest import ROOT
 def test_library_loads_and_exports_header_symbols():
     from torchpq_amd import _lib
     lib = _lib.load()
-    assert lib.tpq_version() == 300
+    assert lib.tpq_version() == 400
     header = open(os.path.join(ROOT, "include", "torchpq_amd.h")).read()
     declared = set(re.findall(r"\b(tpq_[a-z0-9_]+)\s*\(", header))
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
+
+
+def test_library_reads_no_environment_switch_and_owns_no_device_memory():
+    """SURVEY 8(b) "Ownership" / "Threading": the product library carries none of the TPQ_* A/B switches
+    (they exist only in tools/build_variant.sh builds, -DTPQ_AB_SWITCHES) and imports no device allocator:
+    every buffer, the tickets of the one-launch scan finish included, comes from the caller."""
+    import subprocess
+    from torchpq_amd import _lib
+    text = subprocess.run(["strings", "-a", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = sorted(set(re.findall(r"\bTPQ_[A-Z0-9_]+\b", text)))
+    assert names == [], names
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True,
+                         check=True).stdout
+    imported = set(re.findall(r"\bU (\w+)", und))
+    assert not {"hipMalloc", "hipFree", "hipMallocAsync", "hipFreeAsync", "hipHostMalloc"} & imported, imported
+    # no source file of the library calls getenv outside the TPQ_AB_ENV macro (rocPRIM's radix sort, used by
+    # tpq_get_ioa, consults ROCPRIM_USE_ATOMIC_BLOCK_ID on its own: third-party, documented in the header)
+    src_dir = os.path.join(ROOT, "torchpq_amd", "csrc")
+    for f in os.listdir(src_dir):
+        if f.endswith((".hip", ".h", ".cpp")):
+            for line in open(os.path.join(src_dir, f)):
+                if "getenv" in line:
+                    assert f == "common.h" and "TPQ_AB_ENV" in line, (f, line)
+
+
+def test_ticket_and_route_entry_points_validate():
+    from torchpq_amd import _lib
+    lib = _lib.load()
+    assert lib.tpq_ivfpq_scan_tickets_bytes(0) == 0 and lib.tpq_ivfpq_scan_tickets_bytes(1000) == 4000
+    assert lib.tpq_coarse_assign_route_workspace_bytes(128, 1000, 300, 7) == 0   # unknown route
+    # the cascade route adds the cascade's layout for a shape the thresholds would send elsewhere
+    auto = lib.tpq_coarse_assign_route_workspace_bytes(128, 100000, 300, _lib.ASSIGN_ROUTE_AUTO)
+    casc = lib.tpq_coarse_assign_route_workspace_bytes(128, 100000, 300, _lib.ASSIGN_ROUTE_CASCADE)
+    assert auto == lib.tpq_coarse_assign_workspace_bytes(128, 100000, 300) and casc > auto > 0
+    rc = lib.tpq_coarse_assign_route(None, None, None, None, 128, 10, 10, 0, 0, None, 0, None)
+    assert rc == -1 and "null pointer" in _lib.last_error()
 
 
 def test_argument_validation_without_a_gpu():

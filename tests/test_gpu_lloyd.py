@@ -203,7 +203,7 @@ def test_coarse_assign_cascade_labels_are_the_fp32_arg_max(kind, d, m, n, monkey
     """the fp16 cascade behind tpq_coarse_assign (forced on for every shape: by default it takes over
     from 4 096 centroids on): labels == tpq_max_sim == the C oracle, chunked (n > 256) or not"""
     import torchpq_amd.kernels as K
-    monkeypatch.setenv("TPQ_COARSE_ASSIGN_CASCADE_MIN_N", "1")
+    monkeypatch.setattr(K.CoarseAssignHip, "default_route", "cascade")  # (small problems take other paths by default)
     rng = np.random.default_rng(hash((kind, d, m, n)) % 2 ** 31)
     x, cent = _data(kind, 1, d, m, min(n, m), rng)
     if n > m:  # more centroids than points: pad with perturbed copies
@@ -224,7 +224,7 @@ def test_coarse_assign_cascade_ties_and_flags(monkeypatch):
     """duplicated centroids across chunk boundaries (ties must go to the smaller index), a NaN point and
     an out-of-range centroid (the problem is flagged: everything re-checked exactly)"""
     import torchpq_amd.kernels as K
-    monkeypatch.setenv("TPQ_COARSE_ASSIGN_CASCADE_MIN_N", "1")
+    monkeypatch.setattr(K.CoarseAssignHip, "default_route", "cascade")  # (small problems take other paths by default)
     rng = np.random.default_rng(5)
     d, m, n = 48, 3000, 1024
     x = rng.integers(-9, 9, (d, m)).astype(np.float32)

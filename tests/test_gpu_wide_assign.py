@@ -23,7 +23,7 @@ SHAPES = [(129, 1000, 300), (960, 3000, 700), (200, 5000, 2053), (1024, 777, 257
 @pytest.mark.parametrize("shape", SHAPES)
 def test_wide_assign_labels_are_the_fp32_arg_max(kind, shape, monkeypatch):
     import torchpq_amd.kernels as K
-    monkeypatch.setenv("TPQ_COARSE_ASSIGN_WIDE_MIN_WORK", "1")  # (small problems go to the fp32 kernel by default)
+    monkeypatch.setattr(K.CoarseAssignHip, "default_route", "cascade")  # (small problems take other paths by default)
     d, m, n = shape
     rng = np.random.default_rng(hash((kind,) + shape) % 2 ** 31)
     x, cent = _data(kind, 1, d, m, min(n, m), rng)
@@ -48,7 +48,7 @@ def test_wide_assign_labels_are_the_fp32_arg_max(kind, shape, monkeypatch):
 @pytest.mark.parametrize("shape", [(130, 1500, 300), (960, 2000, 513)])
 def test_wide_assign_inner_product(shape, monkeypatch):
     import torchpq_amd.kernels as K
-    monkeypatch.setenv("TPQ_COARSE_ASSIGN_WIDE_MIN_WORK", "1")
+    monkeypatch.setattr(K.CoarseAssignHip, "default_route", "cascade")  # (small problems take other paths by default)
     d, m, n = shape
     rng = np.random.default_rng(11)
     x = (rng.standard_normal((d, m)) + 0.3).astype(np.float32)
@@ -66,7 +66,7 @@ def test_wide_assign_ties_overflow_and_flags(monkeypatch):
     centroid a candidate of every point: the exact kernel takes over), a NaN point and an out-of-range
     centroid (flagged: everything exact)"""
     import torchpq_amd.kernels as K
-    monkeypatch.setenv("TPQ_COARSE_ASSIGN_WIDE_MIN_WORK", "1")
+    monkeypatch.setattr(K.CoarseAssignHip, "default_route", "cascade")  # (small problems take other paths by default)
     rng = np.random.default_rng(5)
     d, m, n = 160, 3000, 1024
     x = rng.integers(-9, 9, (d, m)).astype(np.float32)
@@ -129,8 +129,7 @@ def test_centroids_beyond_the_fp16_range_of_the_data_scale_go_exact(shape, monke
     go to the exact kernel, on the candidate routes of the narrow (chunked) and the wide path alike
     (found by tools/selection_soak.py --mode cascade: the candidate pass emitted nothing and no fallback ran)"""
     import torchpq_amd.kernels as K
-    monkeypatch.setenv("TPQ_COARSE_ASSIGN_WIDE_MIN_WORK", "1")
-    monkeypatch.setenv("TPQ_COARSE_ASSIGN_CASCADE_MIN_N", "1")
+    monkeypatch.setattr(K.CoarseAssignHip, "default_route", "cascade")  # (small problems take other paths by default)
     d, m, n = shape
     rng = np.random.default_rng(d + m)
     x = (1000.0 + rng.standard_normal((d, m))).astype(np.float32)

@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""The reference's own published benchmark grid, run on this library.
+
+The only numbers TorchPQ publishes for the IVFPQ path are 64 records measured on one Tesla T4
+(benchmark/turing/sift1m/json/ivf[8, 16, 32, 64]_pq[4096, 16384]_sift1m.json:1): SIFT1M, 100 k training vectors,
+1 M base vectors, 10 000 queries, n_subvectors m in {8, 16, 32, 64} x n_cells in {4096, 16384} x
+n_probe in {1, 2, ..., 128}, each at k in {1, 10, 100} (mean of 30 runs).  This tool builds the same 8 indexes
+through train() / add() on SIFT-shaped data (the real files when --data-dir holds them, synthetic otherwise:
+there is no network), runs search() end to end at every one of the 192 points and writes, per point: q/s, the
+scan kernel's time (HIP events on the launch stream), its algorithmic bytes (sum of probed cell sizes x m),
+the achieved rate and its fraction of the 8 TB/s spec peak, recall, and the T4 record beside it
+(tools/data/t4_sift1m_grid.json, transcribed from the reference by tools/data/make_t4_grid.py).
+
+    python tools/reference_grid.py [--out profiles/r04_reference_grid.json] [--m 8,16,32,64]
+                                   [--n-cells 4096,16384] [--iters 10] [--no-check]
+
+`use_smart_probing=False` (deterministic scanned bytes).  Checker (never the thing measured): at every
+(m, n_cells) a sample of queries is searched again by the CPU oracle (oracle/, the restatement of the reference's
+algorithm) at n_probe 16 and k = 1, 10, 100; values, addresses and ids must be bit-equal.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402  (SiftLike, load_texmex, exact_nn: the bench's own data)
+
+N_PROBES = (1, 2, 4, 8, 16, 32, 64, 128)
+KS = (1, 10, 100)
+
+
+def t4_table():
+    recs = json.load(open(os.path.join(ROOT, "tools", "data", "t4_sift1m_grid.json")))["records"]
+    return {(r["m"], r["n_cells"], r["n_probe"]): r for r in recs}
+
+
+def timed_ms(fn, iters, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        out = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters, out
+
+
+def oracle_check(idx, queries, n_sample, n_probe=16):
+    """search() of a query sample == the CPU oracle (bit for bit) at k = 1, 10, 100"""
+    from oracle import c_oracle
+    from oracle import ivfpq_oracle as orc
+    x = queries[:, :n_sample].contiguous()
+    idx.n_probe = n_probe
+    xn = x.cpu().numpy()
+    _, cells, npl = idx.probe(x)
+    cells, npl = cells.cpu().numpy(), npl.cpu().numpy()
+    lut = c_oracle.adc_lut(xn, idx.pq_codec.codebook.cpu().numpy())
+    cs = idx._cell_start.cpu().numpy()[cells]
+    sz = idx._cell_size.cpu().numpy()[cells]
+    storage = idx._storage.cpu().numpy()
+    is_empty = idx._is_empty.cpu().numpy()
+    a2i = idx._address2id.cpu().numpy()
+    # the probe itself against the oracle's coarse step (fp32-MFMA arithmetic, same (value desc, cell asc) order)
+    ocells = orc.topk_desc(c_oracle.coarse_sims(xn, idx.vq_codec.codebook.cpu().numpy()), n_probe)[1]
+    ok = bool(np.array_equal(ocells, cells))
+    for k in KS:
+        vals, ids = idx.search(x, k=k)
+        ev, ea = c_oracle.scan_topk(storage, lut, is_empty, cs, sz, npl, k)
+        ei = orc.get_id_by_address(a2i, ea)
+        ok = ok and bool(np.array_equal(vals.cpu().numpy(), ev)) and bool(np.array_equal(ids.cpu().numpy(), ei))
+    return ok
+
+
+def run_index(m, n_cells, base, train, queries, nn, args, t4):
+    from torchpq_amd.index import IVFPQIndex
+    dev = base.device
+    np.random.seed(1234)
+    n_base = base.shape[1]
+    idx = IVFPQIndex(d_vector=base.shape[0], n_subvectors=m, n_cells=n_cells,
+                     initial_size=max(64, 2 * n_base // n_cells), device=str(dev))
+    torch.cuda.synchronize()
+    t0 = time.time()
+    idx.train(train)
+    torch.cuda.synchronize()
+    t_train = time.time() - t0
+    t0 = time.time()
+    for b in range(0, n_base, 1 << 18):
+        idx.add(base[:, b:b + (1 << 18)].contiguous())
+    torch.cuda.synchronize()
+    t_add = time.time() - t0
+    idx.release_spare()
+    idx.use_smart_probing = False
+    sizes = idx._cell_size
+    info = {"m": m, "n_cells": n_cells, "train_s": round(t_train, 3), "add_s": round(t_add, 3),
+            "cell_size_mean": round(float(sizes.float().mean().item()), 1),
+            "cell_size_median": int(sizes.median().item()), "cell_size_max": int(sizes.max().item()),
+            "cells_below_64_slots": int((sizes < 64).sum().item())}
+    if not args.no_check:
+        info["oracle_check"] = {"queries": args.check_queries, "n_probe": 16, "k": list(KS),
+                                "bit_equal": oracle_check(idx, queries, args.check_queries)}
+    scan = idx._ivfpq_topk._scan
+    points = []
+    nq = queries.shape[1]
+    for n_probe in N_PROBES:
+        idx.n_probe = n_probe
+        t_probe, (_, cells, npl) = timed_ms(lambda: idx.probe(queries), args.iters)
+        live = torch.arange(cells.shape[1], device=dev)[None, :] < npl[:, None]
+        algo = int((idx._cell_size[cells] * live).sum().item()) * m
+        for k in KS:
+            scan.record_events = None
+            for _ in range(2):
+                idx.search(queries, k=k)
+            torch.cuda.synchronize()
+            scan.record_events = []
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                vals, ids = idx.search(queries, k=k)
+            e1.record()
+            torch.cuda.synchronize()
+            total_ms = e0.elapsed_time(e1) / args.iters
+            ev = scan.record_events
+            scan.record_events = None
+            scan_ms = float(np.sum([a.elapsed_time(b) for a, b in ev])) / args.iters
+            gbps = algo / scan_ms / 1e6
+            ref = t4[(m, n_cells, n_probe)]
+            p = {"m": m, "n_cells": n_cells, "n_probe": n_probe, "k": k,
+                 "qps": round(nq / total_ms * 1e3, 1), "total_ms": round(total_ms, 4),
+                 "probe_ms": round(t_probe, 4), "scan_ms": round(scan_ms, 4),
+                 "scan_bytes": algo, "scan_GBps": round(gbps, 1), "frac": round(gbps / 8000.0, 4),
+                 "n_split": scan.last_n_split,
+                 "recall_1nn_in_topk": round(float((ids[:nn.shape[0]] == nn[:, None]).any(dim=1).float().mean().item()), 4),
+                 "t4_qps": ref["qps"][str(k)], "t4_recall": ref["recall"][str(k)],
+                 "x_t4": round(nq / total_ms * 1e3 / ref["qps"][str(k)], 2)}
+            points.append(p)
+    del idx
+    torch.cuda.empty_cache()
+    return info, points
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "reference_grid.json"))
+    ap.add_argument("--m", default="8,16,32,64")
+    ap.add_argument("--n-cells", default="4096,16384")
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--nq", type=int, default=10000)
+    ap.add_argument("--n-base", type=int, default=1_000_000)
+    ap.add_argument("--n-train", type=int, default=100_000)
+    ap.add_argument("--check-queries", type=int, default=64)
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--data-dir", default=os.environ.get("TPQ_DATA_DIR"))
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    t4 = t4_table()
+    real = bench.load_texmex(args.data_dir, "sift", dev, args.n_base, args.nq)
+    if real is not None:
+        base, train, queries, nn = real
+        data = f"SIFT1M from {args.data_dir}"
+        if train is None:
+            train = base[:, :args.n_train].contiguous()
+    else:
+        synth = bench.SiftLike(128, dev)
+        base = synth.sample(args.n_base, seed=1)
+        g = torch.Generator(device=dev)
+        g.manual_seed(2)
+        train = base[:, torch.randperm(args.n_base, generator=g, device=dev)[:args.n_train]].contiguous()
+        queries = synth.sample(args.nq, seed=4321)
+        nn = None
+        data = "synthetic (SIFT1M-shaped: non-negative integer-valued clustered fp32, low intrinsic dimension)"
+    if nn is None:
+        nn = bench.exact_nn(queries[:, :1000], base)
+    indexes, points = [], []
+    t_start = time.time()
+    for n_cells in [int(v) for v in args.n_cells.split(",")]:
+        for m in [int(v) for v in args.m.split(",")]:
+            info, pts = run_index(m, n_cells, base, train, queries, nn, args, t4)
+            indexes.append(info)
+            points.extend(pts)
+            print(f"[grid] m={m} n_cells={n_cells} done ({time.time() - t_start:.0f} s)", file=sys.stderr, flush=True)
+    worst = min(points, key=lambda p: p["x_t4"])
+    hot = [p for p in points if p["m"] in (32, 64) and p["n_probe"] >= 16]
+    out = {
+        "what": "the reference's published SIFT1M grid (T4) run through search() end to end on one MI355X",
+        "reference_numbers": "tools/data/t4_sift1m_grid.json <- /root/reference/benchmark/turing/sift1m/json/"
+                             "ivf[8, 16, 32, 64]_pq[4096, 16384]_sift1m.json:1",
+        "data": data, "n_query": int(queries.shape[1]), "iters": args.iters, "use_smart_probing": False,
+        "source_fingerprint": bench.source_fingerprint(),
+        "device": torch.cuda.get_device_name(0),
+        "summary": {
+            "points": len(points),
+            "min_x_t4": worst["x_t4"], "min_x_t4_point": {k: worst[k] for k in ("m", "n_cells", "n_probe", "k")},
+            "points_below_10x_t4": sum(1 for p in points if p["x_t4"] < 10.0),
+            "m32_m64_nprobe_ge16_points": len(hot),
+            "m32_m64_nprobe_ge16_below_0.60": sum(1 for p in hot if p["frac"] < 0.60),
+            "all_oracle_checks_bit_equal": all(i.get("oracle_check", {}).get("bit_equal", True) for i in indexes),
+        },
+        "indexes": indexes, "points": points,
+    }
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(out, open(args.out, "w"), indent=1)
+    print(json.dumps(out["summary"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -6,7 +6,7 @@ tight clusters, large common offset, tiny and huge magnitudes, duplicated centro
     python tools/selection_soak.py [--cases 60] [--seed 0]           tpq_coarse_assign (d <= 128) + tpq_max_sim_select
     python tools/selection_soak.py --mode cascade --cases 200        the fp16 cascades, forced on every shape:
         tpq_coarse_assign narrow (candidate route from 2 chunks on) and wide (128 < d <= 1024), tpq_lloyd_step
-(the cascade mode sets TPQ_COARSE_ASSIGN_CASCADE_MIN_N=1 / TPQ_COARSE_ASSIGN_WIDE_MIN_WORK=1 itself)"""
+(the cascade mode asks for the cascade on every shape: CoarseAssignHip.default_route = "cascade")"""
 import argparse
 import json
 import os
@@ -15,11 +15,11 @@ import sys
 import numpy as np
 import torch
 
-if "--mode" in sys.argv and sys.argv[sys.argv.index("--mode") + 1] == "cascade":
-    os.environ.setdefault("TPQ_COARSE_ASSIGN_CASCADE_MIN_N", "1")   # (read once by the library)
-    os.environ.setdefault("TPQ_COARSE_ASSIGN_WIDE_MIN_WORK", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from torchpq_amd import kernels as K  # noqa: E402
+
+if "--mode" in sys.argv and sys.argv[sys.argv.index("--mode") + 1] == "cascade":
+    K.CoarseAssignHip.default_route = "cascade"
 
 KINDS = ("gauss", "sift", "heavy", "tight", "offset", "tiny", "huge", "dups")
 

@@ -18,6 +18,8 @@ LIB_PATH = os.environ.get("TPQ_AMD_LIB") or os.path.join(_HERE, "libtorchpq_amd.
 METRIC_NEG_SQ_L2 = 0
 METRIC_INNER = 1
 ERR_UNSUPPORTED = -4  # TPQ_ERR_UNSUPPORTED
+ASSIGN_ROUTE_AUTO = 0     # TPQ_ASSIGN_ROUTE_AUTO
+ASSIGN_ROUTE_CASCADE = 1  # TPQ_ASSIGN_ROUTE_CASCADE
 
 _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 
@@ -33,6 +35,11 @@ SIGNATURES = {
                                         _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "tpq_ivfpq_search_fused": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _i64, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "tpq_ivfpq_scan_tickets_bytes": (_sz, [_i]),
+    "tpq_ivfpq_scan_topk_packed_tickets": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
+                                                _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "tpq_ivfpq_search_fused_tickets": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                            _i64, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "tpq_ivfpq_scan_topk_residual": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "tpq_residual_part1": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -65,6 +72,8 @@ SIGNATURES = {
     "tpq_coarse_assign_workspace_bytes": (_sz, [_i, _i64, _i]),
     "tpq_coarse_assign_count_offset": (_sz, [_i, _i64, _i]),
     "tpq_coarse_assign": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _sz, _vp]),
+    "tpq_coarse_assign_route_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
+    "tpq_coarse_assign_route": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _sz, _vp]),
     "tpq_compute_centroids_workspace_bytes": (_sz, [_i, _i, _i]),
     "tpq_compute_centroids": (_i, [_vp, _vp, _vp, _i, _i, _i64, _i, _vp, _sz, _vp]),
     "tpq_get_ioa_workspace_bytes": (_sz, [_i64]),

@@ -38,7 +38,7 @@
 
 namespace tpq {
 // the three-level fp16 cascade of lloyd.hip for one problem with many centroids (euclidean, d <= 128)
-int lloyd_assign_supported(int d, int64_t m, int n);
+int lloyd_assign_supported(int d, int64_t m, int n, int route);
 size_t lloyd_assign_workspace_bytes(int d, int64_t m, int n);
 size_t lloyd_assign_count_offset(int d, int64_t m, int n);
 int lloyd_wide_supported(int d, int64_t m, int n);
@@ -895,11 +895,11 @@ extern "C" int tpq_coarse_assign_supported(int d, int64_t m, int n) {
 }
 
 // d > 128: the cascade's dozen launches and the preparation of the points cost ~0.2 ms + a pass over the
-// data; below this many multiply-adds the fp32 kernel is done sooner (same labels either way)
-static bool wide_cascade_pays(int d, int64_t m, int n) {
-  const char* e = getenv("TPQ_COARSE_ASSIGN_WIDE_MIN_WORK");  // (tests: force the cascade on small shapes)
-  const double min_work = e ? atof(e) : 8589934592.0;
-  return (double)m * (double)n * (double)d >= min_work;
+// data; below this many multiply-adds the fp32 kernel is done sooner (same labels either way).
+// (route == TPQ_ASSIGN_ROUTE_CASCADE: the caller asks for the cascade whatever the size -- tests, tuning)
+static bool wide_cascade_pays(int d, int64_t m, int n, int route) {
+  if (route == TPQ_ASSIGN_ROUTE_CASCADE) return true;
+  return (double)m * (double)n * (double)d >= 8589934592.0;
 }
 
 // workspace = [the two-piece bf16 selection's layout][the cascade's layout]: either path may run (the
@@ -908,13 +908,19 @@ static size_t af_old_total(int d, int64_t m, int n) {
   if (d > 128) return 256;  // wide vectors: the diagnostics word alone
   return (afast::layout(af_ks(d), TPQ_AF_NP, m, n, d).total + 255) / 256 * 256;
 }
-extern "C" size_t tpq_coarse_assign_workspace_bytes(int d, int64_t m, int n) {
-  if (!tpq_coarse_assign_supported(d, m, n)) return 0;
+static bool route_ok(int route) { return route == TPQ_ASSIGN_ROUTE_AUTO || route == TPQ_ASSIGN_ROUTE_CASCADE; }
+
+extern "C" size_t tpq_coarse_assign_route_workspace_bytes(int d, int64_t m, int n, int route) {
+  if (!tpq_coarse_assign_supported(d, m, n) || !route_ok(route)) return 0;
   if (d > 128) {  // [diagnostics word][the cascade's layout, or -- small problems -- the fp32 kernel's maxima]
     const size_t cascade = m > 0 ? lloyd_assign_workspace_bytes(d, m, n) : 0, plain = ((size_t)m * 4 + 255) / 256 * 256;
     return 256 + (cascade > plain ? cascade : plain);
   }
-  return af_old_total(d, m, n) + (m > 0 && lloyd_assign_supported(d, m, n) ? lloyd_assign_workspace_bytes(d, m, n) : 0);
+  return af_old_total(d, m, n) +
+         (m > 0 && lloyd_assign_supported(d, m, n, route) ? lloyd_assign_workspace_bytes(d, m, n) : 0);
+}
+extern "C" size_t tpq_coarse_assign_workspace_bytes(int d, int64_t m, int n) {
+  return tpq_coarse_assign_route_workspace_bytes(d, m, n, TPQ_ASSIGN_ROUTE_AUTO);
 }
 
 // diagnostics: byte offset, inside the workspace, of the int32 number of points the last call sent
@@ -924,10 +930,12 @@ extern "C" size_t tpq_coarse_assign_count_offset(int d, int64_t m, int n) {
   return afast::layout(af_ks(d), TPQ_AF_NP, m, n).count_off;
 }
 
-extern "C" int tpq_coarse_assign(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n,
-                                 int metric, void* workspace, size_t workspace_bytes, tpq_stream_t stream) {
+extern "C" int tpq_coarse_assign_route(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m,
+                                       int n, int metric, int route, void* workspace, size_t workspace_bytes,
+                                       tpq_stream_t stream) {
   TPQ_REQUIRE(A && B && inds, "coarse_assign: null pointer");
   TPQ_REQUIRE(metric == TPQ_METRIC_NEG_SQ_L2 || metric == TPQ_METRIC_INNER, "coarse_assign: bad metric %d", metric);
+  TPQ_REQUIRE(route_ok(route), "coarse_assign: bad route %d", route);
   if (!tpq_coarse_assign_supported(d, m, n)) {
     set_error("coarse_assign: shape d=%d m=%lld n=%d not supported (d <= 1024; d <= 128: padded slice < 2 GiB; "
               "d > 128: m < 2^28, n <= 2^22); use tpq_max_sim",
@@ -935,16 +943,16 @@ extern "C" int tpq_coarse_assign(const float* A, const float* B, float* vals, in
     return TPQ_ERR_UNSUPPORTED;
   }
   if (m == 0) return TPQ_OK;
-  const size_t need = tpq_coarse_assign_workspace_bytes(d, m, n);
+  const size_t need = tpq_coarse_assign_route_workspace_bytes(d, m, n, route);
   TPQ_REQUIRE(workspace && workspace_bytes >= need, "coarse_assign: workspace of %zu bytes needed", need);
   const int euclid = metric == TPQ_METRIC_NEG_SQ_L2 ? 1 : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   char* ws = reinterpret_cast<char*>(workspace);
-  if (d > 128 && !wide_cascade_pays(d, m, n)) {  // a small problem: the fp32 kernel itself
+  if (d > 128 && !wide_cascade_pays(d, m, n, route)) {  // a small problem: the fp32 kernel itself
     check_hip(hipMemsetAsync(ws, 0, 4, st), "coarse_assign memset");
     return tpq_max_sim(A, B, vals ? vals : reinterpret_cast<float*>(ws + 256), inds, 1, d, (int)m, n, metric, stream);
   }
-  if (d > 128 || (euclid && lloyd_assign_supported(d, m, n))) {  // the fp16 cascade (lloyd.hip)
+  if (d > 128 || (euclid && lloyd_assign_supported(d, m, n, route))) {  // the fp16 cascade (lloyd.hip)
     char* cws = ws + af_old_total(d, m, n);
     int rc = lloyd_assign(A, B, vals, inds, d, m, n, euclid, cws, st);
     if (rc) return rc;
@@ -958,4 +966,10 @@ extern "C" int tpq_coarse_assign(const float* A, const float* B, float* vals, in
     case 4: return afast::run<4, TPQ_AF_NP, TPQ_AF_CT>(A, B, vals, inds, d, (int)m, n, euclid, ws, st);
     default: return afast::run<8, TPQ_AF_NP, TPQ_AF_CT>(A, B, vals, inds, d, (int)m, n, euclid, ws, st);
   }
+}
+
+extern "C" int tpq_coarse_assign(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n,
+                                 int metric, void* workspace, size_t workspace_bytes, tpq_stream_t stream) {
+  return tpq_coarse_assign_route(A, B, vals, inds, d, m, n, metric, TPQ_ASSIGN_ROUTE_AUTO, workspace, workspace_bytes,
+                                 stream);
 }

@@ -33,6 +33,15 @@ inline int check_hip(hipError_t e, const char* what) {
     if (_e != hipSuccess) return ::tpq::check_hip(_e, name);     \
   } while (0)
 
+// A/B switches read from the environment exist only in experiment builds (tools/build_variant.sh passes
+// -DTPQ_AB_SWITCHES); the product library reads no environment variable and carries none of their names.
+#ifdef TPQ_AB_SWITCHES
+#include <stdlib.h>
+#define TPQ_AB_ENV(name) getenv(name)
+#else
+#define TPQ_AB_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 constexpr int kWave = 64;  // CDNA wavefront

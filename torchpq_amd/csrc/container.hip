@@ -11,16 +11,6 @@ namespace tpq {
 // ioa[i] = #{ j < i : labels[j] == labels[i] }.  The reference (get_ioa.cu:9-47) gives every
 // unique label one thread that walks ALL n labels -- O(n * n_unique).  Here: stable radix sort
 // of (label, position) [rocPRIM], then rank inside each run of equal labels -- O(n).
-struct IoaWs {
-  int* keys_in;
-  int* keys_out;
-  int* pos_in;
-  int* pos_out;
-  int* run_start;
-  void* temp;
-  size_t temp_bytes;
-};
-
 __global__ __launch_bounds__(256) void ioa_prepare_kernel(const int64_t* __restrict__ labels,
                                                          int* __restrict__ keys,
                                                          int* __restrict__ pos, int64_t n) {
@@ -30,30 +20,42 @@ __global__ __launch_bounds__(256) void ioa_prepare_kernel(const int64_t* __restr
   pos[i] = (int)i;
 }
 
-__global__ __launch_bounds__(256) void ioa_heads_kernel(const int* __restrict__ keys,
-                                                       int* __restrict__ heads, int64_t n) {
-  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (r >= n) return;
-  heads[r] = (r == 0 || keys[r] != keys[r - 1]) ? (int)r : 0;
-}
-
-__global__ __launch_bounds__(256) void ioa_rank_kernel(const int* __restrict__ pos,
-                                                      const int* __restrict__ run_start,
+// rank of sorted position r inside its run of equal keys: r - (first position holding keys[r]), the first
+// position found by binary search in the sorted keys (one launch; the earlier heads + inclusive max-scan +
+// rank passes read and wrote the arrays three times, and rocPRIM's scan consults an environment variable)
+__global__ __launch_bounds__(256) void ioa_rank_kernel(const int* __restrict__ keys,
+                                                      const int* __restrict__ pos,
                                                       int64_t* __restrict__ ioa, int64_t n) {
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= n) return;
-  ioa[pos[r]] = (int64_t)((int)r - run_start[r]);
+  const int key = keys[r];
+  int64_t lo = 0, hi = r;  // first index in [0, r] with keys[index] == key (keys ascending)
+  if (r > 0 && keys[r - 1] == key) {
+    // gallop back first: runs are short against n, so the search stays inside a few cache lines
+    int64_t step = 1;
+    hi = r - 1;
+    while (hi - step >= 0 && keys[hi - step] == key) {
+      hi -= step;
+      step <<= 1;
+    }
+    lo = hi - step >= 0 ? hi - step + 1 : 0;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (keys[mid] == key) hi = mid; else lo = mid + 1;
+    }
+  } else {
+    lo = r;
+  }
+  ioa[pos[r]] = r - lo;
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static size_t ioa_temp_bytes(int64_t n) {
-  size_t sort_b = 0, scan_b = 0;
+  size_t sort_b = 0;
   (void)rocprim::radix_sort_pairs(nullptr, sort_b, (int*)nullptr, (int*)nullptr, (int*)nullptr,
                             (int*)nullptr, (size_t)n, 0, 32, (hipStream_t)0, false);
-  (void)rocprim::inclusive_scan(nullptr, scan_b, (int*)nullptr, (int*)nullptr, (size_t)n,
-                          rocprim::maximum<int>(), (hipStream_t)0, false);
-  return sort_b > scan_b ? sort_b : scan_b;
+  return sort_b;
 }
 
 // ---- get_write_address ---------------------------------------------------------------------
@@ -187,7 +189,7 @@ using namespace tpq;
 
 extern "C" size_t tpq_get_ioa_workspace_bytes(int64_t n) {
   if (n <= 0) return 0;
-  return 5 * align256((size_t)n * sizeof(int)) + align256(ioa_temp_bytes(n));
+  return 4 * align256((size_t)n * sizeof(int)) + align256(ioa_temp_bytes(n));
 }
 
 extern "C" int tpq_get_ioa(const int64_t* labels, int64_t* ioa, int64_t n, int64_t n_cells,
@@ -208,8 +210,7 @@ extern "C" int tpq_get_ioa(const int64_t* labels, int64_t* ioa, int64_t n, int64
   int* keys_out = reinterpret_cast<int*>(p + arr);
   int* pos_in = reinterpret_cast<int*>(p + 2 * arr);
   int* pos_out = reinterpret_cast<int*>(p + 3 * arr);
-  int* run_start = reinterpret_cast<int*>(p + 4 * arr);
-  void* temp = p + 5 * arr;
+  void* temp = p + 4 * arr;
   size_t temp_bytes = ioa_temp_bytes(n);
   const unsigned grid = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(ioa_prepare_kernel, dim3(grid), dim3(256), 0, st, labels, keys_in, pos_in, n);
@@ -220,14 +221,7 @@ extern "C" int tpq_get_ioa(const int64_t* labels, int64_t* ioa, int64_t n, int64
                                                (size_t)n, 0, bits, st, false),
                      "get_ioa radix_sort_pairs");
   if (rc) return rc;
-  hipLaunchKernelGGL(ioa_heads_kernel, dim3(grid), dim3(256), 0, st, keys_out, keys_in, n);
-  TPQ_LAUNCH_CHECK("ioa_heads_kernel");
-  temp_bytes = ioa_temp_bytes(n);
-  rc = check_hip(rocprim::inclusive_scan(temp, temp_bytes, keys_in, run_start, (size_t)n,
-                                         rocprim::maximum<int>(), st, false),
-                 "get_ioa inclusive_scan");
-  if (rc) return rc;
-  hipLaunchKernelGGL(ioa_rank_kernel, dim3(grid), dim3(256), 0, st, pos_out, run_start, ioa, n);
+  hipLaunchKernelGGL(ioa_rank_kernel, dim3(grid), dim3(256), 0, st, keys_out, pos_out, ioa, n);
   TPQ_LAUNCH_CHECK("ioa_rank_kernel");
   return TPQ_OK;
 }

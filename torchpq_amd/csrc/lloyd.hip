@@ -1393,7 +1393,7 @@ static int run_update(const UpdArgs& ua, const float* data, const float* mu, con
                       hipStream_t st) {
   constexpr int DT = (KS + 1) / 2;
   // one round of resident waves: every wave ends with its (256 / NH) x 32 global atomics
-  const char* e = getenv("TPQ_LL_NH");  // (A/B)
+  const char* e = TPQ_AB_ENV("TPQ_LL_NH");  // (variant builds, A/B)
   const int nh = e ? atoi(e) : 1;
   int64_t chunks = (nh == 1 ? 2048 : 3072) / ((int64_t)l * nh * DT);
   if (chunks < 1) chunks = 1;
@@ -1598,7 +1598,7 @@ static int run_assign(const float* A, const float* B, float* vals, int64_t* inds
     // chunked problems: the undecided points do not go through levels 2 and 3 -- their CANDIDATES (the centroids
     // within twice level 1's bound of the best: ~2 per point) get the exact kernel's value (the wide path's
     // machinery).  TPQ_COARSE_ASSIGN_CAND=0: levels 2 and 3 (A/B)
-    static const bool cand_route = !(getenv("TPQ_COARSE_ASSIGN_CAND") && atoi(getenv("TPQ_COARSE_ASSIGN_CAND")) == 0);
+    static const bool cand_route = !(TPQ_AB_ENV("TPQ_COARSE_ASSIGN_CAND") && atoi(TPQ_AB_ENV("TPQ_COARSE_ASSIGN_CAND")) == 0);
     if (chunked) {
       const bool cand = cand_route && n <= (1 << 22);  // (a pair entry carries the centroid in 22 bits)
       if (cand) {
@@ -2263,7 +2263,7 @@ static WideLayout wide_layout(int d, int64_t m, int n) {
   L.U = L.ncb * 8;
   L.T = (m + 255) / 256 * 8;  // whole blocks of 256 points
   L.ysplit = L.ncb >= 8 ? 8 : (L.ncb >= 4 ? 4 : (L.ncb >= 2 ? 2 : 1));  // (gemm_kernel's block mapping)
-  if (const char* e = getenv("TPQ_WIDE_YSPLIT")) L.ysplit = atoi(e);  // (A/B; 1, 2, 4, 8)
+  if (const char* e = TPQ_AB_ENV("TPQ_WIDE_YSPLIT")) L.ysplit = atoi(e);  // (A/B; 1, 2, 4, 8)
   L.cap2 = (int)(((m / 2 > 8192 ? m / 2 : 8192) + 255) / 256 * 256);     // pass 2's compact array, in points
   if (L.cap2 > L.T * 32) L.cap2 = (int)(L.T * 32);
   L.pair_cap = 4 * L.cap2 > 65536 ? 4 * L.cap2 : 65536;
@@ -2354,7 +2354,7 @@ static int run_wide(const float* A, const float* B, float* vals, int64_t* inds, 
                      L.KAp, euclid);
   TPQ_LAUNCH_CHECK("lloyd gprep_centroids_kernel");
   const size_t lds = (size_t)2 * kGStage + 8 * 1024 + sizeof(PairList);
-  static const int tile_ct = getenv("TPQ_WIDE_CT") ? atoi(getenv("TPQ_WIDE_CT")) : 2;  // (A/B of the wave tile)
+  static const int tile_ct = TPQ_AB_ENV("TPQ_WIDE_CT") ? atoi(TPQ_AB_ENV("TPQ_WIDE_CT")) : 2;  // (A/B of the wave tile)
   const auto k_top2 = tile_ct == 4 ? gemm_kernel<false, 4> : gemm_kernel<false, 2>;
   const auto k_cand = tile_ct == 4 ? gemm_kernel<true, 4> : gemm_kernel<true, 2>;
   const int gemm_threads = tile_ct == 4 ? 256 : 512;
@@ -2570,14 +2570,14 @@ static int run_cand_tail(const float* A, const float* B, float* vals, int64_t* i
 }  // namespace lloyd
 
 // hooks for tpq_coarse_assign (assign_fast.hip): the cascade takes euclidean problems with d <= 128
-int lloyd_assign_supported(int d, int64_t m, int n) {
+int lloyd_assign_supported(int d, int64_t m, int n, int route) {
   if (!(d >= 1 && d <= 128 && n >= 1 && n <= (1 << 24) && m >= 1 && m < (1LL << 31))) return 0;
-  if (getenv("TPQ_COARSE_ASSIGN_OLD")) return 0;  // (A/B: the two-piece bf16 selection of assign_fast.hip)
+  if (TPQ_AB_ENV("TPQ_COARSE_ASSIGN_OLD")) return 0;  // (A/B: the two-piece bf16 selection of assign_fast.hip)
   // below ~4 096 centroids the per-call preparation (max-abs + split of the points, the fold of the
   // chunks) costs more than the lighter sweep saves: 128 x 2 048: 1.66 vs 1.48 ms, 128 x 4 096: 2.37 vs 2.76,
   // 128 x 16 384: 8.5 vs 11.0, 64 x 16 384: 4.7 vs 6.0, 128 x 65 536: 39.9 vs 47.4 (1 M points)
-  const char* mn = getenv("TPQ_COARSE_ASSIGN_CASCADE_MIN_N");  // (tests: force the cascade on small shapes)
-  if (n < (mn ? atoi(mn) : 4096)) return 0;
+  // (route == TPQ_ASSIGN_ROUTE_CASCADE: the caller asks for the cascade whatever the size -- tests, tuning)
+  if (route != TPQ_ASSIGN_ROUTE_CASCADE && n < 4096) return 0;
   const lloyd::PrepLayout P = lloyd::prep_layout(1, d, m);
   return (P.T * ((P.KS + 1) / 2) * 2048 <= 0x7fffffffLL && (int64_t)d * m * 4 <= 0x7fffffffLL) ? 1 : 0;
 }
@@ -2593,7 +2593,7 @@ size_t lloyd_assign_count_offset(int d, int64_t m, int n) {  // wide: the points
   const lloyd::AssignLayout L = lloyd::assign_layout(d, m, n);
   // (chunked problems on the candidate route: the points that got an exact step on their candidates)
   const bool cand = L.chunks > 1 && n <= (1 << 22) &&
-                    !(getenv("TPQ_COARSE_ASSIGN_CAND") && atoi(getenv("TPQ_COARSE_ASSIGN_CAND")) == 0);
+                    !(TPQ_AB_ENV("TPQ_COARSE_ASSIGN_CAND") && atoi(TPQ_AB_ENV("TPQ_COARSE_ASSIGN_CAND")) == 0);
   return cand ? L.count1_off : L.count2_off;
 }
 int lloyd_assign(const float* A, const float* B, float* vals, int64_t* inds, int d, int64_t m, int n, int euclid,
@@ -2718,7 +2718,7 @@ extern "C" int tpq_lloyd_step(const float* data, const void* prepared, const flo
   rc = launch_max_sim_list(data, centroids, vals, inds, l, d, (int)m, n, 1, list2, count2, nullptr, nullptr, 0, st);
   if (rc) return rc;
   if (new_centroids) {
-    if (getenv("TPQ_LL_OLD_UPDATE"))  // (A/B: the fp32-data update of kmeans.hip)
+    if (TPQ_AB_ENV("TPQ_LL_OLD_UPDATE"))  // (A/B: the fp32-data update of kmeans.hip)
       return tpq_compute_centroids(data, inds, new_centroids, l, d, m, n, ws + L.upd_off,
                                    tpq_compute_centroids_workspace_bytes(l, d, n), stream);
     float* sums = reinterpret_cast<float*>(ws + L.upd_off);

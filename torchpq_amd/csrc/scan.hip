@@ -27,8 +27,7 @@
 //                        candidates exactly (ascending j) at the end of the query and dumps its
 //                        list; scan_merge_refine_kernel (one wave per query) merges the lists.
 //                        Results are bit-identical to scan_ref_kernel.
-#include <atomic>
-#include <mutex>
+#include <chrono>
 
 #include "scan_device.h"
 
@@ -95,59 +94,24 @@ extern "C" void tpq_debug_set_scan_profile(void* buf) { g_scan_prof = (unsigned 
 #endif
 // ---- tickets of the fused finish ---------------------------------------------------------------------
 // A query split over several workgroups is finished by the last one to arrive: one int32 ticket per query,
-// ZERO when the kernel starts and zero again when it ends (the finisher resets it).  The caller's workspace
-// arrives uninitialised and zeroing it would be a launch of its own, so the library owns a zeroed ring per
-// device (4 MiB, allocated and cleared on first use) and hands every call a fresh stretch of it: calls in
-// flight on different streams never share tickets unless a million queries are in flight at once.
-// During stream capture a stretch is taken from the top of the ring for good (the graph replays with it);
-// a ring that cannot be allocated now (first use inside a capture) means: no fused finish for this call.
+// ZERO when the kernel starts and zero again when it ends (the finisher resets it).  The tickets belong to the
+// CALLER (tpq_ivfpq_scan_tickets_bytes; zeroed once, then reusable by every later call that is ordered after
+// this one): the workspace arrives uninitialised and zeroing it would be a launch of its own, and a buffer
+// owned by the library would be state the boundary does not allow.  No tickets: a split query takes the
+// three-launch path (scan, merge, flagged redo).
 static bool fuse_enabled() {
   static const bool v = [] {
-    const char* e = getenv("TPQ_SCAN_FUSE");  // (A/B: TPQ_SCAN_FUSE=0 runs the three-launch path)
+    const char* e = TPQ_AB_ENV("TPQ_SCAN_FUSE");  // (variant builds, A/B: TPQ_SCAN_FUSE=0 runs the three-launch path)
     return !(e && atoi(e) == 0);
   }();
   return v;
 }
-static int* acquire_tickets(int nq, hipStream_t st) {
-  constexpr size_t kRing = 1u << 20;
-  struct Ring {
-    int* base = nullptr;
-    size_t next = 0, top = kRing;
-    bool failed = false;
-  };
-  static Ring rings[16];
-  static std::mutex mu;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cap) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  const bool capturing = cap != hipStreamCaptureStatusNone;
-  std::lock_guard<std::mutex> lock(mu);
-  Ring& r = rings[dev];
-  if (!r.base) {
-    if (r.failed || capturing) return nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&r.base), kRing * sizeof(int)) != hipSuccess ||
-        hipMemset(r.base, 0, kRing * sizeof(int)) != hipSuccess) {
-      (void)hipGetLastError();
-      r.base = nullptr;
-      r.failed = true;
-      return nullptr;
-    }
-  }
-  const size_t n = (size_t)nq;
-  if (capturing) {
-    if (r.top < n + kRing / 2) return nullptr;  // (half of the ring stays with the eager calls)
-    r.top -= n;
-    return r.base + r.top;
-  }
-  if (n > r.top) return nullptr;
-  if (r.next + n > r.top) r.next = 0;
-  int* p = r.base + r.next;
-  r.next += n;
-  return p;
+// the value that marks a raised flag in this call: non-zero, different from call to call (the flags live in
+// the caller's uninitialised workspace, which may be the memory an earlier call used) -- from the clock, so
+// that the library keeps no counter
+static int fresh_epoch() {
+  const uint64_t ns = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+  return (int)(((uint32_t)(ns ^ (ns >> 29)) * 0x9e3779b1u) | 1u);
 }
 
 static bool has_packed_kernel(int m) {
@@ -158,6 +122,29 @@ static bool has_packed_kernel(int m) {
 }
 static int run_residual_ref(ScanArgs a, ResidualArgs ra, hipStream_t st);
 
+extern "C" size_t tpq_ivfpq_scan_tickets_bytes(int nq) { return nq > 0 ? (size_t)nq * sizeof(int32_t) : 0; }
+
+extern "C" int tpq_ivfpq_search_fused_tickets(const uint8_t* packed, const uint8_t* codes,
+                                              const float* query, const float* codebook, int ds,
+                                              int metric, const uint8_t* is_empty,
+                                              const int64_t* cell_start, const int64_t* cell_size,
+                                              const int64_t* n_probe_list, float* out_vals,
+                                              int64_t* out_addr, const int64_t* address2id,
+                                              int64_t* out_ids, int64_t n_slots, int nq, int max_nprobe,
+                                              int m, int k, int n_split, void* workspace,
+                                              size_t workspace_bytes, int32_t* tickets,
+                                              tpq_stream_t stream) {
+  TPQ_REQUIRE(metric == TPQ_METRIC_NEG_SQ_L2 || metric == TPQ_METRIC_INNER,
+              "ivfpq_search_fused: bad metric %d", metric);
+  TPQ_REQUIRE(ds >= 1 && ds <= 1024, "ivfpq_search_fused: bad sub-vector length %d", ds);
+  ScanArgs a{codes, packed, nullptr, query, codebook, ds, metric == TPQ_METRIC_NEG_SQ_L2 ? 1 : 0,
+             is_empty, cell_start, cell_size, n_probe_list, out_vals, out_addr, address2id, out_ids,
+             nullptr, nullptr, nullptr, nullptr, nullptr, n_slots, nq, max_nprobe, m, k, n_split};
+  a.tickets = tickets;
+  if (packed && has_packed_kernel(m)) return run_packed(a, nullptr, workspace, workspace_bytes, stream);
+  return run_ref(a, workspace, workspace_bytes, stream);
+}
+
 extern "C" int tpq_ivfpq_search_fused(const uint8_t* packed, const uint8_t* codes,
                                       const float* query, const float* codebook, int ds,
                                       int metric, const uint8_t* is_empty,
@@ -167,14 +154,10 @@ extern "C" int tpq_ivfpq_search_fused(const uint8_t* packed, const uint8_t* code
                                       int64_t* out_ids, int64_t n_slots, int nq, int max_nprobe,
                                       int m, int k, int n_split, void* workspace,
                                       size_t workspace_bytes, tpq_stream_t stream) {
-  TPQ_REQUIRE(metric == TPQ_METRIC_NEG_SQ_L2 || metric == TPQ_METRIC_INNER,
-              "ivfpq_search_fused: bad metric %d", metric);
-  TPQ_REQUIRE(ds >= 1 && ds <= 1024, "ivfpq_search_fused: bad sub-vector length %d", ds);
-  ScanArgs a{codes, packed, nullptr, query, codebook, ds, metric == TPQ_METRIC_NEG_SQ_L2 ? 1 : 0,
-             is_empty, cell_start, cell_size, n_probe_list, out_vals, out_addr, address2id, out_ids,
-             nullptr, nullptr, nullptr, nullptr, nullptr, n_slots, nq, max_nprobe, m, k, n_split};
-  if (packed && has_packed_kernel(m)) return run_packed(a, nullptr, workspace, workspace_bytes, stream);
-  return run_ref(a, workspace, workspace_bytes, stream);
+  return tpq_ivfpq_search_fused_tickets(packed, codes, query, codebook, ds, metric, is_empty, cell_start,
+                                        cell_size, n_probe_list, out_vals, out_addr, address2id, out_ids,
+                                        n_slots, nq, max_nprobe, m, k, n_split, workspace, workspace_bytes,
+                                        nullptr, stream);
 }
 
 extern "C" int tpq_ivfpq_scan_topk(const uint8_t* codes, const float* lut, const uint8_t* is_empty,
@@ -203,6 +186,22 @@ static int run_ref(ScanArgs a, void* workspace, size_t workspace_bytes, tpq_stre
   return dispatch_ref(a, R, reinterpret_cast<hipStream_t>(stream));
 }
 
+extern "C" int tpq_ivfpq_scan_topk_packed_tickets(const uint8_t* packed, const uint8_t* codes,
+                                                  const float* lut, const uint8_t* is_empty,
+                                                  const int64_t* cell_start, const int64_t* cell_size,
+                                                  const int64_t* n_probe_list, float* out_vals,
+                                                  int64_t* out_addr, const int64_t* address2id,
+                                                  int64_t* out_ids, int64_t n_slots, int nq, int max_nprobe,
+                                                  int m, int k, int n_split, void* workspace,
+                                                  size_t workspace_bytes, int32_t* tickets,
+                                                  tpq_stream_t stream) {
+  ScanArgs a{codes, packed, lut, nullptr, nullptr, 0, 0, is_empty, cell_start, cell_size,
+             n_probe_list, out_vals, out_addr, address2id, out_ids, nullptr, nullptr, nullptr,
+             nullptr, nullptr, n_slots, nq, max_nprobe, m, k, n_split};
+  a.tickets = tickets;
+  return run_packed(a, nullptr, workspace, workspace_bytes, stream);
+}
+
 extern "C" int tpq_ivfpq_scan_topk_packed(const uint8_t* packed, const uint8_t* codes,
                                           const float* lut, const uint8_t* is_empty,
                                           const int64_t* cell_start, const int64_t* cell_size,
@@ -211,10 +210,9 @@ extern "C" int tpq_ivfpq_scan_topk_packed(const uint8_t* packed, const uint8_t* 
                                           int64_t* out_ids, int64_t n_slots, int nq, int max_nprobe,
                                           int m, int k, int n_split, void* workspace,
                                           size_t workspace_bytes, tpq_stream_t stream) {
-  ScanArgs a{codes, packed, lut, nullptr, nullptr, 0, 0, is_empty, cell_start, cell_size,
-             n_probe_list, out_vals, out_addr, address2id, out_ids, nullptr, nullptr, nullptr,
-             nullptr, nullptr, n_slots, nq, max_nprobe, m, k, n_split};
-  return run_packed(a, nullptr, workspace, workspace_bytes, stream);
+  return tpq_ivfpq_scan_topk_packed_tickets(packed, codes, lut, is_empty, cell_start, cell_size, n_probe_list,
+                                            out_vals, out_addr, address2id, out_ids, n_slots, nq, max_nprobe, m,
+                                            k, n_split, workspace, workspace_bytes, nullptr, stream);
 }
 
 static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_t workspace_bytes,
@@ -260,16 +258,13 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
   a.prof = g_scan_prof;
 #endif
   // flags: raised == equal to this call's epoch; no zeroing pass (it was a launch of its own)
-  static std::atomic<unsigned> g_epoch{0x5eed0001u};
-  a.epoch = (int)(g_epoch.fetch_add(0x9e3779b1u) | 1u);
+  a.epoch = fresh_epoch();
   // the scan workgroups finish the query themselves (merge, write, exact redo): one launch instead of three.
-  // (k <= 248, plain PQ; a query split over several workgroups needs a ticket from the library's ring)
-  a.tickets = nullptr;
+  // (k <= 248, plain PQ; a query split over several workgroups needs the caller's tickets)
   a.fuse = 0;
-  if (!ra && fuse_enabled() && fuse_fits(m, R) && packed_waves(m) * RL >= R) {
-    if (n_split > 1) a.tickets = acquire_tickets(nq, st);
+  if (!ra && fuse_enabled() && fuse_fits(m, R) && packed_waves(m) * RL >= R)
     a.fuse = (n_split == 1 || a.tickets) ? 1 : 0;
-  }
+  if (!a.fuse) a.tickets = nullptr;
   switch (m) {
 #define TPQ_CASE_M(M) case M: rc = dispatch_packed_##M(a, ra, RL, R, st); break;
     TPQ_PACKED_M_LIST(TPQ_CASE_M)

@@ -55,15 +55,24 @@ class GraphedSearch:
         self.k = k
         device = torch.device(index.device)
         self.x = torch.zeros(index.d_vector, n_query, device=device, dtype=torch.float32)
+        # the tickets of the one-launch finish of split queries (csrc/scan.hip) belong to this graph: zeroed
+        # once here, left zero by every replay, freed with the graph's owner
+        self._tickets = torch.zeros(max(n_query, 1), device=device, dtype=torch.int32)
+        scan = index._ivfpq_topk._scan
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side):
-            for _ in range(warmup):  # lazy state (scan-layout copy, part2 tables) is built here
-                index.search(self.x, k=k)
-        torch.cuda.current_stream(device).wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.values, self.ids = index.search(self.x, k=k)
+        prev = scan.ticket_buffer
+        scan.ticket_buffer = self._tickets
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(warmup):  # lazy state (scan-layout copy, part2 tables) is built here
+                    index.search(self.x, k=k)
+            torch.cuda.current_stream(device).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.values, self.ids = index.search(self.x, k=k)
+        finally:
+            scan.ticket_buffer = prev
         # taken AFTER the capture: lazily built state is in place; `_held` pins the tensors
         self._knobs, self._ident, self._held = self._snapshot(index)
 

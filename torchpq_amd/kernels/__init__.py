@@ -45,6 +45,49 @@ class IVFPQTopkHip:
         # timing events recorded on the launch stream around the scan kernel(s)
         self.record_events = None
         self.last_n_split = None
+        # tickets of the one-launch finish of split queries (tpq_ivfpq_*_tickets): caller-owned int32 [n_query],
+        # zero between calls.  One buffer per (device, stream) -- calls that share a buffer must be ordered;
+        # `ticket_buffer` overrides it (GraphedSearch hands in the buffer its graph owns).
+        self.ticket_buffer = None
+        self._ticket_cache = {}
+        self.keep_workspace = False   # diagnostics: keep the last call's workspace in `last_workspace`
+        self.last_workspace = None
+
+    def _tickets(self, n_query, n_split, device):
+        """zeroed int32 [>= n_query] for this (device, current stream), or None (unsplit queries need none;
+        inside a stream capture only a buffer handed in through `ticket_buffer` may be used: a fresh one
+        would be zeroed by a captured memset on every replay)"""
+        if n_split <= 1:
+            return None
+        if self.ticket_buffer is not None:
+            t = self.ticket_buffer
+            assert t.dtype == torch.int32 and t.numel() >= n_query and t.device == torch.device(device)
+            return t
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        dev = torch.device(device)
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        t = self._ticket_cache.get(key)
+        if t is None or t.numel() < n_query:
+            if len(self._ticket_cache) >= 64:
+                self._ticket_cache.clear()
+            t = torch.zeros(max(n_query, 1024), device=dev, dtype=torch.int32)
+            self._ticket_cache[key] = t
+        return t
+
+    def _drop_tickets(self, device):
+        """after a failed call the tickets may be left non-zero: never reuse them"""
+        dev = torch.device(device)
+        self._ticket_cache.pop((dev.index, torch.cuda.current_stream(dev).cuda_stream), None)
+
+    def last_redone(self, n_query):
+        """diagnostics (synchronises; needs keep_workspace): queries of the last one-launch scan that took the
+        in-kernel exact redo (ws_delta[q] == 1, csrc/scan_device.h)"""
+        ws = self.last_workspace
+        if ws is None:
+            return None
+        off = (n_query * 4 + 255) // 256 * 256
+        return int((ws[off:off + 4 * n_query].view(torch.float32) == 1.0).sum().item())
 
     def _n_split(self, n_query, device, slots_hint=None):
         """Workgroups per query so that small batches still fill the chip (256 CUs x 2).
@@ -114,12 +157,15 @@ class IVFPQTopkHip:
             ev[0].record(torch.cuda.current_stream(device))
         with torch.cuda.device(device):
             if packed is not None and self.m in PACKED_M:
-                rc = lib.tpq_ivfpq_scan_topk_packed(
+                tickets = self._tickets(n_query, n_split, device)
+                rc = lib.tpq_ivfpq_scan_topk_packed_tickets(
                     ptr(packed), ptr(data), ptr(precomputed), ptr(is_empty), ptr(cell_start),
                     ptr(cell_size), ptr(n_probe_list), ptr(values), ptr(address), ptr(address2id),
                     ptr(ids), n_data, n_query, n_probe, self.m, k, n_split, ptr(ws), ws_bytes,
-                    stream_ptr(device))
-                check(rc, "tpq_ivfpq_scan_topk_packed")
+                    ptr(tickets), stream_ptr(device))
+                if rc != 0:
+                    self._drop_tickets(device)
+                check(rc, "tpq_ivfpq_scan_topk_packed_tickets")
             else:
                 rc = lib.tpq_ivfpq_scan_topk(
                     ptr(data), ptr(precomputed), ptr(is_empty), ptr(cell_start), ptr(cell_size),
@@ -129,8 +175,9 @@ class IVFPQTopkHip:
         if ev is not None:
             ev[1].record(torch.cuda.current_stream(device))
             self.record_events.append(ev)
+        if self.keep_workspace:
+            self.last_workspace = ws
         return (values, address) if ids is None else (values, address, ids)
-
 
     def topk_fused(self, data, query, codebook, is_empty, cell_start, cell_size, n_probe_list,
                    n_candidates, distance="euclidean", packed=None, address2id=None, n_split=None,
@@ -172,11 +219,17 @@ class IVFPQTopkHip:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(torch.cuda.current_stream(device))
         with torch.cuda.device(device):
-            check(lib.tpq_ivfpq_search_fused(
+            tickets = self._tickets(n_query, n_split, device) if packed is not None else None
+            rc = lib.tpq_ivfpq_search_fused_tickets(
                 ptr(packed), ptr(data), ptr(query), ptr(codebook), ds, metric, ptr(is_empty),
                 ptr(cell_start), ptr(cell_size), ptr(n_probe_list), ptr(values), ptr(address),
                 ptr(address2id), ptr(ids), n_data, n_query, n_probe, self.m, k, n_split, ptr(ws),
-                ws_bytes, stream_ptr(device)), "tpq_ivfpq_search_fused")
+                ws_bytes, ptr(tickets), stream_ptr(device))
+            if rc != 0:
+                self._drop_tickets(device)
+            check(rc, "tpq_ivfpq_search_fused_tickets")
+        if self.keep_workspace:
+            self.last_workspace = ws
         if ev is not None:
             ev[1].record(torch.cuda.current_stream(device))
             self.record_events.append(ev)
@@ -533,9 +586,15 @@ class CoarseAssignHip:
     value -- over all centroids, or (from 4 096 centroids on, and for d > 128) for each of their
     candidates, the 2-3 centroids within twice the bound of the best (tpq_coarse_assign)."""
 
-    def __init__(self, distance="euclidean", **_):
+    # "auto": the library's size thresholds pick the path; "cascade": the fp16 cascade for every shape it
+    # supports (tpq_coarse_assign_route; the parity tests set this to drive the cascade over small shapes)
+    default_route = "auto"
+
+    def __init__(self, distance="euclidean", route=None, **_):
         assert distance in ("euclidean", "inner", "cosine")
+        assert route in (None, "auto", "cascade")
         self.distance = distance
+        self.route = route
         self._last = None
 
     @staticmethod
@@ -557,13 +616,16 @@ class CoarseAssignHip:
         if m == 0:  # (empty tensors have null data pointers)
             self._last = None
             return (torch.empty(0, device=A.device), inds) if return_vals else inds
-        ws_bytes = lib.tpq_coarse_assign_workspace_bytes(d, m, n)
+        route = (_lib.ASSIGN_ROUTE_CASCADE if (self.route or self.default_route) == "cascade"
+                 else _lib.ASSIGN_ROUTE_AUTO)
+        ws_bytes = lib.tpq_coarse_assign_route_workspace_bytes(d, m, n, route)
         ws = torch.empty(max(ws_bytes, 1), device=A.device, dtype=torch.uint8)
         metric = _lib.METRIC_NEG_SQ_L2 if self.distance == "euclidean" else _lib.METRIC_INNER
         vals = torch.empty(m, device=A.device, dtype=torch.float32) if return_vals else None
         with torch.cuda.device(A.device):
-            check(lib.tpq_coarse_assign(ptr(A), ptr(B), ptr(vals) if return_vals else None, ptr(inds), d, m, n,
-                                        metric, ptr(ws), ws_bytes, stream_ptr(A.device)), "tpq_coarse_assign")
+            check(lib.tpq_coarse_assign_route(ptr(A), ptr(B), ptr(vals) if return_vals else None, ptr(inds), d, m,
+                                              n, metric, route, ptr(ws), ws_bytes, stream_ptr(A.device)),
+                  "tpq_coarse_assign_route")
         self._last = (ws, lib.tpq_coarse_assign_count_offset(d, m, n))
         return (vals, inds) if return_vals else inds
 
