@@ -96,7 +96,10 @@ int tpq_ivfpq_scan_topk(const uint8_t* codes, const float* lut, const uint8_t* i
  *          be ordered (same stream, or otherwise serialised): one buffer per stream in flight.  After
  *          a failed launch or a device fault zero the buffer again.  A graph captured with a ticket
  *          buffer replays with it: it must outlive the graph.  tickets == NULL (and the entry points
- *          without the argument): split queries take the three launches. */
+ *          without the argument): split queries take the three launches.
+ * slots_hint  expected number of slots a query scans (n_probe x mean cell size; 0 = unknown).  Performance
+ *          only: long cells let the kernel keep shorter candidate lists per wave (results are the same
+ *          either way; a wrong hint costs an exact in-kernel redo of the queries it misleads). */
 int tpq_ivfpq_pack_codes(const uint8_t* codes, uint8_t* packed, int64_t n_slots, int m,
                          int64_t slot_begin, int64_t slot_end, tpq_stream_t stream);
 
@@ -114,7 +117,8 @@ int tpq_ivfpq_scan_topk_packed_tickets(const uint8_t* packed, const uint8_t* cod
                                        float* out_vals, int64_t* out_addr, const int64_t* address2id,
                                        int64_t* out_ids, int64_t n_slots, int nq, int max_nprobe,
                                        int m, int k, int n_split, void* workspace,
-                                       size_t workspace_bytes, int32_t* tickets, tpq_stream_t stream);
+                                       size_t workspace_bytes, int32_t* tickets, int64_t slots_hint,
+                                       tpq_stream_t stream);
 
 /* Fused a-3 + a-1: the scan workgroup builds its query's LUT itself from the query and the PQ
  * codebook (bit-identical entries to tpq_adc_lut: same fma chains), so the [m][nq][256] table is
@@ -135,7 +139,8 @@ int tpq_ivfpq_search_fused_tickets(const uint8_t* packed, const uint8_t* codes, 
                                    const int64_t* n_probe_list, float* out_vals, int64_t* out_addr,
                                    const int64_t* address2id, int64_t* out_ids, int64_t n_slots,
                                    int nq, int max_nprobe, int m, int k, int n_split, void* workspace,
-                                   size_t workspace_bytes, int32_t* tickets, tpq_stream_t stream);
+                                   size_t workspace_bytes, int32_t* tickets, int64_t slots_hint,
+                                   tpq_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * SURVEY 8(f)-3  residual-PQ list scan (pq_use_residual=True)

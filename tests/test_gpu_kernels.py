@@ -166,10 +166,15 @@ def test_scan_short_lists_overflow_is_redone_exactly(K, m, k, n_split):
     assert np.isin(ea[0], top).all()  # the construction holds: query 0's answer is inside the blocks
     scan = K.IVFPQTopkHip(m=m)
     st = T(storage)
+    scan.keep_workspace = True
+    # (slots_hint = one long cell: the kernel then keeps the SHORT lists this test is about; without a hint
+    # it sizes them for 4k entries and nothing overflows)
     v, a = scan.topk(st, T(lut), T(is_empty), T(cs), T(sz), T(npl), n_candidates=k,
-                     packed=K.PackCodesHip()(st), n_split=n_split)
+                     packed=K.PackCodesHip()(st), n_split=n_split, slots_hint=n)
     assert np.array_equal(N(v), ev)
     assert np.array_equal(N(a), ea)
+    if k <= 248:  # (one-launch finish: the diagnostics word says the redo ran)
+        assert scan.last_redone(nq) >= 1
 
 
 def test_scan_packed_falls_back_when_lds_is_short(K):

@@ -72,7 +72,7 @@ def test_split_queries_finish_on_caller_owned_tickets(K, m, k, n_split):
         a = torch.empty(nq, k, device=DEV, dtype=torch.int64)
         rc = lib.tpq_ivfpq_scan_topk_packed_tickets(
             _p(packed), _p(st), _p(lt), _p(emp), _p(tcs), _p(tsz), _p(tnpl), _p(v), _p(a), None, None,
-            storage.shape[1], nq, n_probe, m, k, n_split, _p(ws), ws_bytes, _p(tickets), stream)
+            storage.shape[1], nq, n_probe, m, k, n_split, _p(ws), ws_bytes, _p(tickets), 0, stream)
         assert rc == 0, _lib.last_error()
         return v, a
 
@@ -154,11 +154,12 @@ def test_graph_replay_consumes_its_overflow_flags(K):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            scan.topk(st, lut, *targs, n_candidates=k, packed=packed, n_split=n_split)
+            scan.topk(st, lut, *targs, n_candidates=k, packed=packed, n_split=n_split, slots_hint=n)
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            v, a = scan.topk(st, lut, *targs, n_candidates=k, packed=packed, n_split=n_split)
+            # (slots_hint: one long cell -> the short per-wave lists this test is about)
+            v, a = scan.topk(st, lut, *targs, n_candidates=k, packed=packed, n_split=n_split, slots_hint=n)
         redone = {}
         for name, src in (("bad", lut_bad), ("ok", lut_ok), ("bad", lut_bad), ("ok", lut_ok)):
             lut.copy_(T(src))

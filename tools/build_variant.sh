@@ -10,6 +10,7 @@ set -euo pipefail
 NAME="$1"; EXTRA="${2:-}"; shift 2
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 CS="${ROOT}/torchpq_amd/csrc"
+SRC_DIR="${SRC_DIR:-$CS}"   # (sources of the recompiled units; another directory = an older copy of the kernels for A/B)
 OUT="${ROOT}/torchpq_amd/variants"
 mkdir -p "$OUT/obj_${NAME}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
@@ -19,12 +20,12 @@ pids=()
 for unit in "$@"; do
   if [[ "$unit" == scan_packed_* ]]; then
     src="scan_packed.hip"; def="-DTPQ_PACKED_M=${unit#scan_packed_}"
-  elif [[ -f "${CS}/${unit}.hip" ]]; then
+  elif [[ -f "${SRC_DIR}/${unit}.hip" ]]; then
     src="${unit}.hip"; def=""
   else
     src="${unit}.cpp"; def=""
   fi
-  ( "$HIPCC" "${FLAGS[@]}" $EXTRA $def -x hip -c "${CS}/${src}" -o "$OUT/obj_${NAME}/${unit}.o" ) &
+  ( "$HIPCC" "${FLAGS[@]}" $EXTRA $def -x hip -c "${SRC_DIR}/${src}" -o "$OUT/obj_${NAME}/${unit}.o" ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p" || { echo "compile failed" >&2; exit 1; }; done

@@ -21,6 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--m", type=int, default=64)
     ap.add_argument("--r", type=int, default=1)
+    ap.add_argument("--rm", type=int, default=2, help="registers of the merged list (fused finish); 0 = three-launch kernel")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     with tempfile.TemporaryDirectory() as td:
@@ -31,7 +32,7 @@ def main():
             "--cuda-device-only", "-S", os.path.join(ROOT, "torchpq_amd", "csrc", "scan_packed.hip"),
             "-o", asm], stderr=subprocess.DEVNULL)
         text = open(asm).read()
-    name = f"_ZN3tpq18scan_packed_kernelILi{a.r}ELi{a.m}ELb0EEEvNS_8ScanArgsENS_12ResidualArgsEf"
+    name = f"_ZN3tpq18scan_packed_kernelILi{a.r}ELi{a.m}ELb0ELi{a.rm}EEEvNS_8ScanArgsENS_12ResidualArgsEf"
     start = text.index(f"\n{name}:")
     body = text[start:text.index("s_endpgm", start)].splitlines()
     # loops: header label -> [first line, last line carrying "Header=<label>"]
@@ -50,7 +51,7 @@ def main():
     tile = max(loops.items(), key=lambda kv: count(kv[1][0], kv[1][1], r"\bv_perm_b32\b"))
     lo, hi = tile[1]
     out = {
-        "kernel": f"scan_packed_kernel<{a.r},{a.m},false>",
+        "kernel": f"scan_packed_kernel<{a.r},{a.m},false,{a.rm}>",
         "isa_lines": len(body),
         "tile_loop": {"header": tile[0], "first_line": lo, "last_line": hi,
                       "v_perm_b32": count(lo, hi, r"\bv_perm_b32\b"),

@@ -108,6 +108,7 @@ def run_index(m, n_cells, base, train, queries, nn, args, t4):
         info["oracle_check"] = {"queries": args.check_queries, "n_probe": 16, "k": list(KS),
                                 "bit_equal": oracle_check(idx, queries, args.check_queries)}
     scan = idx._ivfpq_topk._scan
+    scan.keep_workspace = True   # diagnostics: queries that took the in-kernel exact redo (last_redone)
     points = []
     nq = queries.shape[1]
     for n_probe in N_PROBES:
@@ -137,7 +138,7 @@ def run_index(m, n_cells, base, train, queries, nn, args, t4):
                  "qps": round(nq / total_ms * 1e3, 1), "total_ms": round(total_ms, 4),
                  "probe_ms": round(t_probe, 4), "scan_ms": round(scan_ms, 4),
                  "scan_bytes": algo, "scan_GBps": round(gbps, 1), "frac": round(gbps / 8000.0, 4),
-                 "n_split": scan.last_n_split,
+                 "n_split": scan.last_n_split, "queries_redone_exactly": scan.last_redone(nq),
                  "recall_1nn_in_topk": round(float((ids[:nn.shape[0]] == nn[:, None]).any(dim=1).float().mean().item()), 4),
                  "t4_qps": ref["qps"][str(k)], "t4_recall": ref["recall"][str(k)],
                  "x_t4": round(nq / total_ms * 1e3 / ref["qps"][str(k)], 2)}

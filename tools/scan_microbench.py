@@ -60,13 +60,13 @@ def main():
         pk = packed if layout == "packed" else None
         for _ in range(2):
             r = scan.topk(storage, lut, None, cs, sz, npl, n_candidates=args.k, packed=pk,
-                          n_split=args.n_split)
+                          n_split=args.n_split, slots_hint=args.n_probe * args.cell)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.iters):
             r = scan.topk(storage, lut, None, cs, sz, npl, n_candidates=args.k, packed=pk,
-                          n_split=args.n_split)
+                          n_split=args.n_split, slots_hint=args.n_probe * args.cell)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.iters

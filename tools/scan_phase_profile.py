@@ -55,11 +55,11 @@ def main():
         cb = torch.randn(m, 2, 256, generator=g, device=dev) * 20
         q = torch.randn(2 * m, nq, generator=g, device=dev) * 20
         run = lambda: scan.topk_fused(storage, q, cb, None, cs, sz, npl, n_candidates=args.k, packed=packed,
-                                      n_split=args.n_split)
+                                      n_split=args.n_split, slots_hint=args.n_probe * args.cell)
     else:
         lut = torch.randn(m, nq, 256, generator=g, device=dev) * 50 - 300
         run = lambda: scan.topk(storage, lut, None, cs, sz, npl, n_candidates=args.k, packed=packed,
-                                n_split=args.n_split)
+                                n_split=args.n_split, slots_hint=args.n_probe * args.cell)
     for _ in range(2):
         run()
     prof = torch.zeros(nq * 64 * 16, device=dev, dtype=torch.int64)

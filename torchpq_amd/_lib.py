@@ -37,9 +37,9 @@ SIGNATURES = {
                                     _i64, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "tpq_ivfpq_scan_tickets_bytes": (_sz, [_i]),
     "tpq_ivfpq_scan_topk_packed_tickets": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
-                                                _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
+                                                _i, _i, _i, _i, _i, _vp, _sz, _vp, _i64, _vp]),
     "tpq_ivfpq_search_fused_tickets": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                            _i64, _i, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
+                                            _i64, _i, _i, _i, _i, _i, _vp, _sz, _vp, _i64, _vp]),
     "tpq_ivfpq_scan_topk_residual": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "tpq_residual_part1": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -133,7 +133,7 @@ extern "C" int tpq_ivfpq_search_fused_tickets(const uint8_t* packed, const uint8
                                               int64_t* out_ids, int64_t n_slots, int nq, int max_nprobe,
                                               int m, int k, int n_split, void* workspace,
                                               size_t workspace_bytes, int32_t* tickets,
-                                              tpq_stream_t stream) {
+                                              int64_t slots_hint, tpq_stream_t stream) {
   TPQ_REQUIRE(metric == TPQ_METRIC_NEG_SQ_L2 || metric == TPQ_METRIC_INNER,
               "ivfpq_search_fused: bad metric %d", metric);
   TPQ_REQUIRE(ds >= 1 && ds <= 1024, "ivfpq_search_fused: bad sub-vector length %d", ds);
@@ -141,6 +141,7 @@ extern "C" int tpq_ivfpq_search_fused_tickets(const uint8_t* packed, const uint8
              is_empty, cell_start, cell_size, n_probe_list, out_vals, out_addr, address2id, out_ids,
              nullptr, nullptr, nullptr, nullptr, nullptr, n_slots, nq, max_nprobe, m, k, n_split};
   a.tickets = tickets;
+  a.slots_hint = slots_hint;
   if (packed && has_packed_kernel(m)) return run_packed(a, nullptr, workspace, workspace_bytes, stream);
   return run_ref(a, workspace, workspace_bytes, stream);
 }
@@ -157,7 +158,7 @@ extern "C" int tpq_ivfpq_search_fused(const uint8_t* packed, const uint8_t* code
   return tpq_ivfpq_search_fused_tickets(packed, codes, query, codebook, ds, metric, is_empty, cell_start,
                                         cell_size, n_probe_list, out_vals, out_addr, address2id, out_ids,
                                         n_slots, nq, max_nprobe, m, k, n_split, workspace, workspace_bytes,
-                                        nullptr, stream);
+                                        nullptr, 0, stream);
 }
 
 extern "C" int tpq_ivfpq_scan_topk(const uint8_t* codes, const float* lut, const uint8_t* is_empty,
@@ -194,11 +195,12 @@ extern "C" int tpq_ivfpq_scan_topk_packed_tickets(const uint8_t* packed, const u
                                                   int64_t* out_ids, int64_t n_slots, int nq, int max_nprobe,
                                                   int m, int k, int n_split, void* workspace,
                                                   size_t workspace_bytes, int32_t* tickets,
-                                                  tpq_stream_t stream) {
+                                                  int64_t slots_hint, tpq_stream_t stream) {
   ScanArgs a{codes, packed, lut, nullptr, nullptr, 0, 0, is_empty, cell_start, cell_size,
              n_probe_list, out_vals, out_addr, address2id, out_ids, nullptr, nullptr, nullptr,
              nullptr, nullptr, n_slots, nq, max_nprobe, m, k, n_split};
   a.tickets = tickets;
+  a.slots_hint = slots_hint;
   return run_packed(a, nullptr, workspace, workspace_bytes, stream);
 }
 
@@ -212,7 +214,7 @@ extern "C" int tpq_ivfpq_scan_topk_packed(const uint8_t* packed, const uint8_t* 
                                           size_t workspace_bytes, tpq_stream_t stream) {
   return tpq_ivfpq_scan_topk_packed_tickets(packed, codes, lut, is_empty, cell_start, cell_size, n_probe_list,
                                             out_vals, out_addr, address2id, out_ids, n_slots, nq, max_nprobe, m,
-                                            k, n_split, workspace, workspace_bytes, nullptr, stream);
+                                            k, n_split, workspace, workspace_bytes, nullptr, 0, stream);
 }
 
 static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_t workspace_bytes,
@@ -249,7 +251,7 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
   }
   const int n_lists = n_split * packed_waves(m);
   // registers of the per-wave lists (<= R)
-  const int RL = list_regs_scan(k, packed_waves(m));
+  const int RL = list_regs_scan(k, m, a.max_nprobe, a.slots_hint);
   a.small_lists = RL < R ? 1 : 0;
   rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, RL, n_lists), "ivfpq_scan_packed");
   if (rc) return rc;

@@ -38,6 +38,7 @@ struct ScanArgs {
   int epoch;                 // value that marks a raised flag in this call (non-zero)
   int* tickets;              // fused finish, n_split > 1: the CALLER's [nq] int32, zero on entry, zero on exit
   int fuse;                  // fused finish (scan_packed_kernel RM > 0): the scan workgroups write the result
+  int64_t slots_hint;        // host only: expected slots scanned per query (0 = unknown), sizes the per-wave lists
 };
 
 #ifdef TPQ_SCAN_PROFILE
@@ -59,19 +60,29 @@ struct ProbeTable {  // lives in LDS
 
 // wave 0 fills the probe table; cells whose start equals the previous probe's start are
 // skipped (ivfpq_topk.cu:864-866)
+struct ProbeRegs {  // the first 64 probes' extents, one per lane (fetch_probes: the loads are issued early)
+  int st, sz;
+};
+__device__ __forceinline__ ProbeRegs fetch_probes(const ScanArgs& a, int q, int n_probe, int base) {
+  const int p = base + lane_id();
+  ProbeRegs r{0, 0};
+  if (p < n_probe) {
+    r.st = (int)a.cell_start[(int64_t)q * a.max_nprobe + p];
+    r.sz = (int)a.cell_size[(int64_t)q * a.max_nprobe + p];
+    if (p > 0 && a.cell_start[(int64_t)q * a.max_nprobe + p - 1] == (int64_t)r.st) r.sz = 0;
+    if (r.sz < 0) r.sz = 0;
+  }
+  return r;
+}
 __device__ __forceinline__ void build_probe_table(const ScanArgs& a, int q, int n_probe,
-                                                  ProbeTable t, int tile_shift = 6) {
+                                                  ProbeTable t, int tile_shift = 6,
+                                                  const ProbeRegs* first = nullptr) {
   const int lane = lane_id();
   int running = 0;
   for (int base = 0; base < n_probe; base += 64) {
     const int p = base + lane;
-    int st = 0, sz = 0;
-    if (p < n_probe) {
-      st = (int)a.cell_start[(int64_t)q * a.max_nprobe + p];
-      sz = (int)a.cell_size[(int64_t)q * a.max_nprobe + p];
-      if (p > 0 && a.cell_start[(int64_t)q * a.max_nprobe + p - 1] == (int64_t)st) sz = 0;
-      if (sz < 0) sz = 0;
-    }
+    const ProbeRegs r = (base == 0 && first) ? *first : fetch_probes(a, q, n_probe, base);
+    const int st = r.st, sz = r.sz;
     int tiles = (sz + (1 << tile_shift) - 1) >> tile_shift;
     int incl = tiles;  // inclusive wave scan
 #pragma unroll
@@ -87,46 +98,6 @@ __device__ __forceinline__ void build_probe_table(const ScanArgs& a, int q, int 
     running += readlane_i(incl, 63);
   }
   if (lane == 0) t.tile_begin[n_probe] = running;
-}
-
-// The packed kernel walks the CONCATENATION of the probed cells 64 slots at a time, as the reference does
-// (ivfpq_topk.cu:856-870: tpb slots of the concatenation per step), not cell by cell: a 64-slot group may span
-// several cells, so cells of 61 slots (IVF16384 over 1 M vectors) or 244 (IVF4096) leave no idle lanes and
-// pay no per-cell tile overhead.  Table: start[p]; sb[p] = slots of the concatenation before probe p
-// (sb[n_probe] = total); delta[p] = start[p] - sb[p], so that concatenation slot g of probe p is address g + delta[p].
-struct PackedProbeTable {  // lives in LDS
-  int* start;  // [max_nprobe]
-  int* delta;  // [max_nprobe]
-  int* sb;     // [max_nprobe + 1]
-};
-__device__ __forceinline__ void build_packed_probe_table(const ScanArgs& a, int q, int n_probe,
-                                                         PackedProbeTable t) {
-  const int lane = lane_id();
-  int running = 0;
-  for (int base = 0; base < n_probe; base += 64) {
-    const int p = base + lane;
-    int st = 0, sz = 0;
-    if (p < n_probe) {
-      st = (int)a.cell_start[(int64_t)q * a.max_nprobe + p];
-      sz = (int)a.cell_size[(int64_t)q * a.max_nprobe + p];
-      if (p > 0 && a.cell_start[(int64_t)q * a.max_nprobe + p - 1] == (int64_t)st) sz = 0;  // ivfpq_topk.cu:864-866
-      if (sz < 0) sz = 0;
-    }
-    int incl = sz;  // inclusive wave scan
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += o;
-    }
-    if (p < n_probe) {
-      const int before = running + incl - sz;
-      t.start[p] = st;
-      t.sb[p] = before;
-      t.delta[p] = st - before;
-    }
-    running += readlane_i(incl, 63);
-  }
-  if (lane == 0) t.sb[n_probe] = running;
 }
 
 // lists travel as keys: `lv` holds the high words (value images), `li` the low words (~index)
@@ -558,16 +529,13 @@ struct ResidualLut {
 // into sub-quantizer order through a private LDS row (stride M/4+1 dwords: conflict-free), then
 // sums LUT entries in the reference's order.
 template <int M, class LutFn>
-__device__ __forceinline__ float exact_from_packed(const uint8_t* __restrict__ packed,
-                                                   int64_t n_slots, int idx, bool active,
-                                                   uint32_t* scratch, int row_id,
+__device__ __forceinline__ float exact_from_chunks(const typename scan_layout::Layout<M>::chunk_t (&w)[scan_layout::Layout<M>::kChunks],
+                                                   int idx, bool active, uint32_t* scratch, int row_id,
                                                    const LutFn& lutfn, float init = 0.f) {
   using L = scan_layout::Layout<M>;
   constexpr int G = M / 4;
   uint32_t* row = scratch + row_id * (G + 1);
   if (active) {
-    typename L::chunk_t w[L::kChunks];
-    L::load(packed, n_slots, idx, w);
 #pragma unroll
     for (int d = 0; d < G; ++d) {
       const scan_layout::BlockAt<M> kb(4 * d);
@@ -592,6 +560,16 @@ __device__ __forceinline__ float exact_from_packed(const uint8_t* __restrict__ p
     }
   }
   return active ? v : -INFINITY;
+}
+template <int M, class LutFn>
+__device__ __forceinline__ float exact_from_packed(const uint8_t* __restrict__ packed,
+                                                   int64_t n_slots, int idx, bool active,
+                                                   uint32_t* scratch, int row_id,
+                                                   const LutFn& lutfn, float init = 0.f) {
+  using L = scan_layout::Layout<M>;
+  typename L::chunk_t w[L::kChunks] = {};
+  if (active) L::load(packed, n_slots, idx, w);
+  return exact_from_chunks<M>(w, idx, active, scratch, row_id, lutfn, init);
 }
 
 // phase 2, wave-level: the merged list already carries EXACT values; write the best k and raise
@@ -748,9 +726,9 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
   float* qv_all = reinterpret_cast<float*>(smem + lut_bytes + aux_bytes);
   int* qi_all = reinterpret_cast<int*>(smem + lut_bytes + aux_bytes + NW * 256);
   int* ptab = reinterpret_cast<int*>(smem + lut_bytes + aux_bytes + NW * 512);
-  PackedProbeTable tab{ptab, ptab + a.max_nprobe, ptab + 2 * a.max_nprobe};
+  ProbeTable tab{ptab, ptab + a.max_nprobe, ptab + 2 * a.max_nprobe};
   unsigned* tau_key = reinterpret_cast<unsigned*>(ptab + 3 * a.max_nprobe + 1);
-  int* tile_ctr = reinterpret_cast<int*>(tau_key + 1);  // m > 64: next group to hand out
+  int* tile_ctr = reinterpret_cast<int*>(tau_key + 1);  // m > 64: next tile to hand out
   float* red = reinterpret_cast<float*>(tile_ctr + 1);  // [2 NW] reduction scratch
   float* wave_q = red + 2 * NW;                // [NW] each wave's r-th best
   float* pbase = wave_q + NW;                  // RES: [max_nprobe] base_sims of the probe
@@ -767,8 +745,11 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
   unsigned* jmax = reinterpret_cast<unsigned*>(qv_all);  // [M] (the queues are not live yet)
   if (threadIdx.x < M) jmax[threadIdx.x] = 0u;
   __syncthreads();
+  // (wave 0 issues the loads of the probe table FIRST and builds the table after the LUT is staged: done up front,
+  // its two dependent global round trips kept the other waves at the staging barrier for 1.7 us per query)
+  ProbeRegs probes0{0, 0};
   if (wave == 0) {
-    build_packed_probe_table(a, q, n_probe, tab);
+    probes0 = fetch_probes(a, q, n_probe, 0);
     if (lane == 0) {
       *tau_key = f2key(-INFINITY);
       *tile_ctr = 0;
@@ -779,6 +760,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
   const float* part1 = RES ? ra.part1 : nullptr;
   if (!a.lut && !part1) stage_query(a, q, xq, NW * 64);
   stage_lut_blocked<M>(a, q, lut, NW * 64, jmax, xq, part1);
+  if (wave == 0) build_probe_table(a, q, n_probe, tab, packed_tile_shift(M), &probes0);
   float probe_mx = 0.f;
   if constexpr (RES) {
     for (int pp = threadIdx.x; pp < n_probe; pp += NW * 64) {
@@ -823,11 +805,9 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
   sel.init(qv_all + wave * 64, qi_all + wave * 64, a.k);
   sel.margin = delta2;
 
-  // 64-slot groups of the concatenation; this workgroup's share of them
-  const int total_slots = tab.sb[n_probe];
-  const int total_groups = (total_slots + 63) >> 6;
-  const int g_begin = (int)(((int64_t)total_groups * part) / a.n_split);
-  const int g_end = (int)(((int64_t)total_groups * (part + 1)) / a.n_split);
+  const int total_tiles = tab.tile_begin[n_probe];
+  const int t_begin = (int)(((int64_t)total_tiles * part) / a.n_split);
+  const int t_end = (int)(((int64_t)total_tiles * (part + 1)) / a.n_split);
 
   // Workgroup-shared admission threshold.  Two valid lower bounds of the final k-th best:
   //  (a) any wave's own k-th best (tau_key, atomic max);
@@ -852,128 +832,60 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
     }
   };
 
-  {
-    constexpr int S = packed_slots(M);  // 64-slot groups per wave per iteration
-    // Groups are dealt round-robin to the waves: group g_begin + (i S + u) NW + wave is sub-tile u of wave
-    // `wave`'s i-th iteration.  A cell's slots are thus spread over all waves 64 at a time, whatever the cell
-    // size -- the short per-wave lists (list_regs_scan) count on every wave holding ~1/NW of the top-k, and the
-    // nearest cell alone can hold half of it.
+  if constexpr (packed_slots(M) == 1) {
     struct Tile {
-      int s[S];       // the lane's slot address of sub-tile u
-      bool valid[S];
-      float add[S];   // RES: base_p + slot_term[s]
+      int s;
+      bool valid;
+      float add;  // RES: base_p + slot_term[s]
     };
-    // walk state, wave-uniform: `pw` = a probe at or before the next group's first slot; the slots of probe pw
-    // end at `next_b`, and concatenation slot g of probe pw sits at address g + cur_delta
-    int pw = 0;
-    int next_b = n_probe > 0 ? tab.sb[1] : 0;
-    int cur_delta = n_probe > 0 ? tab.delta[0] : 0;
-    auto window = [&](int pb) -> int {  // lane l: sb[pb + 1 + l], the ends of probes pb, pb + 1, ...
-      const int i = pb + 1 + lane;
-      return i < n_probe ? tab.sb[i] : 0x7fffffff;
-    };
-    auto locate_group = [&](int grp, int& s_out, bool& valid_out, float& add_out) {
-      const int g0 = grp << 6, g = g0 + lane;
-      int p = pw;      // per lane from here on
-      int d = cur_delta;
-      if (g0 + 63 >= next_b) {  // wave-uniform: the group is not inside probe pw
-        int pb = pw, c0, w;
-        for (;;) {  // whole windows of probes that end at or before g0
-          w = window(pb);
-          c0 = __popcll(__ballot(w <= g0));
-          if (c0 < 64) break;
-          pb += 64;
-        }
-        p = pb + c0;
-        int lo = c0;
-        for (;;) {  // the (few) probe ends inside the group: a lane past an end belongs to the next probe
-          const int c1 = __popcll(__ballot(w <= g0 + 63));
-          for (int j = lo; j < c1; ++j) p += (g >= __builtin_amdgcn_readlane(w, j)) ? 1 : 0;
-          if (c1 < 64) {
-            pw = pb + c1;
-            break;
-          }
-          pb += 64;
-          w = window(pb);
-          lo = 0;
-        }
-        pw = pw < n_probe - 1 ? pw : n_probe - 1;
-        p = p < n_probe - 1 ? p : n_probe - 1;
-        next_b = __builtin_amdgcn_readfirstlane(tab.sb[pw + 1]);
-        cur_delta = __builtin_amdgcn_readfirstlane(tab.delta[pw]);
-        d = tab.delta[p];
+    int p = 0;
+    auto locate = [&](int T) -> Tile {
+      while (T >= tab.tile_begin[p + 1]) ++p;
+      const int off = ((T - tab.tile_begin[p]) << 6) + lane;
+      Tile t{tab.start[p] + off, off < tab.size[p], 0.f};
+      if constexpr (RES) {
+        if (t.valid) t.add = pbase[p] + ra.slot_term[t.s];
       }
-      s_out = g + d;
-      valid_out = g < total_slots;
-      if constexpr (RES) add_out = valid_out ? pbase[p] + ra.slot_term[s_out] : 0.f;
+      return t;
     };
-    auto locate = [&](int grp0, Tile& t) {
-#pragma unroll
-      for (int u = 0; u < S; ++u) {
-        const int grp = grp0 + u * NW;
-        t.valid[u] = false;
-        t.s[u] = 0;
-        t.add[u] = 0.f;
-        if (grp < g_end) locate_group(grp, t.s[u], t.valid[u], t.add[u]);  // wave-uniform
-      }
-    };
-    auto load_tile = [&](const Tile& t, typename L::chunk_t (&w)[S][L::kChunks]) {
-#pragma unroll
-      for (int u = 0; u < S; ++u)
-        if (t.valid[u]) L::load(a.packed, a.n_slots, t.s[u], w[u]);
-    };
-    auto consume = [&](const typename L::chunk_t (&w)[S][L::kChunks], const Tile& t) {
-      float v[S];
-      bool live[S];
-#pragma unroll
-      for (int u = 0; u < S; ++u) {
-        v[u] = 0.f;
-        live[u] = t.valid[u];
-        if (t.valid[u]) {
-          if (a.is_empty) live[u] = (a.is_empty[t.s[u]] == 0);
-          v[u] = L::accumulate(w[u], t.s[u], lut);
-          if constexpr (RES) v[u] += t.add[u];
-        }
+    auto consume = [&](const typename L::chunk_t(&w)[L::kChunks], const Tile& t) {
+      float v = 0.f;
+      bool live = t.valid;
+      if (t.valid) {
+        if (a.is_empty) live = (a.is_empty[t.s] == 0);
+        v = L::accumulate(w, t.s, lut);
+        if constexpr (RES) v += t.add;
       }
       refresh_tau();
-      if constexpr (S > 1) {
-        bool any = false;
-#pragma unroll
-        for (int u = 0; u < S; ++u) any = any || (live[u] && (v[u] >= sel.tau - delta2));
-        if (__ballot(any) == 0ull) return;  // the common case: one ballot for S x 64 slots
-      }
-#pragma unroll
-      for (int u = 0; u < S; ++u) {
-        const float tau_before = sel.tau;
-        const int flushes_before = sel.n_flush;
-        sel.push(live[u] && (v[u] >= sel.tau - delta2), v[u], t.s[u]);
-        if (sel.n_flush != flushes_before) publish(tau_before);
-      }
+      const float tau_before = sel.tau;
+      const int flushes_before = sel.n_flush;
+      sel.push(live && (v >= sel.tau - delta2), v, t.s);
+      if (sel.n_flush != flushes_before) publish(tau_before);
     };
 
+    // software pipeline: the codes of tile T+NW are in flight while tile T is being consumed
+    // (m <= 64; larger m runs 16 waves per workgroup under a 128-VGPR cap and relies on them)
     if constexpr (M <= 64) {
-      // software pipeline: the codes of the wave's next iteration are in flight while this one is consumed
-      // (larger m runs 16 waves per workgroup under a 128-VGPR cap and relies on them)
-      typename L::chunk_t w0[S][L::kChunks], w1[S][L::kChunks];
-      Tile m0, m1;
-      int T = g_begin + wave;
-      if (T < g_end) {
-        locate(T, m0);
-        load_tile(m0, w0);
+      typename L::chunk_t w0[L::kChunks], w1[L::kChunks];
+      Tile m0{0, false, 0.f}, m1{0, false, 0.f};
+      int T = t_begin + wave;
+      if (T < t_end) {
+        m0 = locate(T);
+        if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
       }
-      while (T < g_end) {
-        int Tn = T + S * NW;
-        if (Tn < g_end) {
-          locate(Tn, m1);
-          load_tile(m1, w1);
+      while (T < t_end) {
+        int Tn = T + NW;
+        if (Tn < t_end) {
+          m1 = locate(Tn);
+          if (m1.valid) L::load(a.packed, a.n_slots, m1.s, w1);
         }
         consume(w0, m0);
         T = Tn;
-        if (T >= g_end) break;
-        Tn = T + S * NW;
-        if (Tn < g_end) {
-          locate(Tn, m0);
-          load_tile(m0, w0);
+        if (T >= t_end) break;
+        Tn = T + NW;
+        if (Tn < t_end) {
+          m0 = locate(Tn);
+          if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
         }
         consume(w1, m1);
         T = Tn;
@@ -982,26 +894,127 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
       // One 16-wave workgroup per CU and one tile in flight per wave: with a static deal the waves
       // drift apart (the oldest wave of a SIMD wins the issue arbitration), the early finishers
       // idle at the end-of-query barrier and the stragglers run alone, latency-bound -- 37-41 % of
-      // the workgroup's life at m = 120.  Groups are therefore handed out from an LDS counter (one
-      // integer atomic per iteration, fetched while the previous one is consumed); a wave's group
+      // the workgroup's life at m = 120.  Tiles are therefore handed out from an LDS counter (one
+      // integer atomic per tile, fetched while the previous tile is consumed); a wave's tile
       // indices still increase, which is all locate() needs.
-      static_assert(M <= 64 || S == 1, "the group counter hands out single groups");
       auto grab = [&]() -> int {
         int t = 0;
         if (lane == 0) t = atomicAdd(tile_ctr, 1);
-        return g_begin + __builtin_amdgcn_readfirstlane(t);
+        return t_begin + __builtin_amdgcn_readfirstlane(t);
       };
-      typename L::chunk_t w0[S][L::kChunks];
-      Tile m0;
+      typename L::chunk_t w0[L::kChunks];
       int T = grab();
-      while (T < g_end) {
-        m0.valid[0] = false;
-        m0.s[0] = 0;
-        m0.add[0] = 0.f;
-        locate_group(T, m0.s[0], m0.valid[0], m0.add[0]);
-        load_tile(m0, w0);
+      while (T < t_end) {
+        const Tile m0 = locate(T);
+        if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
         const int Tn = grab();
         consume(w0, m0);
+        T = Tn;
+      }
+    }
+  } else {
+    constexpr int S = packed_slots(M);          // slots per lane per tile, 64 apart
+    constexpr int TS = packed_tile_shift(M);    // log2(slots per tile)
+    struct Tile {
+      int s;      // the lane's first slot; its u-th slot is s + 64 u
+      int rem;    // slots of the cell from s on: the u-th slot exists iff 64 u < rem
+      float add;  // RES: base_p (slot_term is added per slot)
+    };
+    int p = 0;
+    auto locate = [&](int T) -> Tile {
+      while (T >= tab.tile_begin[p + 1]) ++p;
+      const int off = ((T - tab.tile_begin[p]) << TS) + lane;
+      Tile t{tab.start[p] + off, tab.size[p] - off, 0.f};
+      if constexpr (RES) t.add = pbase[p];
+      return t;
+    };
+    auto load_tile = [&](const Tile& t, typename L::chunk_t (&w)[S][L::kChunks], float (&term)[S]) {
+  #pragma unroll
+      for (int u = 0; u < S; ++u) {
+        if (64 * u < t.rem) {
+          L::load(a.packed, a.n_slots, t.s + 64 * u, w[u]);
+          if constexpr (RES) term[u] = ra.slot_term[t.s + 64 * u];
+        }
+      }
+    };
+    auto consume = [&](const typename L::chunk_t (&w)[S][L::kChunks], const float (&term)[S],
+                       const Tile& t) {
+      float v[S];
+      bool live[S];
+  #pragma unroll
+      for (int u = 0; u < S; ++u) {
+        v[u] = 0.f;
+        live[u] = 64 * u < t.rem;
+        if (live[u]) {
+          if (a.is_empty) live[u] = (a.is_empty[t.s + 64 * u] == 0);
+          v[u] = L::accumulate(w[u], t.s + 64 * u, lut);
+          if constexpr (RES) v[u] += t.add + term[u];
+        }
+      }
+      refresh_tau();
+      if constexpr (S > 1) {
+        bool any = false;
+  #pragma unroll
+        for (int u = 0; u < S; ++u) any = any || (live[u] && (v[u] >= sel.tau - delta2));
+        if (__ballot(any) == 0ull) return;  // the common case: one ballot for S x 64 slots
+      }
+  #pragma unroll
+      for (int u = 0; u < S; ++u) {
+        const float tau_before = sel.tau;
+        const int flushes_before = sel.n_flush;
+        sel.push(live[u] && (v[u] >= sel.tau - delta2), v[u], t.s + 64 * u);
+        if (sel.n_flush != flushes_before) publish(tau_before);
+      }
+    };
+
+    // software pipeline: the codes of tile T+NW are in flight while tile T is being consumed
+    // (m <= 64; larger m runs 16 waves per workgroup under a 128-VGPR cap and relies on them)
+    if constexpr (M <= 64) {
+      typename L::chunk_t w0[S][L::kChunks], w1[S][L::kChunks];
+      float r0[S] = {}, r1[S] = {};
+      Tile m0{0, 0, 0.f}, m1{0, 0, 0.f};
+      int T = t_begin + wave;
+      if (T < t_end) {
+        m0 = locate(T);
+        load_tile(m0, w0, r0);
+      }
+      while (T < t_end) {
+        int Tn = T + NW;
+        if (Tn < t_end) {
+          m1 = locate(Tn);
+          load_tile(m1, w1, r1);
+        }
+        consume(w0, r0, m0);
+        T = Tn;
+        if (T >= t_end) break;
+        Tn = T + NW;
+        if (Tn < t_end) {
+          m0 = locate(Tn);
+          load_tile(m0, w0, r0);
+        }
+        consume(w1, r1, m1);
+        T = Tn;
+      }
+    } else {
+      // One 16-wave workgroup per CU and one tile in flight per wave: with a static deal the waves
+      // drift apart (the oldest wave of a SIMD wins the issue arbitration), the early finishers
+      // idle at the end-of-query barrier and the stragglers run alone, latency-bound -- 37-41 % of
+      // the workgroup's life at m = 120.  Tiles are therefore handed out from an LDS counter (one
+      // integer atomic per tile, fetched while the previous tile is consumed); a wave's tile
+      // indices still increase, which is all locate() needs.
+      auto grab = [&]() -> int {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(tile_ctr, 1);
+        return t_begin + __builtin_amdgcn_readfirstlane(t);
+      };
+      typename L::chunk_t w0[S][L::kChunks];
+      float r0[S] = {};
+      int T = grab();
+      while (T < t_end) {
+        const Tile m0 = locate(T);
+        load_tile(m0, w0, r0);
+        const int Tn = grab();
+        consume(w0, r0, m0);
         T = Tn;
       }
     }
@@ -1099,14 +1112,14 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
       // of candidates that can still matter may have evicted one that matters too: flag the query
       // for the exact kernel.  (A list whose worst entry is below the cut lost nothing: everything
       // it evicted was worse still.)
-      // (A wave that admitted no more candidates than its list holds evicted nothing at all: a query of a few
-      // hundred slots -- n_probe 1 or 2 on the reference's benchmark grid -- fills lists whose cut is still
-      // -inf, and must not take the exact redo for it.)
+      // (A flush folds at most 64 candidates in, so a list of 64 R entries that has seen no more than R
+      // flushes evicted nothing at all: a query of a few hundred slots -- n_probe 1 or 2 on the reference's
+      // benchmark grid -- fills lists whose cut is still -inf, and must not take the exact redo for it.)
       const Key kl = readlane_key(sel.top.k[R - 1], 63);
 #ifndef TPQ_EXP_NO_OVERFLOW_FLAG  // knock-out for tests/test_gpu_kernels.py's adversarial case
       // (write-through, agent scope: with the fused finish the reader is the query's LAST workgroup, possibly on
       // another XCD, inside this launch -- a plain store could still sit in this XCD's L2 when it looks)
-      if (sel.n_admitted > 64 * R && key_index(kl) != kPadIdx && key_value(kl) >= cut && lane == 0)
+      if (sel.n_flush > R && key_index(kl) != kPadIdx && key_value(kl) >= cut && lane == 0)
         __hip_atomic_store(a.flags + q, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
     }
@@ -1129,7 +1142,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
         // reference with two different bases: leave such queries to the exact kernel)
         int myp = -1, n_match = 0;
         for (int pp = 0; pp < n_probe; ++pp) {
-          const bool hit = want && ((unsigned)(idx - tab.start[pp]) < (unsigned)(tab.sb[pp + 1] - tab.sb[pp]));
+          const bool hit = want && ((unsigned)(idx - tab.start[pp]) < (unsigned)tab.size[pp]);
           myp = (hit && myp < 0) ? pp : myp;
           n_match += hit ? 1 : 0;
         }
@@ -1138,17 +1151,20 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
         init = pbase[myp];
         p2 = ra.part2 + (int64_t)pcell[myp] * (M * 256);
       }
+      // every wanted lane fetches its candidate's packed bytes NOW, in one batch: loaded inside the passes
+      // below (16 rows each: the un-permute scratch is 16 rows per wave), each pass waited out a memory
+      // latency of its own -- 6.5 of the 45 us a 16-probe query of 244-slot cells lives at k = 100
+      typename L::chunk_t cw[L::kChunks] = {};
+      if (want) L::load(a.packed, a.n_slots, idx, cw);
 #pragma unroll 1
       for (int pass = 0; pass < 64 / RR; ++pass) {
         if (((wmask >> (RR * pass)) & ((1ull << RR) - 1ull)) == 0ull) continue;  // wave-uniform
         const bool mine = want && ((lane / RR) == pass);
         float ep;
         if constexpr (RES)
-          ep = exact_from_packed<M>(a.packed, a.n_slots, idx, mine, scratch, lane % RR,
-                                    ResidualLut<M>{lut, p2}, init);
+          ep = exact_from_chunks<M>(cw, idx, mine, scratch, lane % RR, ResidualLut<M>{lut, p2}, init);
         else
-          ep = exact_from_packed<M>(a.packed, a.n_slots, idx, mine, scratch, lane % RR,
-                                    LdsLut<M>{lut});
+          ep = exact_from_chunks<M>(cw, idx, mine, scratch, lane % RR, LdsLut<M>{lut});
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         e = mine ? ep : e;
       }
@@ -1275,7 +1291,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
       WaveSelector<RM> xs;
       xs.init(qv_all + wave * 64, qi_all + wave * 64, a.k);
       for (int pp = 0; pp < n_probe; ++pp) {
-        const int size = tab.sb[pp + 1] - tab.sb[pp], start = tab.start[pp];
+        const int size = tab.size[pp], start = tab.start[pp];
         for (int off0 = wave * 64; off0 < size; off0 += NW * 64) {
           const int off = off0 + lane;
           const bool valid = off < size;
@@ -1397,11 +1413,22 @@ static int list_regs_packed(int k) { return pow2_ceil((k + kBandSlack + 63) / 64
 #ifndef TPQ_SCAN_MIN_RL_K
 #define TPQ_SCAN_MIN_RL_K 1  // experiment knob: below this k the lists keep the full k + 8
 #endif
-static int list_regs_scan(int k, int nw) {
+// The 2k budget counts on a cell's tiles being dealt to ALL the waves of the workgroup: the nearest cell alone
+// can hold half of the top-k.  A cell much shorter than one round of tiles (waves x slots per tile: 512 slots at
+// m = 64, 1024 at m = 32) lands in few waves -- on the reference's own benchmark grid (IVF4096 over 1 M vectors:
+// 244 slots, ONE 256-slot tile at m <= 32) the 2k budget sent 1-2 % of the queries (93 % at n_probe = 1) through
+// the exact redo at k = 100 (profiles/r04_reference_grid.json, "queries_redone_exactly") -- and gets 4k; so does
+// a caller that gives no hint.  (Full-size lists everywhere would cost the long cells 10 % at k = 100, m <= 32.)
+static int list_regs_scan(int k, int m, int max_nprobe, int64_t slots_hint) {
+  const int nw = packed_waves(m);
   const int rp = list_regs_packed(k);
   if (k < TPQ_SCAN_MIN_RL_K) return rp;
+  const int64_t round_slots = (int64_t)nw * 64 * packed_slots(m);
+  // ("spread": the mean probed cell fills at least three quarters of a round of tiles)
+  const bool spread = slots_hint > 0 && 4 * slots_hint >= 3 * round_slots * (max_nprobe > 0 ? max_nprobe : 1);
+  const int budget = (spread ? 2 : 4) * k;
   int rl = 1;
-  while (rl < rp && nw * 64 * rl < 2 * k) rl <<= 1;
+  while (rl < rp && nw * 64 * rl < budget) rl <<= 1;
   return rl;
 }
 

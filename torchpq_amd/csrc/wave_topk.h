@@ -195,7 +195,6 @@ struct WaveSelector {
   float tau;  // admission threshold: candidates with v < tau cannot reach the final top-k
   int k;
   int n_flush;  // flushes so far (wave-uniform)
-  int n_admitted;  // candidates enqueued so far (wave-uniform): <= 64 R means the list never evicted anything
   float margin; // admission slack: candidates down to tau - margin are kept (packed scan: 2*delta)
 
   __device__ __forceinline__ void init(float* qv_, int* qi_, int k_) {
@@ -206,7 +205,6 @@ struct WaveSelector {
     tau = -INFINITY;
     k = k_;
     n_flush = 0;
-    n_admitted = 0;
     margin = 0.f;
   }
 
@@ -233,7 +231,6 @@ struct WaveSelector {
     unsigned long long mask = __ballot(pass);
     if (mask == 0ull) return;
     int n = __popcll(mask);
-    n_admitted += n;
     if (qn + n > 64) {
       flush();
     }

@@ -162,7 +162,7 @@ class IVFPQTopkHip:
                     ptr(packed), ptr(data), ptr(precomputed), ptr(is_empty), ptr(cell_start),
                     ptr(cell_size), ptr(n_probe_list), ptr(values), ptr(address), ptr(address2id),
                     ptr(ids), n_data, n_query, n_probe, self.m, k, n_split, ptr(ws), ws_bytes,
-                    ptr(tickets), stream_ptr(device))
+                    ptr(tickets), int(slots_hint or 0), stream_ptr(device))
                 if rc != 0:
                     self._drop_tickets(device)
                 check(rc, "tpq_ivfpq_scan_topk_packed_tickets")
@@ -224,7 +224,7 @@ class IVFPQTopkHip:
                 ptr(packed), ptr(data), ptr(query), ptr(codebook), ds, metric, ptr(is_empty),
                 ptr(cell_start), ptr(cell_size), ptr(n_probe_list), ptr(values), ptr(address),
                 ptr(address2id), ptr(ids), n_data, n_query, n_probe, self.m, k, n_split, ptr(ws),
-                ws_bytes, ptr(tickets), stream_ptr(device))
+                ws_bytes, ptr(tickets), int(slots_hint or 0), stream_ptr(device))
             if rc != 0:
                 self._drop_tickets(device)
             check(rc, "tpq_ivfpq_search_fused_tickets")
