@@ -61,7 +61,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix-core peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix-core peak (MI355X_MICROARCH.md; not the 2:1-sparsity figure)
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 
 
 # ---------------------------------------------------------------------------------------------

@@ -226,6 +226,32 @@ struct WaveSelector {
     tau = fmaxf(tau, top.kth_value(k));
   }
 
+  // Large k (the packed scan's pool mode): every admitted candidate is ALSO appended to an append-only pool in
+  // the caller's workspace (keys: value image, ~index); the sorted list then only has to be long enough for the
+  // admission threshold, not for k.  A full pool drops the candidate and latches `n` beyond `cap` (the query is
+  // then redone exactly).
+  struct Pool {
+    unsigned* hi;
+    unsigned* lo;
+    int n, cap;  // wave-uniform
+  };
+  __device__ __forceinline__ void push_pool(Pool& pool, bool pass, float v, int idx) {
+    const unsigned long long mask = __ballot(pass);
+    if (mask == 0ull) return;
+    const int n = __popcll(mask);
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+    if (pool.n + n <= pool.cap) {
+      if (pass) {
+        pool.hi[pool.n + rank] = f2key(v);
+        pool.lo[pool.n + rank] = ~(unsigned)idx;
+      }
+      pool.n += n;
+    } else {
+      pool.n = pool.cap + 1;  // overflow, latched
+    }
+    push(pass, v, idx);
+  }
+
   // every lane calls; lanes with pass==true enqueue (v, idx)
   __device__ __forceinline__ void push(bool pass, float v, int idx) {
     unsigned long long mask = __ballot(pass);
