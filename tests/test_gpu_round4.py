@@ -252,3 +252,52 @@ def test_wide_codes_beyond_the_instantiated_scan_layouts(m):
         v, i = idx.search(xq, k=k)
         assert np.array_equal(N(v), ev)
         assert np.array_equal(N(i), orc.get_id_by_address(N(idx._address2id), ea))
+
+
+# ---------------------------------------------------------------------------------------------
+# large k (k > 248 leaves the one-launch finish; reference: fn/IVFPQTopk.py:64-104 serves k <= 1024)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m", [4, 8, 12, 16, 24, 32, 40, 64, 96, 120, 128])
+@pytest.mark.parametrize("k,n_split", [(300, 1), (500, 3), (1000, 1), (1016, 2), (249, 5)])
+def test_large_k_equals_the_oracle(K, m, k, n_split):
+    from test_gpu_kernels import _random_index
+    rng = np.random.default_rng(m * 10007 + k)
+    n_cells, nq, n_probe = 48, 7, 20
+    storage, is_empty, start, sizes, a2i = _random_index(rng, m, n_cells, 330, n_tomb=40, dup_frac=0.02)
+    lut = (rng.standard_normal((m, nq, 256)) * 100).astype(np.float32)
+    cells = np.stack([rng.permutation(n_cells)[:n_probe] for _ in range(nq)])
+    cells[1, 5] = cells[1, 2]              # a cell listed twice, non-adjacent: its slots count twice
+    npl = np.full(nq, n_probe, np.int64)
+    npl[2] = 1                             # fewer than k candidates: padded rows
+    cs, sz = start[cells], sizes[cells]
+    ev, ea = c_oracle.scan_topk(storage, lut, is_empty, cs, sz, npl, k)
+    ei = orc.get_id_by_address(a2i, ea)
+    scan = K.IVFPQTopkHip(m=m)
+    st = T(storage)
+    v, a, i = scan.topk(st, T(lut), T(is_empty), T(cs), T(sz), T(npl), n_candidates=k,
+                        packed=K.PackCodesHip()(st), n_split=n_split, address2id=T(a2i))
+    assert np.array_equal(N(v), ev) and np.array_equal(N(a), ea) and np.array_equal(N(i), ei)
+
+
+@pytest.mark.parametrize("m,k", [(64, 1000), (16, 400)])
+def test_large_k_on_ascending_values(K, m, k):
+    """slots arranged so that every slot beats all before it (ascending values along the scan order): each one
+    passes the admission threshold -- the worst case for the candidate queues and lists"""
+    rng = np.random.default_rng(m + k)
+    n, nq = 40000, 2
+    lut = np.zeros((m, nq, 256), np.float32)
+    lut[0, :, :] = np.arange(256, dtype=np.float32)[None, :] * 256.0
+    lut[1, :, :] = np.arange(256, dtype=np.float32)[None, :]
+    codes = np.zeros((n, m), np.uint8)
+    order = np.arange(n) % 65536
+    codes[:, 0] = order >> 8
+    codes[:, 1] = order & 255
+    storage = np.ascontiguousarray(codes.reshape(n, m // 4, 4).transpose(1, 0, 2))
+    is_empty = np.zeros(n, np.uint8)
+    cs, sz, npl = np.zeros((nq, 1), np.int64), np.full((nq, 1), n, np.int64), np.ones(nq, np.int64)
+    ev, ea = c_oracle.scan_topk(storage, lut, is_empty, cs, sz, npl, k)
+    scan = K.IVFPQTopkHip(m=m)
+    st = T(storage)
+    v, a = scan.topk(st, T(lut), T(is_empty), T(cs), T(sz), T(npl), n_candidates=k,
+                     packed=K.PackCodesHip()(st), n_split=1)
+    assert np.array_equal(N(v), ev) and np.array_equal(N(a), ea)
