@@ -142,6 +142,28 @@ def test_lloyd_step_non_finite_data_and_centroids_go_through_the_exact_path():
     assert N(step.rechecked())[2] == n
 
 
+def test_lloyd_prepare_scale_from_a_sample_flags_what_the_sample_missed():
+    """from 2^18 points on tpq_lloyd_prepare reads every sixteenth 4-KiB run of a row for the scale and leaves one
+    bit of headroom: an outlier in an unsampled run that exceeds it flags its sub-problem (all of it re-checked
+    exactly); one inside the headroom does not; labels equal the fp32 kernel's either way"""
+    import torchpq_amd.kernels as K
+    rng = np.random.default_rng(17)
+    l, d, n, k = 3, 16, 300_000, 64
+    x = rng.standard_normal((l, d, n)).astype(np.float32)
+    cent = x[:, :, :k].copy()
+    big = float(np.abs(x).max())
+    x[1, 4, 5000] = 9.0 * big        # run 4 of its row (5000 // 1024): not a sampled run, beyond the headroom
+    x[2, 7, 7000] = 1.5 * big        # unsampled too, inside the headroom
+    step = K.LloydStepHip(T(x), T(cent))
+    _, lab, new = step(T(cent))
+    _, l32 = K.MaxSimHip(distance="euclidean")(T(x), T(cent), dim=2, mode="tn")
+    assert torch.equal(lab, l32)
+    rc = N(step.rechecked())
+    assert rc[1] == n and rc[0] < n // 5 and rc[2] < n // 5
+    ref_new = K.ComputeCentroidsHip()(T(x), l32, k)
+    assert float((new - ref_new).abs().max()) <= 1e-5 * float(ref_new.abs().max())
+
+
 @pytest.mark.parametrize("case", ["1", "3", "tol", "redo", "redo_b"])
 def test_fit_through_the_prepared_path_vs_oracle_and_reference(fx_kmeans_fit, case, monkeypatch):
     """MultiKMeans.fit forced through LloydStepHip on the reference-made fixture (d = 8: the gate on

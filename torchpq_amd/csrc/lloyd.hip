@@ -120,9 +120,12 @@ __global__ __launch_bounds__(256) void mu_kernel(const float* __restrict__ B, fl
 
 // max |x - mu| per sub-problem (bits of a non-negative float: integer order == value order) and a
 // flag for any non-finite element.  grid (chunks, d, l)
+// `sample` > 1: only every sample-th 4-KiB run of a row is read (tpq_lloyd_prepare: the scale then leaves one bit
+// of headroom and split_kernel, which sees every element, flags what exceeds it -- a full pass over 16 GB for
+// a power of two was 2.8 ms of the 13.3 ms the preparation took)
 __global__ __launch_bounds__(256) void maxabs_kernel(const float* __restrict__ A, const float* __restrict__ mu,
                                                     unsigned* __restrict__ maxbits, int* __restrict__ flag, int d,
-                                                    int64_t m) {
+                                                    int64_t m, int sample = 1) {
   const int k = blockIdx.y, b = blockIdx.z;
   const float* row = A + ((int64_t)b * d + k) * m;
   const float mk = mu[b * kMu + k];
@@ -131,14 +134,14 @@ __global__ __launch_bounds__(256) void maxabs_kernel(const float* __restrict__ A
   const int64_t per = (m + gridDim.x - 1) / gridDim.x;
   const int64_t i0 = (int64_t)blockIdx.x * per, i1 = (i0 + per) < m ? (i0 + per) : m;
   if ((m & 3) == 0 && (per & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0) {
-    for (int64_t i = i0 + (int64_t)threadIdx.x * 4; i < i1; i += 1024) {
+    for (int64_t i = i0 + (int64_t)threadIdx.x * 4; i < i1; i += 1024 * (int64_t)sample) {
       const float4 x = *reinterpret_cast<const float4*>(row + i);
       const float v0 = fabsf(x.x - mk), v1 = fabsf(x.y - mk), v2 = fabsf(x.z - mk), v3 = fabsf(x.w - mk);
       bad |= !(v0 <= 3.0e38f) | !(v1 <= 3.0e38f) | !(v2 <= 3.0e38f) | !(v3 <= 3.0e38f);
       mx = fmaxf(fmaxf(mx, fmaxf(v0, v1)), fmaxf(v2, v3));
     }
   } else {
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256 * (int64_t)sample) {
       const float v = fabsf(row[i] - mk);
       bad |= !(v <= 3.0e38f);
       mx = fmaxf(mx, v);
@@ -163,8 +166,9 @@ __global__ __launch_bounds__(256) void maxabs_kernel(const float* __restrict__ A
 }
 
 // s[b] = 2^(13 - floor(log2 max)): max |x - mu| s in [2^13, 2^14)
+// (headroom = 1: the maximum came from a sample; it lands in [2^12, 2^13) and the data may exceed it twofold)
 __global__ void scale_kernel(const unsigned* __restrict__ maxbits, int* __restrict__ flag, float* __restrict__ scale,
-                             int l) {
+                             int l, int headroom = 0) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= l) return;
   const float mx = __uint_as_float(maxbits[b]);
@@ -173,7 +177,7 @@ __global__ void scale_kernel(const unsigned* __restrict__ maxbits, int* __restri
     flag[b] = 1;
   } else if (mx > 0.f) {
     int e = ilogbf(mx);
-    int se = 13 - e;
+    int se = 13 - headroom - e;
     se = se > 100 ? 100 : (se < -100 ? -100 : se);
     s = ldexpf(1.f, se);
     if (!(mx * s < 16384.f)) flag[b] = 1;  // (a clamped exponent on astronomically large data)
@@ -197,54 +201,59 @@ __device__ __forceinline__ void unpack_bound_norms(float y, float& n2r, float& n
 }
 constexpr int kCm = 4;  // words per sub-problem in cmax2_bits: max N, max |c|^2, max |C - Ch|^2, -
 
-// pieces + norms.  grid (ceil(T / 4), l), 4 waves; wave -> tile of 32 points, lane (point l31, half)
-// holds dimensions 16 st + 8 half + j of its point: the B operand of v_mfma_f32_32x32x16_f16.
+// pieces + norms.  grid (ceil(m / 256), l), 4 waves; LANE = POINT (64 consecutive points per wave = two tiles):
+// every load instruction reads 256 contiguous bytes of one dimension's row, and a lane owns the 64 contiguous
+// bytes of its point in each (k-step pair, piece), written as four 16-byte chunks -- a wave's stores of one pair
+// are two whole 2-KiB runs.  (Round 3's kernel gave a lane (point, half of a k-step): 128-byte reads, 32-byte
+// interleaved writes, 2.9 TB/s over 16 GB in + 16 GB out.)  Every element is seen here, so this is also where a
+// non-finite value, or one beyond the range the (sampled) scale leaves, flags its sub-problem.
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ A, const float* __restrict__ mu,
                                                    const float* __restrict__ scale, u32x4* __restrict__ hi,
-                                                   u32x4* __restrict__ mid, float2* __restrict__ norms, int d,
-                                                   int64_t m, int64_t T, int KS) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+                                                   u32x4* __restrict__ mid, float2* __restrict__ norms,
+                                                   int* __restrict__ flag, int d, int64_t m, int64_t T, int KS) {
   const int b = blockIdx.y;
-  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t tile = i >> 5;
   if (tile >= T) return;
-  const int64_t i = tile * 32 + l31;
+  const int l31 = (int)(i & 31);
   const bool iv = i < m;
   const float* Ab = A + (int64_t)b * d * m + (iv ? i : 0);
+  const float* mub = mu + b * kMu;
   const float s = scale[b];
   const int Q = (KS + 1) / 2;
-  const int64_t fo = ((int64_t)b * T + tile) * Q * 128 + l31 * 4 + half;  // in 16-byte chunks
   float n2c = 0.f, n2r = 0.f, n2m = 0.f;
-  for (int st = 0; st < KS; ++st) {
-    float x[8];
+  int bad = 0;
+  for (int q = 0; q < Q; ++q) {
+    float x[32];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = 16 * st + 8 * half + j;
+    for (int j = 0; j < 32; ++j) {
+      const int k = 32 * q + j;
       x[j] = (iv && k < d) ? Ab[(int64_t)k * m] : 0.f;
     }
-    f16x8 h, mm;
+    const int64_t fo = (((int64_t)b * T + tile) * Q + q) * 128 + l31 * 4;  // in 16-byte chunks
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = 16 * st + 8 * half + j;
-      const float a = (iv && k < d) ? (x[j] - mu[b * kMu + k]) * s : 0.f;
-      const _Float16 hh = (_Float16)a;
-      const float r = a - (float)hh;
-      h[j] = hh;
-      mm[j] = (_Float16)r;
-      n2c = fmaf(a, a, n2c);
-      n2r = fmaf(x[j], x[j], n2r);
-      n2m = fmaf(r, r, n2m);
+    for (int c = 0; c < 4; ++c) {
+      f16x8 h, mm;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 32 * q + 8 * c + j;
+        const float xv = x[8 * c + j];
+        const float a = (iv && k < d) ? (xv - mub[k]) * s : 0.f;
+        bad |= !(fabsf(a) < 16384.f);
+        const _Float16 hh = (_Float16)a;
+        const float r = a - (float)hh;
+        h[j] = hh;
+        mm[j] = (_Float16)r;
+        n2c = fmaf(a, a, n2c);
+        n2r = fmaf(xv, xv, n2r);
+        n2m = fmaf(r, r, n2m);
+      }
+      hi[fo + c] = __builtin_bit_cast(u32x4, h);
+      mid[fo + c] = __builtin_bit_cast(u32x4, mm);
     }
-    hi[fo + (st >> 1) * 128 + (st & 1) * 2] = __builtin_bit_cast(u32x4, h);
-    mid[fo + (st >> 1) * 128 + (st & 1) * 2] = __builtin_bit_cast(u32x4, mm);
   }
-  if (KS & 1) {  // the empty second k-step of the last pair
-    hi[fo + (KS >> 1) * 128 + 2] = u32x4{0u, 0u, 0u, 0u};
-    mid[fo + (KS >> 1) * 128 + 2] = u32x4{0u, 0u, 0u, 0u};
-  }
-  n2c += __shfl_xor(n2c, 32, 64);
-  n2r += __shfl_xor(n2r, 32, 64);
-  n2m += __shfl_xor(n2m, 32, 64);
-  if (half == 0) norms[(int64_t)b * T * 32 + tile * 32 + l31] = make_float2(n2c, pack_bound_norms(n2r, n2m));
+  norms[(int64_t)b * T * 32 + i] = make_float2(n2c, pack_bound_norms(n2r, n2m));
+  if (__ballot(bad != 0) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag + b, 1);
 }
 
 // ---- per iteration: centroid fragments -----------------------------------------------------------
@@ -1572,9 +1581,9 @@ static int run_assign(const float* A, const float* B, float* vals, int64_t* inds
   TPQ_LAUNCH_CHECK("lloyd maxabs_kernel");
   hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(64), 0, st, maxbits, flag, scale, 1);
   TPQ_LAUNCH_CHECK("lloyd scale_kernel");
-  hipLaunchKernelGGL(split_kernel, dim3((unsigned)((P.T + 3) / 4), 1), dim3(256), 0, st, A, mu, scale,
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)((P.T + 7) / 8), 1), dim3(256), 0, st, A, mu, scale,
                      reinterpret_cast<u32x4*>(p + P.hi_off), reinterpret_cast<u32x4*>(p + P.mid_off),
-                     reinterpret_cast<float2*>(p + P.norms_off), d, m, P.T, KS);
+                     reinterpret_cast<float2*>(p + P.norms_off), flag, d, m, P.T, KS);
   TPQ_LAUNCH_CHECK("lloyd split_kernel");
   hipLaunchKernelGGL(cprep_kernel, dim3(8 * L.chunks, 1), dim3(64), 0, st, B, mu, scale, frags, cmax, cflag, d, n, KS);
   TPQ_LAUNCH_CHECK("lloyd cprep_kernel");
@@ -2649,13 +2658,18 @@ extern "C" int tpq_lloyd_prepare(const float* data, const float* centroids0, voi
   int chunks = (int)(4096 / ((int64_t)l * d));
   if (chunks < 1) chunks = 1;
   if ((int64_t)chunks * 4096 > m) chunks = (int)((m + 4095) / 4096);
-  hipLaunchKernelGGL(lloyd::maxabs_kernel, dim3(chunks, d, l), dim3(256), 0, st, data, mu, maxbits, flag, d, m);
+  // the scale is a power of two: read a sixteenth of a large problem for it (every sixteenth 4-KiB run of each
+  // row) and leave one bit of headroom; split_kernel flags the sub-problem whose data exceed it after all
+  const int sample = m >= (1 << 18) ? 16 : 1;
+  hipLaunchKernelGGL(lloyd::maxabs_kernel, dim3(chunks, d, l), dim3(256), 0, st, data, mu, maxbits, flag, d, m,
+                     sample);
   TPQ_LAUNCH_CHECK("lloyd maxabs_kernel");
-  hipLaunchKernelGGL(lloyd::scale_kernel, dim3((l + 63) / 64), dim3(64), 0, st, maxbits, flag, scale, l);
+  hipLaunchKernelGGL(lloyd::scale_kernel, dim3((l + 63) / 64), dim3(64), 0, st, maxbits, flag, scale, l,
+                     sample > 1 ? 1 : 0);
   TPQ_LAUNCH_CHECK("lloyd scale_kernel");
-  hipLaunchKernelGGL(lloyd::split_kernel, dim3((unsigned)((L.T + 3) / 4), l), dim3(256), 0, st, data, mu, scale,
+  hipLaunchKernelGGL(lloyd::split_kernel, dim3((unsigned)((L.T + 7) / 8), l), dim3(256), 0, st, data, mu, scale,
                      reinterpret_cast<lloyd::u32x4*>(p + L.hi_off), reinterpret_cast<lloyd::u32x4*>(p + L.mid_off),
-                     reinterpret_cast<float2*>(p + L.norms_off), d, m, L.T, L.KS);
+                     reinterpret_cast<float2*>(p + L.norms_off), flag, d, m, L.T, L.KS);
   TPQ_LAUNCH_CHECK("lloyd split_kernel");
   return TPQ_OK;
 }
