@@ -233,6 +233,34 @@ int tpq_ivfpq_coarse_probe(const float* query, const float* centroids,
                            int64_t* cell_size, int64_t* n_probe_list, int d, int nq, int n_cells,
                            int n_probe, float smart_temperature, void* workspace,
                            size_t workspace_bytes, tpq_stream_t stream);
+/* The same call with the choice of the SELECTING arithmetic left to the caller (the result -- cells, order,
+ * similarities -- is the fp32 kernel's, bit for bit, on every route).  The reference's reduced-precision coarse GEMM
+ * (use_tensor_core / fp16_scale_mode, torchpq/metric.py:47-73, index/IVFPQIndex.py:98-125) trades accuracy for speed;
+ * here the fp16 matrix cores only select: fast similarities of all (query, cell) pairs, a candidate band of twice a
+ * rigorous error bound around the n_probe-th best, and the fp32 chain's own value for every candidate (d <= 128,
+ * n_cells % 32 == 0; other shapes take the fp32 kernels on every route).
+ *   TPQ_PROBE_ROUTE_AUTO  what tpq_ivfpq_coarse_probe does: the fp16 selection from 2 048 cells on (batches of more
+ *                         than 256 queries, n_probe <= 112), the fp32 kernels otherwise
+ *   TPQ_PROBE_ROUTE_FP32  the fp32-MFMA similarity kernels
+ *   TPQ_PROBE_ROUTE_FP16  the fp16 selection whenever the shape allows it
+ * workspace: tpq_ivfpq_coarse_probe_route_workspace_bytes(d, nq, n_cells, route). */
+#define TPQ_PROBE_ROUTE_AUTO 0
+#define TPQ_PROBE_ROUTE_FP32 1
+#define TPQ_PROBE_ROUTE_FP16 2
+size_t tpq_ivfpq_coarse_probe_route_workspace_bytes(int d, int nq, int n_cells, int route);
+int tpq_ivfpq_coarse_probe_route(const float* query, const float* centroids,
+                                 const int64_t* cell_start_tbl, const int64_t* cell_size_tbl,
+                                 float* topk_sims, int64_t* cells, int64_t* cell_start,
+                                 int64_t* cell_size, int64_t* n_probe_list, int d, int nq, int n_cells,
+                                 int n_probe, float smart_temperature, int route, const void* prepared,
+                                 void* workspace, size_t workspace_bytes, tpq_stream_t stream);
+/* What the fp16 selection needs of the CENTROIDS alone (their mean, the fp16 scale, MFMA fragments, row copies,
+ * |C|^2) can be prepared once per codebook into a caller-owned block and handed to every call (`prepared`; NULL: it is
+ * prepared into the workspace per call, ~0.1 ms at 16 384 cells).  tpq_ivfpq_coarse_probe_prepared_bytes is 0 for shapes
+ * without the fp16 pass.  The block is only read by the probe calls. */
+size_t tpq_ivfpq_coarse_probe_prepared_bytes(int d, int n_cells);
+int tpq_ivfpq_coarse_probe_prepare(const float* centroids, int d, int n_cells, void* prepared,
+                                   size_t prepared_bytes, tpq_stream_t stream);
 
 /* a-5  smart probing          torchpq/index/IVFPQIndex.py:499-512
  * topk_sims f32 [rows][n_probe] -> n_probe_list i64 [rows] in [0, n_probe]

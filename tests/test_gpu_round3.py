@@ -63,16 +63,25 @@ def _probe_data(kind, d, nq, n_cells, rng):
     (32, 1100, 16500, 8, True),      # 128-query blocks + group filter (IVF16384 regime)
     (24, 1300, 8200, 64, False),
     (128, 10000, 1024, 32, False),   # configs[1]'s coarse step
+    (128, 700, 4096, 16, True),      # the reference grid's IVF4096
+    (128, 300, 16384, 128, False),   # ... and IVF16384 at its largest n_probe
+    (100, 513, 2052, 40, True),      # ragged everywhere: d, queries, cells (a multiple of 4 only)
+    (64, 1000, 3000, 1000, False),   # n_probe close to the candidate list's limit
 ])
-def test_coarse_probe_is_bit_exact(K, kind, d, nq, n_cells, n_probe, smart):
+@pytest.mark.parametrize("route", ["auto", "fp32", "fp16"])
+def test_coarse_probe_is_bit_exact(K, kind, d, nq, n_cells, n_probe, smart, route):
     """sims == oracle.coarse_sims gathered at the chosen cells, cells == the (value desc, column asc)
-    top-n_probe of the oracle's sims, n_probe_list == smart probing of those sims."""
+    top-n_probe of the oracle's sims, n_probe_list == smart probing of those sims -- on every route: the fp32-MFMA
+    kernels, and the fp16 selection pass + exact candidates (use_tensor_core=True; "auto" takes it from 2 048 cells)"""
     rng = np.random.default_rng(1000 * d + nq + len(kind))
     x, c = _probe_data(kind, d, nq, n_cells, rng)
     sizes = rng.integers(0, 500, n_cells).astype(np.int64)
     start = (np.cumsum(sizes + 3) - sizes - 3).astype(np.int64)
-    sims, cells, cs, sz, npl = K.CoarseProbeHip()(T(x), T(c), T(start), T(sizes), n_probe,
-                                                  30.0 if smart else None)
+    tc = T(c)
+    # (the codebook's share of the fp16 pass prepared once, as IVFPQIndex does -- or per call, inside the workspace)
+    prepared = K.CoarseProbeHip.prepare(tc) if (route == "fp16" and nq % 2 == 0) else None
+    sims, cells, cs, sz, npl = K.CoarseProbeHip(route=route)(T(x), tc, T(start), T(sizes), n_probe,
+                                                             30.0 if smart else None, prepared=prepared)
     full = c_oracle.coarse_sims(x, c)
     ev, ei = orc.topk_desc(full, n_probe)          # value desc, ties -> smaller column
     assert np.array_equal(N(sims), ev)
@@ -89,6 +98,41 @@ def test_coarse_probe_is_bit_exact(K, kind, d, nq, n_cells, n_probe, smart):
         assert np.array_equal(got, N(K.SmartProbingHip()(T(ev), 30.0)))
     else:
         assert np.array_equal(N(npl), np.full(nq, n_probe))
+
+
+@pytest.mark.parametrize("case", ["identical_cells", "nan_query", "huge_centroid", "tiny", "offset", "far_queries"])
+def test_coarse_probe_fp16_route_on_degenerate_data(K, case):
+    """the fp16 selection's exits: a candidate band that overflows its list (thousands of identical centroids),
+    queries / centroids the fp16 scale cannot hold (band = inf), magnitudes of 1e-18, a large common offset --
+    the result is the fp32 route's, bit for bit"""
+    rng = np.random.default_rng(len(case))
+    d, nq, n_cells, n_probe = 64, 400, 4096, 32
+    x = (rng.standard_normal((d, nq)) * 3).astype(np.float32)
+    c = (rng.standard_normal((d, n_cells)) * 3).astype(np.float32)
+    if case == "identical_cells":
+        c[:, 100:3000] = c[:, 100:101]
+    elif case == "nan_query":
+        x[3, 7] = np.nan
+        x[5, 9] = np.inf
+    elif case == "huge_centroid":
+        c[:, 77] = 1.0e9
+    elif case == "tiny":
+        x *= 1e-18
+        c *= 1e-18
+    elif case == "offset":
+        x += 1.0e4
+        c += 1.0e4
+    elif case == "far_queries":      # beyond the range the centroids give the fp16 scale: those queries go exact
+        x[:, ::7] *= 50.0
+    z = np.zeros(n_cells, np.int64)
+    want = K.CoarseProbeHip(route="fp32")(T(x), T(c), T(z), T(z), n_probe, 30.0)
+    tc = T(c)
+    got = K.CoarseProbeHip(route="fp16")(T(x), tc, T(z), T(z), n_probe, 30.0, prepared=K.CoarseProbeHip.prepare(tc))
+    ok_rows = np.ones(nq, bool)
+    if case == "nan_query":
+        ok_rows[[7, 9]] = False    # rows of NaN similarities have no defined order on either route
+    for a, b in zip(want, got):
+        assert np.array_equal(N(a)[ok_rows], N(b)[ok_rows], equal_nan=True)
 
 
 def test_a_sim_does_not_depend_on_the_batch_it_arrives_in(K):

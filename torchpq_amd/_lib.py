@@ -20,6 +20,7 @@ METRIC_INNER = 1
 ERR_UNSUPPORTED = -4  # TPQ_ERR_UNSUPPORTED
 ASSIGN_ROUTE_AUTO = 0     # TPQ_ASSIGN_ROUTE_AUTO
 ASSIGN_ROUTE_CASCADE = 1  # TPQ_ASSIGN_ROUTE_CASCADE
+PROBE_ROUTE_AUTO, PROBE_ROUTE_FP32, PROBE_ROUTE_FP16 = 0, 1, 2  # TPQ_PROBE_ROUTE_*
 
 _vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
 
@@ -54,6 +55,11 @@ SIGNATURES = {
     "tpq_ivfpq_coarse_probe_workspace_bytes": (_sz, [_i, _i]),
     "tpq_ivfpq_coarse_probe": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f,
                                     _vp, _sz, _vp]),
+    "tpq_ivfpq_coarse_probe_route_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "tpq_ivfpq_coarse_probe_route": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i,
+                                          _vp, _vp, _sz, _vp]),
+    "tpq_ivfpq_coarse_probe_prepared_bytes": (_sz, [_i, _i]),
+    "tpq_ivfpq_coarse_probe_prepare": (_i, [_vp, _i, _i, _vp, _sz, _vp]),
     "tpq_get_id_by_address": (_i, [_vp, _i64, _vp, _vp, _i64, _vp]),
     "tpq_get_address_by_id": (_i, [_vp, _i64, _vp, _vp, _i64, _vp]),
     "tpq_max_sim": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -12,7 +12,7 @@ stale() {  # object older than its source or any shared header?
   local obj="$1" src="$2"
   [[ ! -f "$obj" || "$obj" -ot "$src" || "$obj" -ot "${HERE}/common.h" \
      || "$obj" -ot "${HERE}/wave_topk.h" || "$obj" -ot "${HERE}/scan_layout.h" \
-     || "$obj" -ot "${HERE}/scan_device.h" \
+     || "$obj" -ot "${HERE}/scan_device.h" || "$obj" -ot "${HERE}/probe_fast.h" \
      || "$obj" -ot "${HERE}/../../include/torchpq_amd.h" || "${FORCE:-0}" == "1" ]]
 }
 # the scan-layout kernels: one translation unit per sub-quantizer count

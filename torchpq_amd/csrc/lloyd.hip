@@ -38,6 +38,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "probe_fast.h"
 
 namespace tpq {
 int launch_max_sim_list(const float* A, const float* B, float* vals, int64_t* inds, int l, int d, int m, int n,
@@ -46,6 +47,7 @@ int launch_max_sim_list(const float* A, const float* B, float* vals, int64_t* in
 namespace lloyd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -252,7 +254,8 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ A,
       mid[fo + c] = __builtin_bit_cast(u32x4, mm);
     }
   }
-  norms[(int64_t)b * T * 32 + i] = make_float2(n2c, pack_bound_norms(n2r, n2m));
+  // (a point the scale cannot hold carries an infinite norm: every bound derived from it is infinite, whoever reads it)
+  norms[(int64_t)b * T * 32 + i] = make_float2(bad ? INFINITY : n2c, pack_bound_norms(n2r, n2m));
   if (__ballot(bad != 0) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag + b, 1);
 }
 
@@ -2576,9 +2579,371 @@ static int run_cand_tail(const float* A, const float* B, float* vals, int64_t* i
   return launch_max_sim_list(A, B, vals, inds, 1, d, (int)m, n, 1, list1, count_fb, keys, Ac, L.cap, st);
 }
 
+// ---- the coarse step of search(): fast similarities of every (query, cell) pair (probe_fast.h) ---------------
+// coarse_kernel's loop -- hi pieces only, one product per k-step, the -N MFMA, two column tiles per A operand,
+// the chunk's fragments staged once per block by LDS-DMA -- with another epilogue: instead of the top-2 update (2.5
+// VALU instructions per value, what bounds level 1) the 16 values a lane holds of its query are stored as four
+// 16-byte pieces of the query's row (rows 8 g + 4 half + j of a 32 x 32 tile are four consecutive cells), and the
+// maximum over each 128-cell group is kept for the row select's group filter.  grid (query blocks, 256-cell chunks);
+// a block walks n_wide wide tiles per wave (small query batches: one, so that 10 000 queries x 64 chunks are 1 280 blocks).
+struct ProbeSimsArgs {
+  const u32x4* hi;
+  const u32x4* frags;
+  float* sims;
+  float* gmax;
+  int nq, n_cells, n_groups, n_wide;
+  int64_t T;
+  int chunk_frag_stride;
+};
+
+template <int KS>
+__global__ __launch_bounds__(kWaves * 64, 2) void probe_sims_kernel(ProbeSimsArgs a) {
+  constexpr int FPU = 2 * KS + 1;  // fragments per unit in global memory
+  constexpr int FL = KS + 1;       // ... in LDS
+  constexpr int Q = (KS + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int chunk = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l31 = lane & 31, half = lane >> 5;
+  {
+    const char* src = reinterpret_cast<const char*>(a.frags) + (size_t)chunk * a.chunk_frag_stride * 16;
+    for (int f = wave; f < 8 * FL; f += kWaves) {
+      const int unit = f / FL, j = f % FL;
+      const int sf = unit * FPU + (j ? 2 * j - 1 : 0);  // -N, then the hi piece of k-step j - 1
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + sf * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(smem + f * 1024), 16, 0, 0);
+    }
+  }
+  const int64_t slice = a.T * Q * 2048;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(a.hi)), 0, (int)slice, 0x00020000);
+  const int n_wide = a.n_wide;
+  auto wide_of = [&](int t) -> int64_t { return ((int64_t)blockIdx.x * n_wide + t) * kWaves + wave; };
+  auto frag_voff = [&](int t) -> int {
+    const int64_t wt = wide_of(t);
+    return (t < n_wide && 2 * wt < a.T) ? (int)(2 * wt * Q * 2048) + l31 * 64 + half * 16 : 0x7ffffff0;
+  };
+  f16x8 xsb[2][2][KS];  // [buffer][column tile][k-step]
+  auto load_frag = [&](int voff, auto e_c, f16x8 (&dst)[2][KS]) {
+    constexpr int e = decltype(e_c)::value, ct = e / KS, st = e % KS;
+    dst[ct][st] = __builtin_bit_cast(
+        f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, ct * Q * 2048 + (st >> 1) * 2048 + (st & 1) * 32, 0));
+  };
+  {
+    const int voff = frag_voff(0);
+    static_for<0, 2 * KS>([&](auto e_c) { load_frag(voff, e_c, xsb[0]); });
+  }
+  __syncthreads();  // fragments (vmcnt(0) of the DMA) are in LDS
+  const u32x4* fp = reinterpret_cast<const u32x4*>(smem) + lane;
+  auto ldsf = [&](const u32x4* p) -> f16x8 { return __builtin_bit_cast(f16x8, *p); };
+  f32x16 acc[2];
+  f16x8 a0 = ldsf(fp + 1 * 64), a1 = a0, aring[3];
+  if constexpr (KS > 1) a1 = ldsf(fp + 2 * 64);
+  bf16x8 bones = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (half == 0) {
+    bones[0] = (__bf16)1.0f;
+    bones[1] = (__bf16)1.0f;
+    bones[2] = (__bf16)1.0f;
+  }
+  float gm[2][2];  // [column tile][group of the chunk]
+  // the sims rows of this block's queries as ONE buffer resource (base: the block's first query, the chunk's first
+  // cell): a lane's stores are buffer_store_dwordx4 at a 32-bit offset -- its row, its half -- plus a compile-time
+  // constant; rows beyond nq get an offset beyond the resource's range and are dropped by the hardware (64-bit
+  // per-lane pointers and exec-mask predicates put this kernel 319 registers over its budget)
+  const int64_t q_block0 = (int64_t)blockIdx.x * n_wide * kWaves * 64;
+  const int64_t rows_here = (a.nq - q_block0) < (int64_t)n_wide * kWaves * 64 ? (a.nq - q_block0) : (int64_t)n_wide * kWaves * 64;
+  const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(a.sims + q_block0 * a.n_cells + chunk * 256), 0,
+      (int)(rows_here > 0 ? (rows_here - 1) * (int64_t)a.n_cells * 4 + (a.n_cells - chunk * 256) * 4 : 0), 0x00020000);
+  int svoff[2];    // byte offset of the lane's row (and half) of each column tile inside that resource
+  const int units_here = (a.n_cells - chunk * 256 + 31) / 32;  // (n_cells % 32 == 0: whole units)
+
+  auto unit = [&](auto u_c, int voff_next, const f16x8 (&xs)[2][KS], f16x8 (&xsn)[2][KS]) {
+    constexpr int U = decltype(u_c)::value;
+    const u32x4* up = fp + U * FL * 64;
+    const u32x4* upn = fp + ((U + 1) & 7) * FL * 64;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bf16x8 cfrag = __builtin_bit_cast(bf16x8, up[0]);
+    if constexpr (U < 4) {
+      constexpr int l0 = (U * 2 * KS) / 4, l1 = ((U + 1) * 2 * KS) / 4;
+      static_for<l0, l1>([&](auto e_c) { load_frag(voff_next, e_c, xsn); });
+    }
+    static_for<0, KS>([&](auto s_c) {
+      constexpr int st = decltype(s_c)::value;
+      if constexpr (st + 2 < KS) aring[(st + 2) % 3] = ldsf(up + (1 + st + 2) * 64);
+      if constexpr (st == 0) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xs[0][0], zero, 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, xs[1][0], zero, 0, 0, 0);
+        a0 = ldsf(upn + 1 * 64);
+      } else if constexpr (st == 1) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xs[0][1], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, xs[1][1], acc[1], 0, 0, 0);
+        a1 = ldsf(upn + 2 * 64);
+      } else {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[st % 3], xs[0][st], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aring[st % 3], xs[1][st], acc[1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, acc[1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (U < units_here) {  // wave-uniform (the last chunk of a cell count that is not a multiple of 256)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        float mx = gm[ct][U >> 2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = {acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]};
+          mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srsrc, svoff[ct], (U * 32 + 8 * g) * 4, 0);
+        }
+        gm[ct][U >> 2] = mx;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  auto tile = [&](int t, auto cb_c) {
+    constexpr int CB = decltype(cb_c)::value, NX = 1 - CB;
+    const int voff_next = frag_voff(t + 1);
+    const int64_t wt = wide_of(t);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int64_t qi = (2 * wt + ct) * 32 + l31;
+      svoff[ct] = qi < a.nq ? (int)((qi - q_block0) * a.n_cells * 4) + half * 16 : 0x7ffffff0;
+      gm[ct][0] = gm[ct][1] = -INFINITY;
+    }
+    static_for<0, 8>([&](auto u_c) { unit(u_c, voff_next, xsb[CB], xsb[NX]); });
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int64_t qi = (2 * wt + ct) * 32 + l31;
+#pragma unroll
+      for (int gg = 0; gg < 2; ++gg) {
+        const float m2 = fmaxf(gm[ct][gg], __shfl_xor(gm[ct][gg], 32, 64));  // the two halves hold disjoint cells
+        const int grp = chunk * 2 + gg;
+        if (half == 0 && qi < a.nq && grp < a.n_groups) a.gmax[qi * a.n_groups + grp] = m2;
+      }
+    }
+  };
+  using std::integral_constant;
+#pragma unroll 1
+  for (int t = 0; t < n_wide; t += 2) {
+    if (2 * ((int64_t)blockIdx.x * n_wide + t) * kWaves >= a.T) break;
+    tile(t, integral_constant<int, 0>{});
+    if (t + 1 >= n_wide || 2 * ((int64_t)blockIdx.x * n_wide + t + 1) * kWaves >= a.T) break;
+    tile(t + 1, integral_constant<int, 1>{});
+  }
+}
+
+// band[q] = 2 delta' of query q: emit()'s level-1 bound (the pieces this query and the worst centroid actually drop, the
+// fp32 accumulation of the MFMA terms, the subnormal pieces, and the exact chain's own rounding), in f' units;
+// +inf when the queries or the centroids do not fit the fp16 scale (the select then evaluates the query exactly)
+__global__ __launch_bounds__(256) void probe_band_kernel(const float2* __restrict__ norms, const unsigned* __restrict__ cmax2_bits,
+                                                        const float* __restrict__ scale,
+                                                        const int* __restrict__ cflag, float* __restrict__ band, int nq,
+                                                        float eps, float eps_exact, float eta) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  const float s = scale[0];
+  const float cn = sqrtf(__uint_as_float(cmax2_bits[0])), cnr = sqrtf(__uint_as_float(cmax2_bits[1]));
+  const float c2 = sqrtf(__uint_as_float(cmax2_bits[2]));
+  const float2 n2 = norms[q];
+  float n2r, n2m;
+  unpack_bound_norms(n2.y, n2r, n2m);
+  const float an = sqrtf(n2.x), anr = sqrtf(n2r) * s;
+  const float t1 = an + cn, t2 = anr + cnr * s;
+  const float a2 = sqrtf(n2m);
+  const float dropped = a2 * (2.002f * cn + c2) + 1.001f * an * c2;
+  float delta = 1.26f * (dropped + eps * t1 * t1 + eta * (2.f * cn + an) + eps_exact * t2 * t2);
+  if (cflag[0] != 0 || !(delta < 3.0e38f)) delta = INFINITY;  // (a query beyond the scale: n2.x = inf -> delta = inf)
+  band[q] = 2.f * delta;
+}
+
+// the centroids as rows, and |C|^2 as the exact kernels sum it (ascending k, fma)
+__global__ __launch_bounds__(256) void probe_rows_kernel(const float* __restrict__ C, float* __restrict__ ct,
+                                                        float* __restrict__ c2, int d, int n_cells) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8 threads
+  float sq = 0.f;
+  for (int k0 = 0; k0 < d; k0 += 32) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = k0 + ty + 8 * r, c = c0 + tx;
+      tile[ty + 8 * r][tx] = (k < d && c < n_cells) ? C[(int64_t)k * n_cells + c] : 0.f;
+    }
+    __syncthreads();
+    if (ty == 0) {  // (one thread per cell: the chain is sequential in k)
+#pragma unroll
+      for (int kk = 0; kk < 32; ++kk)
+        if (k0 + kk < d) sq = fmaf(tile[kk][tx], tile[kk][tx], sq);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = c0 + ty + 8 * r, k = k0 + tx;
+      if (c < n_cells && k < d) ct[(int64_t)c * d + k] = tile[tx][ty + 8 * r];
+    }
+    __syncthreads();
+  }
+  if (ty == 0 && c0 + tx < n_cells) c2[c0 + tx] = sq;
+}
+
+// Everything that depends on the centroids alone -- mean, scale (from the CENTROIDS' range, one bit of headroom: a
+// query beyond it gets an infinite norm from split_kernel and is evaluated exactly), fp16 fragments, row copies, |C|^2
+// -- is prepared once per codebook (tpq_ivfpq_coarse_probe_prepare) or, without a prepared block, per call.
+struct ProbePrepared {
+  int KS, chunks;
+  size_t mu_off, scale_off, cflag_off, maxbits_off, cmax_off, frags_off, ct_off, c2_off, total;
+};
+static int probe_ks(int d) { return d <= 32 ? 2 : (d <= 64 ? 4 : 8); }
+static ProbePrepared probe_prepared_layout(int d, int n_cells) {
+  ProbePrepared L;
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  L.KS = probe_ks(d);
+  L.chunks = (n_cells + 255) / 256;
+  L.mu_off = 0;
+  L.scale_off = (size_t)kMu * 4;
+  L.cflag_off = L.scale_off + 4;      // (also the "flag" of maxabs / scale: non-finite centroids)
+  L.maxbits_off = L.cflag_off + 4;
+  L.cmax_off = L.maxbits_off + 4;
+  L.frags_off = up(L.cmax_off + 4 * kCm);
+  L.ct_off = up(L.frags_off + (size_t)L.chunks * 8 * (2 * L.KS + 1) * 1024);
+  L.c2_off = up(L.ct_off + (size_t)n_cells * d * 4);
+  L.total = up(L.c2_off + (size_t)n_cells * 4);
+  return L;
+}
+struct ProbeLayout {
+  PrepLayout P;
+  ProbePrepared C;
+  int KS, n_groups;
+  size_t prep_off, flag_off, sims_off, gmax_off, band_off, prepared_off, total;
+};
+static ProbeLayout probe_layout(int d, int nq, int n_cells) {
+  ProbeLayout L;
+  L.C = probe_prepared_layout(d, n_cells);
+  L.KS = L.C.KS;
+  L.P = prep_layout(1, 16 * L.KS, nq);
+  L.n_groups = (n_cells + 127) / 128;
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  L.prep_off = 0;
+  L.flag_off = up(L.P.total);
+  L.sims_off = L.flag_off + 256;
+  L.gmax_off = up(L.sims_off + (size_t)nq * n_cells * 4);
+  L.band_off = up(L.gmax_off + (size_t)nq * L.n_groups * 4);
+  L.prepared_off = up(L.band_off + (size_t)nq * 4);   // (used when the caller passes no prepared block)
+  L.total = L.prepared_off + L.C.total;
+  return L;
+}
+
+template <int KS>
+static int run_probe_prepare(const float* centroids, int d, int n_cells, char* prepared, const ProbePrepared& C,
+                             hipStream_t st) {
+  float* mu = reinterpret_cast<float*>(prepared + C.mu_off);
+  float* scale = reinterpret_cast<float*>(prepared + C.scale_off);
+  int* cflag = reinterpret_cast<int*>(prepared + C.cflag_off);
+  unsigned* maxbits = reinterpret_cast<unsigned*>(prepared + C.maxbits_off);
+  unsigned* cmax = reinterpret_cast<unsigned*>(prepared + C.cmax_off);
+  int rc = check_hip(hipMemsetAsync(prepared, 0, C.frags_off, st), "coarse_probe_prepare memset");
+  if (rc) return rc;
+  hipLaunchKernelGGL(mu_kernel, dim3(d, 1), dim3(256), 0, st, centroids, mu, d, n_cells);
+  TPQ_LAUNCH_CHECK("lloyd mu_kernel");
+  int chunks = (int)(4096 / (int64_t)d);
+  if (chunks < 1) chunks = 1;
+  if ((int64_t)chunks * 4096 > n_cells) chunks = (n_cells + 4095) / 4096;
+  hipLaunchKernelGGL(maxabs_kernel, dim3(chunks, d, 1), dim3(256), 0, st, centroids, mu, maxbits, cflag, d,
+                     (int64_t)n_cells, 1);
+  TPQ_LAUNCH_CHECK("lloyd maxabs_kernel");
+  hipLaunchKernelGGL(scale_kernel, dim3(1), dim3(64), 0, st, maxbits, cflag, scale, 1, 1);
+  TPQ_LAUNCH_CHECK("lloyd scale_kernel");
+  hipLaunchKernelGGL(cprep_kernel, dim3(8 * C.chunks, 1), dim3(64), 0, st, centroids, mu, scale,
+                     reinterpret_cast<u32x4*>(prepared + C.frags_off), cmax, cflag, d, n_cells, KS);
+  TPQ_LAUNCH_CHECK("lloyd cprep_kernel");
+  hipLaunchKernelGGL(probe_rows_kernel, dim3((n_cells + 31) / 32), dim3(256), 0, st, centroids,
+                     reinterpret_cast<float*>(prepared + C.ct_off), reinterpret_cast<float*>(prepared + C.c2_off), d,
+                     n_cells);
+  TPQ_LAUNCH_CHECK("probe_rows_kernel");
+  return TPQ_OK;
+}
+
+template <int KS>
+static int run_probe_sims(const float* query, const char* prepared, int d, int nq, int n_cells, char* ws,
+                          const ProbeLayout& L, ProbeFastBuffers* out, hipStream_t st) {
+  const PrepLayout& P = L.P;
+  const ProbePrepared& C = L.C;
+  char* p = ws + L.prep_off;
+  int* flag = reinterpret_cast<int*>(ws + L.flag_off);   // (queries beyond the scale carry it in their norm)
+  float* sims = reinterpret_cast<float*>(ws + L.sims_off);
+  float* gmax = reinterpret_cast<float*>(ws + L.gmax_off);
+  float* band = reinterpret_cast<float*>(ws + L.band_off);
+  const float* mu = reinterpret_cast<const float*>(prepared + C.mu_off);
+  const float* scale = reinterpret_cast<const float*>(prepared + C.scale_off);
+  const int* cflag = reinterpret_cast<const int*>(prepared + C.cflag_off);
+  const unsigned* cmax = reinterpret_cast<const unsigned*>(prepared + C.cmax_off);
+  const u32x4* frags = reinterpret_cast<const u32x4*>(prepared + C.frags_off);
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)((P.T + 7) / 8), 1), dim3(256), 0, st, query, mu, scale,
+                     reinterpret_cast<u32x4*>(p + P.hi_off), reinterpret_cast<u32x4*>(p + P.mid_off),
+                     reinterpret_cast<float2*>(p + P.norms_off), flag, d, (int64_t)nq, P.T, KS);
+  TPQ_LAUNCH_CHECK("lloyd split_kernel");
+  hipLaunchKernelGGL(probe_band_kernel, dim3((nq + 255) / 256), dim3(256), 0, st,
+                     reinterpret_cast<const float2*>(p + P.norms_off), cmax, scale, cflag, band, nq,
+                     level_eps(KS, 16 * KS, 1), (float)(d + 4) / 16777216.0f, sqrtf((float)(16 * KS)) / 8192.0f);
+  TPQ_LAUNCH_CHECK("probe_band_kernel");
+  const size_t lds = (size_t)8 * (KS + 1) * 1024;
+  auto kernel = probe_sims_kernel<KS>;
+  int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds), "probe_sims_kernel attr");
+  if (rc) return rc;
+  // wide tiles (64 queries) per wave: as few as it takes to put >= ~1 000 blocks on the chip
+  const int64_t wide = (P.T + 1) / 2;
+  int n_wide = (int)((wide * C.chunks) / ((int64_t)kWaves * 1024));
+  n_wide = n_wide < 1 ? 1 : (n_wide > kWide ? kWide : n_wide);
+  const int64_t per_block = (int64_t)kWaves * n_wide;
+  ProbeSimsArgs pa{reinterpret_cast<const u32x4*>(p + P.hi_off), frags, sims, gmax, nq, n_cells, L.n_groups, n_wide,
+                   P.T, 8 * (2 * KS + 1) * 64};
+  hipLaunchKernelGGL(kernel, dim3((unsigned)((wide + per_block - 1) / per_block), C.chunks), dim3(kWaves * 64), lds, st,
+                     pa);
+  TPQ_LAUNCH_CHECK("probe_sims_kernel");
+  *out = ProbeFastBuffers{sims, gmax, band, reinterpret_cast<const float*>(prepared + C.ct_off),
+                          reinterpret_cast<const float*>(prepared + C.c2_off), L.n_groups};
+  return TPQ_OK;
+}
+
 }  // namespace lloyd
 
-// hooks for tpq_coarse_assign (assign_fast.hip): the cascade takes euclidean problems with d <= 128
+// hooks for tpq_ivfpq_coarse_probe (select.hip, probe_fast.h): euclidean, d <= 128, whole 16-byte pieces per row
+int lloyd_probe_supported(int d, int nq, int n_cells) {
+  if (!(d >= 1 && d <= 128 && nq >= 1 && n_cells >= 256 && (n_cells & 31) == 0 && n_cells <= (1 << 22))) return 0;
+  return (int64_t)nq * n_cells < (1LL << 36) ? 1 : 0;
+}
+size_t lloyd_probe_workspace_bytes(int d, int nq, int n_cells) {
+  return lloyd_probe_supported(d, nq, n_cells) ? lloyd::probe_layout(d, nq, n_cells).total : 0;
+}
+size_t lloyd_probe_prepared_bytes(int d, int n_cells) {
+  return lloyd_probe_supported(d, 1, n_cells) ? lloyd::probe_prepared_layout(d, n_cells).total : 0;
+}
+int lloyd_probe_prepare(const float* centroids, int d, int n_cells, char* prepared, hipStream_t st) {
+  const lloyd::ProbePrepared C = lloyd::probe_prepared_layout(d, n_cells);
+  switch (C.KS) {
+    case 2: return lloyd::run_probe_prepare<2>(centroids, d, n_cells, prepared, C, st);
+    case 4: return lloyd::run_probe_prepare<4>(centroids, d, n_cells, prepared, C, st);
+    default: return lloyd::run_probe_prepare<8>(centroids, d, n_cells, prepared, C, st);
+  }
+}
+int lloyd_probe_sims(const float* query, const float* centroids, const void* prepared, int d, int nq, int n_cells,
+                     char* ws, ProbeFastBuffers* out, hipStream_t st) {
+  const lloyd::ProbeLayout L = lloyd::probe_layout(d, nq, n_cells);
+  const char* prep = reinterpret_cast<const char*>(prepared);
+  if (!prep) {  // no prepared block: prepare into the workspace, for this call
+    int rc = lloyd_probe_prepare(centroids, d, n_cells, ws + L.prepared_off, st);
+    if (rc) return rc;
+    prep = ws + L.prepared_off;
+  }
+  switch (L.KS) {
+    case 2: return lloyd::run_probe_sims<2>(query, prep, d, nq, n_cells, ws, L, out, st);
+    case 4: return lloyd::run_probe_sims<4>(query, prep, d, nq, n_cells, ws, L, out, st);
+    default: return lloyd::run_probe_sims<8>(query, prep, d, nq, n_cells, ws, L, out, st);
+  }
+}
 int lloyd_assign_supported(int d, int64_t m, int n, int route) {
   if (!(d >= 1 && d <= 128 && n >= 1 && n <= (1 << 24) && m >= 1 && m < (1LL << 31))) return 0;
   if (TPQ_AB_ENV("TPQ_COARSE_ASSIGN_OLD")) return 0;  // (A/B: the two-piece bf16 selection of assign_fast.hip)

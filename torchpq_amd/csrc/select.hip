@@ -4,6 +4,7 @@
 // (torchpq/kernels/cuda/top1_select.cu:542, top32_select.cu:484-636, topk_select.cu:662-805,
 // dispatch torchpq/fn/Topk.py:43-67): one 64-lane wave per row, register top-k (wave_topk.h).
 #include "common.h"
+#include "probe_fast.h"
 #include "wave_topk.h"
 
 namespace tpq {
@@ -34,6 +35,10 @@ struct ProbeEpilogue {
   int64_t* n_probe_list;          // [rows]
   float inv_t;                    // 1 / temperature; <= 0: n_probe_list = k
 };
+
+template <int R>
+__device__ __forceinline__ void write_row(const WaveTopK<R>& top, float* __restrict__ vals, int64_t* __restrict__ idx,
+                                          int row, int k, const ProbeEpilogue& pe);
 
 // one wave selects row `row` (its values at xr[0 .. cols), global memory or LDS) -- the body of
 // topk_select_kernel and of probe_small_kernel
@@ -121,6 +126,17 @@ __device__ __forceinline__ void select_row(float* qvw, int* qiw, const float* xr
     }
   }
   sel.flush();
+  write_row<R>(sel.top, vals, idx, row, k, pe);
+}
+
+// the selected row: values, columns and -- coarse probe -- the cells' extents and the probe count
+template <int R>
+__device__ __forceinline__ void write_row(const WaveTopK<R>& top, float* __restrict__ vals, int64_t* __restrict__ idx,
+                                          int row, int k, const ProbeEpilogue& pe) {
+  const int lane = lane_id();
+  struct {
+    const WaveTopK<R>& top;
+  } sel{top};
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int e = r * 64 + lane;
@@ -185,6 +201,135 @@ __global__ __launch_bounds__(kSelWaves * 64) void topk_select_kernel(const float
   const int row = blockIdx.x * kSelWaves + wave;
   if (row >= rows) return;
   select_row<R>(qv + wave * 64, qi + wave * 64, x + (int64_t)row * cols, a2, b2, vals, idx, row, cols, k, pe, gf);
+}
+
+// The coarse step's row select on FAST similarities (probe_fast.h): one wave per query.
+//   1. the k best fast values of the row, kept with a margin: everything within `band` = 2 delta' of the running
+//      k-th best is admitted and the list holds 64 R > k entries (the group filter works on fast values too: a group
+//      is read when its maximum reaches the k-th largest group maximum minus the band);
+//   2. every list entry within the band of the k-th best fast value is a CANDIDATE: the exact top-k is among them
+//      (|f' - e'| <= delta' for every cell).  A lane evaluates its candidate with the fp32 kernels' own arithmetic --
+//      acc = fma chain over ascending k of C[k][c] x[k], v = ((2 acc) - |x|^2) - |C|^2 -- from the centroid's row copy;
+//   3. the candidates are re-ranked by (exact value desc, cell asc) and the best k written: coarse_sims_kernel +
+//      topk_select_kernel's output, bit for bit.
+// A list full of candidates (an entry may have been evicted), or band = +inf (queries / centroids beyond the fp16 scale):
+// the wave evaluates ALL cells of its query exactly -- slow, and normally never taken.
+template <int R>
+__global__ __launch_bounds__(kSelWaves * 64) void probe_select_fast_kernel(ProbeFastBuffers fb, const float* __restrict__ x,
+                                                                          float* __restrict__ vals,
+                                                                          int64_t* __restrict__ idx, int d, int nq,
+                                                                          int n_cells, int k, ProbeEpilogue pe) {
+  __shared__ float qv[kSelWaves * 64];
+  __shared__ int qi[kSelWaves * 64];
+  __shared__ float xq_all[kSelWaves * 128];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int row = blockIdx.x * kSelWaves + wave;
+  if (row >= nq) return;
+  float* xq = xq_all + wave * 128;
+  for (int t = lane; t < d; t += 64) xq[t] = x[(int64_t)t * nq + row];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  float q2 = 0.f;
+  for (int t = 0; t < d; ++t) q2 = fmaf(xq[t], xq[t], q2);
+  auto exact = [&](int c) -> float {  // the fp32 kernels' value of (query, cell c)
+    const float4* __restrict__ cr = reinterpret_cast<const float4*>(fb.ct + (int64_t)c * d);
+    float acc = 0.f;
+    int t = 0;
+    for (; t + 16 <= d; t += 16) {
+      float4 y[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) y[u] = cr[(t >> 2) + u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc = fmaf(y[u].x, xq[t + 4 * u], acc);
+        acc = fmaf(y[u].y, xq[t + 4 * u + 1], acc);
+        acc = fmaf(y[u].z, xq[t + 4 * u + 2], acc);
+        acc = fmaf(y[u].w, xq[t + 4 * u + 3], acc);
+      }
+    }
+    for (; t < d; ++t) acc = fmaf(fb.ct[(int64_t)c * d + t], xq[t], acc);
+    float v = 2.f * acc;
+    v = v - q2;
+    v = v - fb.c2[c];
+    return v + 0.0f;
+  };
+  const float band = fb.band[row];
+  WaveTopK<R> ex;
+  bool slow = !(band < INFINITY);
+  if (!slow) {
+    WaveSelector<R> sel;
+    sel.init(qv + wave * 64, qi + wave * 64, k);
+    sel.margin = band;
+    const float* __restrict__ xr = fb.sims + (int64_t)row * n_cells;
+    const float* __restrict__ gm = fb.gmax + (int64_t)row * fb.n_groups;
+    // phase 1: the k-th largest group maximum (a lower bound of the k-th largest fast value)
+    for (int base = 0; base < fb.n_groups; base += 64) {
+      const int g = base + lane;
+      const float v = g < fb.n_groups ? gm[g] + 0.0f : -INFINITY;
+      sel.push(g < fb.n_groups && (v >= sel.tau - band), v, g);
+    }
+    sel.flush();
+    const float tau0 = sel.top.kth_value(k) - band;  // -inf while there are fewer than k groups
+    sel.init(qv + wave * 64, qi + wave * 64, k);
+    sel.margin = band;
+    // phase 2: the groups that can hold a candidate, four (eight loads) at a time
+    for (int base = 0; base < fb.n_groups; base += 64) {
+      const int g = base + lane;
+      const bool hot = g < fb.n_groups && (gm[g] >= tau0);
+      unsigned long long mask = __ballot(hot);
+      while (mask != 0ull) {
+        int gs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          gs[u] = -1;
+          if (mask != 0ull) {
+            gs[u] = base + (int)__builtin_ctzll(mask);
+            mask &= mask - 1ull;
+          }
+        }
+        float va[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int c = gs[u >> 1] * 128 + 64 * (u & 1) + lane;
+          va[u] = (gs[u >> 1] >= 0 && c < n_cells) ? xr[c] : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (gs[u >> 1] >= 0) {  // wave-uniform
+            const int c = gs[u >> 1] * 128 + 64 * (u & 1) + lane;
+            const float v = va[u] + 0.0f;
+            sel.push(c < n_cells && (v >= sel.tau - band), v, c);
+          }
+        }
+      }
+    }
+    sel.flush();
+    const float cut = sel.top.kth_value(k) - band;
+    const Key last = readlane_key(sel.top.k[R - 1], 63);
+    if (key_index(last) != kPadIdx && key_value(last) >= cut) slow = true;  // a full list of candidates: wave-uniform
+    if (!slow) {
+      ex.init();
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int c = key_index(sel.top.k[r]);
+        const bool want = c != kPadIdx && key_value(sel.top.k[r]) >= cut;
+        if (__ballot(want) == 0ull) break;  // sorted by fast value: nothing further down qualifies
+        const float e = want ? exact(c) : -INFINITY;
+        ex.insert_unsorted(want ? make_key(e, c) : pad_key());
+      }
+    }
+  }
+  if (slow) {  // every cell, exactly
+    WaveSelector<R> sel;
+    sel.init(qv + wave * 64, qi + wave * 64, k);
+    for (int base = 0; base < n_cells; base += 64) {
+      const int c = base + lane;
+      const float v = c < n_cells ? exact(c) : -INFINITY;
+      sel.push(c < n_cells && (v >= sel.tau), v, c);
+    }
+    sel.flush();
+    ex = sel.top;
+  }
+  write_row<R>(ex, vals, idx, row, k, pe);
 }
 
 // Small batches (tpq_ivfpq_coarse_probe, nq <= kProbeSmallMaxQ): the whole coarse step of a query in ONE
@@ -615,10 +760,62 @@ static int select_impl(const float* x, const float* a2, const float* b2, float* 
   return launch_select<16>(x, a2, b2, vals, idx, rows, cols, k, st, pe, gf);
 }
 
-extern "C" size_t tpq_ivfpq_coarse_probe_workspace_bytes(int nq, int n_cells) {
-  if (nq <= 0 || n_cells <= 0) return 0;
+// Which arithmetic selects (results are the same either way, bit for bit):
+//   TPQ_PROBE_ROUTE_AUTO   the fp16 selection pass + exact candidates from kProbeFastMinCells cells on, where the fp32
+//                          similarity GEMM dominates the coarse step; the fp32 kernels below
+//   TPQ_PROBE_ROUTE_FP32   the fp32-MFMA similarity kernels always
+//   TPQ_PROBE_ROUTE_FP16   the fp16 selection pass whenever the shape supports it (use_tensor_core=True)
+constexpr int kProbeFastMinCells = 2048;
+static bool probe_fast_route(int d, int nq, int n_cells, int n_probe, int route);
+
+static size_t probe_fp32_workspace_bytes(int nq, int n_cells) {
   // sims [nq][n_cells] + group maxima [nq][ceil(n_cells / 128)]
   return ((size_t)nq * (size_t)n_cells + (size_t)nq * (size_t)((n_cells + 127) / 128)) * sizeof(float);
+}
+extern "C" size_t tpq_ivfpq_coarse_probe_route_workspace_bytes(int d, int nq, int n_cells, int route) {
+  if (nq <= 0 || n_cells <= 0) return 0;
+  const size_t plain = probe_fp32_workspace_bytes(nq, n_cells);
+  if (route == TPQ_PROBE_ROUTE_FP32 || !lloyd_probe_supported(d, nq, n_cells)) return plain;
+  const size_t fast = lloyd_probe_workspace_bytes(d, nq, n_cells);
+  return fast > plain ? fast : plain;
+}
+extern "C" size_t tpq_ivfpq_coarse_probe_workspace_bytes(int nq, int n_cells) {
+  if (nq <= 0 || n_cells <= 0) return 0;
+  return tpq_ivfpq_coarse_probe_route_workspace_bytes(128, nq, n_cells, TPQ_PROBE_ROUTE_AUTO);  // (covers every d <= 128)
+}
+
+extern "C" size_t tpq_ivfpq_coarse_probe_prepared_bytes(int d, int n_cells) {
+  return lloyd_probe_prepared_bytes(d, n_cells);
+}
+extern "C" int tpq_ivfpq_coarse_probe_prepare(const float* centroids, int d, int n_cells, void* prepared,
+                                              size_t prepared_bytes, tpq_stream_t stream) {
+  TPQ_REQUIRE(centroids && prepared, "ivfpq_coarse_probe_prepare: null pointer");
+  const size_t need = lloyd_probe_prepared_bytes(d, n_cells);
+  if (need == 0) {
+    set_error("ivfpq_coarse_probe_prepare: shape d=%d n_cells=%d has no fp16 selection pass (d <= 128, n_cells %% 32 == 0)",
+              d, n_cells);
+    return TPQ_ERR_UNSUPPORTED;
+  }
+  TPQ_REQUIRE(prepared_bytes >= need, "ivfpq_coarse_probe_prepare: prepared block of %zu bytes needed", need);
+  return lloyd_probe_prepare(centroids, d, n_cells, reinterpret_cast<char*>(prepared), reinterpret_cast<hipStream_t>(stream));
+}
+
+static bool probe_fast_route(int d, int nq, int n_cells, int n_probe, int route) {
+  if (route == TPQ_PROBE_ROUTE_FP32 || !lloyd_probe_supported(d, nq, n_cells)) return false;
+  if (n_probe + 16 > 1024) return false;  // (the candidate list: 64 R >= n_probe + 16 entries, R <= 16)
+  if (route == TPQ_PROBE_ROUTE_FP16) return true;
+  // (beyond 112 probes the candidate list takes four registers per lane and the fast select's folds cost more than
+  // the fp32 GEMM saves: 16 384 cells, 128 probes: 1.15 ms against 0.83; 64 probes: 0.38 against 0.67)
+  return n_cells >= kProbeFastMinCells && nq > kProbeSmallMaxQ && n_probe <= 112;
+}
+
+template <int R>
+static int launch_probe_fast(const ProbeFastBuffers& fb, const float* x, float* vals, int64_t* idx, int d, int nq,
+                             int n_cells, int k, const ProbeEpilogue& pe, hipStream_t st) {
+  hipLaunchKernelGGL(probe_select_fast_kernel<R>, dim3((nq + kSelWaves - 1) / kSelWaves), dim3(kSelWaves * 64), 0, st,
+                     fb, x, vals, idx, d, nq, n_cells, k, pe);
+  TPQ_LAUNCH_CHECK("probe_select_fast_kernel");
+  return TPQ_OK;
 }
 
 extern "C" int tpq_ivfpq_coarse_probe(const float* query, const float* centroids,
@@ -628,6 +825,20 @@ extern "C" int tpq_ivfpq_coarse_probe(const float* query, const float* centroids
                                       int n_cells, int n_probe, float smart_temperature,
                                       void* workspace, size_t workspace_bytes,
                                       tpq_stream_t stream) {
+  return tpq_ivfpq_coarse_probe_route(query, centroids, cell_start_tbl, cell_size_tbl, topk_sims, cells, cell_start,
+                                      cell_size, n_probe_list, d, nq, n_cells, n_probe, smart_temperature,
+                                      TPQ_PROBE_ROUTE_AUTO, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int tpq_ivfpq_coarse_probe_route(const float* query, const float* centroids,
+                                            const int64_t* cell_start_tbl, const int64_t* cell_size_tbl,
+                                            float* topk_sims, int64_t* cells, int64_t* cell_start,
+                                            int64_t* cell_size, int64_t* n_probe_list, int d, int nq,
+                                            int n_cells, int n_probe, float smart_temperature, int route,
+                                            const void* prepared, void* workspace, size_t workspace_bytes,
+                                            tpq_stream_t stream) {
+  TPQ_REQUIRE(route == TPQ_PROBE_ROUTE_AUTO || route == TPQ_PROBE_ROUTE_FP32 || route == TPQ_PROBE_ROUTE_FP16,
+              "ivfpq_coarse_probe: bad route %d", route);
   TPQ_REQUIRE(query && centroids && cell_start_tbl && cell_size_tbl && topk_sims && cells &&
                   cell_start && cell_size && n_probe_list,
               "ivfpq_coarse_probe: null pointer argument");
@@ -636,7 +847,7 @@ extern "C" int tpq_ivfpq_coarse_probe(const float* query, const float* centroids
   TPQ_REQUIRE(n_probe >= 1 && n_probe <= n_cells && n_probe <= 1024,
               "ivfpq_coarse_probe: n_probe=%d out of range (n_cells=%d, max 1024)", n_probe, n_cells);
   if (nq == 0) return TPQ_OK;
-  const size_t need = tpq_ivfpq_coarse_probe_workspace_bytes(nq, n_cells);
+  const size_t need = tpq_ivfpq_coarse_probe_route_workspace_bytes(d, nq, n_cells, route);
   if (!workspace || workspace_bytes < need) {
     set_error("ivfpq_coarse_probe: workspace too small (%zu < %zu)", workspace_bytes, need);
     return TPQ_ERR_WORKSPACE;
@@ -644,6 +855,18 @@ extern "C" int tpq_ivfpq_coarse_probe(const float* query, const float* centroids
   float* sims = reinterpret_cast<float*>(workspace);
   ProbeEpilogue pe{cell_start_tbl, cell_size_tbl, cell_start, cell_size, n_probe_list,
                    smart_temperature > 0.f ? 1.0f / smart_temperature : 0.f};
+  if (probe_fast_route(d, nq, n_cells, n_probe, route)) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ProbeFastBuffers fb;
+    int rc = lloyd_probe_sims(query, centroids, prepared, d, nq, n_cells, reinterpret_cast<char*>(workspace), &fb, st);
+    if (rc) return rc;
+    const int r = (n_probe + 16 + 63) / 64;
+    if (r <= 1) return launch_probe_fast<1>(fb, query, topk_sims, cells, d, nq, n_cells, n_probe, pe, st);
+    if (r <= 2) return launch_probe_fast<2>(fb, query, topk_sims, cells, d, nq, n_cells, n_probe, pe, st);
+    if (r <= 4) return launch_probe_fast<4>(fb, query, topk_sims, cells, d, nq, n_cells, n_probe, pe, st);
+    if (r <= 8) return launch_probe_fast<8>(fb, query, topk_sims, cells, d, nq, n_cells, n_probe, pe, st);
+    return launch_probe_fast<16>(fb, query, topk_sims, cells, d, nq, n_cells, n_probe, pe, st);
+  }
   if (nq <= kProbeSmallMaxQ && n_cells <= kProbeSmallMaxCells && d <= kProbeSmallMaxD &&
       (long long)n_cells * d <= (1 << 20)) {  // one launch: sims row in LDS + select, one block per query
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

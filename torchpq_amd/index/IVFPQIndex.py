@@ -91,12 +91,14 @@ class IVFPQIndex(CellContainer):
 
     @use_tensor_core.setter
     def use_tensor_core(self, value):
+        """True: the coarse step SELECTS on the fp16 matrix cores wherever the shape allows it (d <= 128) and
+        gives every candidate cell the fp32 kernel's own similarity -- the cells, their order and the
+        similarities are unchanged, bit for bit (the reference's knob, :98-125, trades accuracy for the speed).
+        False (default): the library's thresholds decide (the same pass from 2 048 cells on)."""
         assert type(value) is bool
         assert self.use_cublas
-        # fp16 matrix-core coarse GEMM breaks the 1e-4 distance tolerance; fp32 is always used
-        self._use_tensor_core = False
-        if value:
-            self.print_message("warning: reduced-precision coarse GEMM is not used on MI355X", 1)
+        self._use_tensor_core = value
+        self._coarse_probe.route = "fp16" if value else "auto"
 
     @property
     def fp16_scale_mode(self):
@@ -368,9 +370,18 @@ class IVFPQIndex(CellContainer):
             smart = self.use_smart_probing and self.n_probe > 1
             sims, cells, cs, sz, npl = self._coarse_probe(
                 x, self.vq_codec.codebook, self._cell_start, self._cell_size, self.n_probe,
-                self.smart_probing_temperature if smart else None)
+                self.smart_probing_temperature if smart else None, prepared=self._probe_prepared())
             return sims, cells, npl, (cs, sz)
         return (*self.probe(x), None)
+
+    def _probe_prepared(self):
+        """the coarse codebook's share of the fp16 selection pass, rebuilt when the codebook changes"""
+        cb = self.vq_codec.codebook
+        key = (cb.data_ptr(), tuple(cb.shape), util.tensor_version(cb))
+        cached = getattr(self, "_probe_prep_cache", None)
+        if cached is None or cached[0] != key or cb.is_inference():
+            self._probe_prep_cache = cached = (key, self._coarse_probe.prepare(cb))
+        return cached[1]
 
     def probe(self, x):
         """Coarse step: (topk_sims, cells [n_query, n_probe], n_probe_list [n_query])."""

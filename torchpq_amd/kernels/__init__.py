@@ -479,7 +479,34 @@ class CoarseProbeHip:
     """The coarse step of IVFPQIndex.search in one call (tpq_ivfpq_coarse_probe): sims on the fp32
     matrix cores, row top-n_probe, list extents of the chosen cells, per-query probe count."""
 
-    def __call__(self, query, centroids, cell_start, cell_size, n_probe, smart_temperature=None):
+    ROUTES = {"auto": _lib.PROBE_ROUTE_AUTO, "fp32": _lib.PROBE_ROUTE_FP32, "fp16": _lib.PROBE_ROUTE_FP16}
+
+    def __init__(self, route="auto"):
+        """route: which arithmetic SELECTS ("auto": the library's thresholds; "fp32": the fp32-MFMA kernels;
+        "fp16": the fp16 selection pass + exact candidates wherever the shape allows) -- the result is the
+        same, bit for bit, on every route (tpq_ivfpq_coarse_probe_route)"""
+        assert route in self.ROUTES
+        self.route = route
+
+    @staticmethod
+    def prepare(centroids):
+        """the centroid-only part of the fp16 selection pass (tpq_ivfpq_coarse_probe_prepare), or None when the
+        shape has none: a uint8 tensor to pass as `prepared` for as long as `centroids` does not change"""
+        d, n_cells = centroids.shape
+        assert centroids.dtype == torch.float32
+        centroids = centroids.contiguous()
+        require_gpu(centroids)
+        lib = load()
+        nbytes = lib.tpq_ivfpq_coarse_probe_prepared_bytes(d, n_cells)
+        if nbytes == 0:
+            return None
+        out = torch.empty(nbytes, device=centroids.device, dtype=torch.uint8)
+        with torch.cuda.device(centroids.device):
+            check(lib.tpq_ivfpq_coarse_probe_prepare(ptr(centroids), d, n_cells, ptr(out), nbytes,
+                                                     stream_ptr(centroids.device)), "tpq_ivfpq_coarse_probe_prepare")
+        return out
+
+    def __call__(self, query, centroids, cell_start, cell_size, n_probe, smart_temperature=None, prepared=None):
         """query [d, n_query] f32, centroids [d, n_cells] f32, cell_start / cell_size [n_cells] i64
         -> (topk_sims [n_query, n_probe] f32, cells, cell_start, cell_size [n_query, n_probe] i64,
             n_probe_list [n_query] i64)"""
@@ -501,14 +528,15 @@ class CoarseProbeHip:
         if nq == 0:
             return sims, cells, cs, sz, npl
         lib = load()
-        ws_bytes = lib.tpq_ivfpq_coarse_probe_workspace_bytes(nq, n_cells)
+        route = self.ROUTES[self.route]
+        ws_bytes = lib.tpq_ivfpq_coarse_probe_route_workspace_bytes(d, nq, n_cells, route)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
         t = float(smart_temperature) if smart_temperature else 0.0
         with torch.cuda.device(dev):
-            check(lib.tpq_ivfpq_coarse_probe(
+            check(lib.tpq_ivfpq_coarse_probe_route(
                 ptr(query), ptr(centroids), ptr(cell_start), ptr(cell_size), ptr(sims), ptr(cells),
-                ptr(cs), ptr(sz), ptr(npl), d, nq, n_cells, n_probe, t, ptr(ws), ws_bytes,
-                stream_ptr(dev)), "tpq_ivfpq_coarse_probe")
+                ptr(cs), ptr(sz), ptr(npl), d, nq, n_cells, n_probe, t, route, ptr(prepared), ptr(ws), ws_bytes,
+                stream_ptr(dev)), "tpq_ivfpq_coarse_probe_route")
         return sims, cells, cs, sz, npl
 
 
