@@ -81,7 +81,9 @@ extern "C" size_t tpq_ivfpq_scan_workspace_bytes(int nq, int k, int n_split, int
   if (n_split < 1) n_split = 1;
   int R = list_regs_packed(k) > list_regs(k) ? list_regs_packed(k) : list_regs(k);
   if (R > 16) R = 16;
-  return ws_bytes_for(nq, R, n_split * packed_waves(m));  // covers both kernels
+  const size_t lists = ws_bytes_for(nq, R, n_split * packed_waves(m));  // covers both kernels
+  const size_t pools = list_regs_packed(k) >= 16 ? pool_ws_bytes(nq, k, n_split * packed_waves(m)) : 0;  // pool mode
+  return lists > pools ? lists : pools;
 }
 
 static int run_ref(ScanArgs a, void* workspace, size_t workspace_bytes, tpq_stream_t stream);
@@ -250,6 +252,37 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
     return dispatch_ref(a, Rr, st);
   }
   const int n_lists = n_split * packed_waves(m);
+  // (measured against the sorted lists of the three-launch path, C2 shape, 10 000 queries: m = 64, k = 600 / 1000:
+  // 6.1 / 6.9 ms against 7.1 / 8.3; m = 120 (1 000 queries), k = 1000: 2.0 against 3.4 -- and k = 600: 1.9 against 1.6;
+  // m = 16, 32: within 2 %; k = 300, 500 at m = 64: 4.1 / 4.5 against 3.6 / 4.0)
+  if (!ra && R >= 16 && (packed_waves(m) < 16 || k > 768) && fuse_enabled()) {
+    // the largest k, plain PQ: pool mode (scan_device.h) -- threshold lists of ceil(k / waves) entries, unsorted pools,
+    // one ranking kernel per query; flagged queries (a pool or the ranking buffer overflowed) redone exactly
+    // (the ranking kernel takes a query's lists into LDS: fewer workgroups per query when they would not fit)
+    if (a.n_split > pool_max_split(m, k)) a.n_split = pool_max_split(m, k);
+    const int n_lists_p = a.n_split * packed_waves(m);
+    rc = need_ws(workspace, workspace_bytes, pool_ws_bytes(nq, k, n_lists_p), "ivfpq_scan_packed");
+    if (rc) return rc;
+    fill_ws_pool(a, workspace, n_lists_p);
+    a.epoch = fresh_epoch();
+    a.fuse = 0;
+    a.tickets = nullptr;
+    a.small_lists = 0;
+#ifdef TPQ_SCAN_PROFILE
+    a.prof = g_scan_prof;
+#endif
+    switch (m) {
+#define TPQ_CASE_M(M) case M: rc = dispatch_pool_##M(a, pool_list_regs(k, m), st); break;
+      TPQ_PACKED_M_LIST(TPQ_CASE_M)
+#undef TPQ_CASE_M
+      default: rc = TPQ_ERR_UNSUPPORTED; break;
+    }
+    if (rc) return rc;
+    ScanArgs b = a;
+    b.n_split = 1;
+    b.only_flagged = a.flags;
+    return dispatch_ref(b, list_regs(k), st);
+  }
   // registers of the per-wave lists (<= R)
   const int RL = list_regs_scan(k, m, a.max_nprobe, a.slots_hint);
   a.small_lists = RL < R ? 1 : 0;

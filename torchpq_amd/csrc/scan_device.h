@@ -39,6 +39,12 @@ struct ScanArgs {
   int* tickets;              // fused finish, n_split > 1: the CALLER's [nq] int32, zero on entry, zero on exit
   int fuse;                  // fused finish (scan_packed_kernel RM > 0): the scan workgroups write the result
   int64_t slots_hint;        // host only: expected slots scanned per query (0 = unknown), sizes the per-wave lists
+  // pool mode (k > 248, scan_packed_kernel RM < 0): per (query, split, wave) an append-only pool of pool_cap
+  // admitted candidates (keys: value image, ~address), later overwritten in place by the exact candidates
+  unsigned* pool_hi;
+  unsigned* pool_lo;
+  int* pool_cnt;             // [nq][n_lists] exact candidates the list holds after the scan kernel
+  int pool_cap;
 };
 
 #ifdef TPQ_SCAN_PROFILE
@@ -712,6 +718,15 @@ constexpr int packed_aux_bytes(int /*R*/, int M) {
 // per query), which writes the result; an overflowing candidate band is redone, exactly, by that same
 // workgroup.  One launch instead of three (scan, scan_merge_refine_kernel, the flagged redo): at one query
 // the two extra launches were 25 of 64 us.  RM = registers of the merged list (list_regs_packed(k)).
+//
+// RM < 0 ("pool mode", k > 504, plain PQ; scan.hip holds the rule): folding 64 candidates into a sorted list of k + 8 (or even 2k / NW)
+// entries is what made large k slow -- at k = 1000 the tile loop ran 275 us per query against 106 at k = 100.
+// Here the sorted per-wave list (R registers) only serves the ADMISSION THRESHOLD: it holds the wave's
+// ceil(k / NW) best (bound (b) below needs no more), and every admitted candidate is also appended to an
+// unsorted pool in the workspace.  Nothing is ever evicted from a pool, so at the end of the query the counting
+// rounds run over the pools, the entries at or above the cut are compacted through the wave's queue, re-evaluated
+// exactly and written back -- unsorted; scan_pool_merge_kernel ranks a query's ~k exact candidates in LDS.
+// A pool that fills up flags the query for the exact kernel.
 template <int R, int M, bool RES, int RM = 0>
 __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(ScanArgs a,
                                                                                     ResidualArgs ra,
@@ -804,6 +819,11 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
   WaveSelector<R> sel;
   sel.init(qv_all + wave * 64, qi_all + wave * 64, a.k);
   sel.margin = delta2;
+  typename WaveSelector<R>::Pool pool{nullptr, nullptr, 0, 0};
+  if constexpr (RM < 0) {
+    const int64_t o = (((int64_t)q * a.n_split + part) * NW + wave) * a.pool_cap;
+    pool = {a.pool_hi + o, a.pool_lo + o, 0, a.pool_cap};
+  }
 
   const int total_tiles = tab.tile_begin[n_probe];
   const int t_begin = (int)(((int64_t)total_tiles * part) / a.n_split);
@@ -859,7 +879,8 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
       refresh_tau();
       const float tau_before = sel.tau;
       const int flushes_before = sel.n_flush;
-      sel.push(live && (v >= sel.tau - delta2), v, t.s);
+      if constexpr (RM < 0) sel.push_pool(pool, live && (v >= sel.tau - delta2), v, t.s);
+      else sel.push(live && (v >= sel.tau - delta2), v, t.s);
       if (sel.n_flush != flushes_before) publish(tau_before);
     };
 
@@ -962,7 +983,8 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
       for (int u = 0; u < S; ++u) {
         const float tau_before = sel.tau;
         const int flushes_before = sel.n_flush;
-        sel.push(live[u] && (v[u] >= sel.tau - delta2), v[u], t.s + 64 * u);
+        if constexpr (RM < 0) sel.push_pool(pool, live[u] && (v[u] >= sel.tau - delta2), v[u], t.s + 64 * u);
+        else sel.push(live[u] && (v[u] >= sel.tau - delta2), v[u], t.s + 64 * u);
         if (sel.n_flush != flushes_before) publish(tau_before);
       }
     };
@@ -1026,6 +1048,141 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
     publish(tau_before);
   }
   TPQ_PROF(a, blockIdx.x, 5);
+
+  if constexpr (RM < 0) {
+    // ---- pool mode: cut, compaction, exact values ----
+    static_assert(!RES, "pool mode serves plain PQ");
+    __syncthreads();  // every wave has published its quantile
+    TPQ_PROF(a, blockIdx.x, 6);
+    float shared_tau;
+    {
+      float qmin = reinterpret_cast<volatile float*>(wave_q)[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) qmin = fminf(qmin, reinterpret_cast<volatile float*>(wave_q)[w]);
+      shared_tau = fmaxf(qmin, key2f(*reinterpret_cast<volatile unsigned*>(tau_key)));
+    }
+    constexpr int PR = RM == -1 ? 16 : 32;  // pool registers: pool_cap = 64 PR entries (1024 / 2048)
+    const bool overflow = pool.n > pool.cap;
+    const int n_use = overflow ? 0 : pool.n;
+    unsigned ph[PR], pl[PR];
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+      ph[r] = 0u;
+      pl[r] = 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+      if (r * 64 >= n_use) break;  // wave-uniform
+      const int e = r * 64 + lane;
+      const bool valid = e < n_use;
+      // (agent-scope loads: the wave reads back what it stored itself, past its L1)
+      ph[r] = valid ? __hip_atomic_load(pool.hi + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      pl[r] = valid ? __hip_atomic_load(pool.lo + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    }
+    // counting rounds over the pools: invariant "at least k pool entries of the workgroup are >= lo"
+    unsigned lo = f2key(shared_tau), hi = 0xFFFFFFFFu;
+    {
+      unsigned* cnt = reinterpret_cast<unsigned*>(qv_all);  // [3][NW][NW] (the queues are empty)
+      auto count_ge = [&](unsigned t) -> unsigned {
+        unsigned c = 0;
+#pragma unroll
+        for (int r = 0; r < PR; ++r) {
+          if (r * 64 >= n_use) break;  // wave-uniform
+          c += (unsigned)__popcll(__ballot(ph[r] >= t && ph[r] != 0u));
+        }
+        return c;
+      };
+      auto wave_max = [&](unsigned x) -> unsigned {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+          const unsigned o = (unsigned)__shfl_xor((int)x, d, 64);
+          x = o > x ? o : x;
+        }
+        return x;
+      };
+#pragma unroll 1
+      for (int round = 0; round < 3; ++round) {
+        unsigned my_t = 0;
+        if (round == 0) {
+          if (lane < NW) my_t = f2key(reinterpret_cast<volatile float*>(wave_q)[lane]);
+        } else {
+          const unsigned long long span = (unsigned long long)(hi - lo);
+          my_t = lo + (unsigned)((span * (unsigned)(lane + 1)) / (unsigned)(NW + 1));
+        }
+        unsigned mine = 0;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          const unsigned c = count_ge((unsigned)__builtin_amdgcn_readlane((int)my_t, j));
+          mine = (lane == j) ? c : mine;
+        }
+        unsigned* cr = cnt + (round % 2) * NW * NW;
+        if (lane < NW) cr[wave * NW + lane] = mine;
+        __syncthreads();
+        unsigned total = 0;
+        if (lane < NW) {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) total += cr[w * NW + lane];
+        }
+        const bool in = lane < NW;
+        const bool ok = in && total >= (unsigned)a.k;
+        const unsigned best_ok = wave_max(ok ? my_t : 0u);
+        const unsigned best_no = ~wave_max((in && !ok) ? ~my_t : 0u);
+        lo = best_ok > lo ? best_ok : lo;
+        hi = best_no < hi ? best_no : hi;
+        if (hi == 0xFFFFFFFFu || hi <= lo) break;  // workgroup-uniform
+      }
+    }
+    __syncthreads();  // the counts lay over the queues
+    TPQ_PROF(a, blockIdx.x, 7);
+    const float cut = fmaxf(shared_tau, key2f(lo)) - delta2;
+    constexpr int RR = refine_rows(M);
+    constexpr int RX = NW == 4 ? 8 : 4;  // the wave's exact candidates, sorted: ~2 ceil(k / NW) entries at k = 1000
+    uint32_t* scratch = scratch_all + wave * RR * (M / 4 + 1);
+    int* qi = qi_all + wave * 64;
+    int qn = 0, n_out = 0;
+    WaveTopK<RX> ex;
+    ex.init();
+    auto drain = [&]() {  // the (<= 64) queued addresses: exact values, folded into the wave's sorted list
+      if (qn == 0) return;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      const bool act = lane < qn;
+      const int idx = act ? qi[lane] : 0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      typename L::chunk_t cw[L::kChunks] = {};
+      if (act) L::load(a.packed, a.n_slots, idx, cw);
+      float e = -INFINITY;
+#pragma unroll 1
+      for (int pass = 0; pass * RR < qn; ++pass) {
+        const bool mine = act && ((lane / RR) == pass);
+        const float ep = exact_from_chunks<M>(cw, idx, mine, scratch, lane % RR, LdsLut<M>{lut});
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        e = mine ? ep : e;
+      }
+      ex.insert_unsorted(act ? make_key(e + 0.0f, idx) : pad_key());
+      n_out += qn;
+      qn = 0;
+    };
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+      if (r * 64 >= n_use) break;  // wave-uniform
+      const bool want = ph[r] != 0u && key2f(ph[r]) >= cut;
+      const unsigned long long wmask = __ballot(want);
+      if (wmask == 0ull) continue;
+      const int n = __popcll(wmask);
+      if (qn + n > 64) drain();
+      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(wmask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wmask, 0));
+      if (want) qi[qn + rank] = (int)~pl[r];
+      qn += n;
+    }
+    drain();
+    // the sorted list goes where the pool was (its entries are all in registers by now); more candidates than
+    // the list holds, or a pool that filled up: the exact kernel redoes the query
+    store_list<RX>(ex, reinterpret_cast<float*>(pool.hi), reinterpret_cast<int*>(pool.lo));
+    if (lane == 0 && (overflow || n_out > 64 * RX)) a.flags[q] = a.epoch;
+    TPQ_PROF(a, blockIdx.x, 8);
+    TPQ_PROF(a, blockIdx.x, 9);
+    return;
+  }
 
   // End of query, per wave and without any barrier: re-evaluate the surviving candidates of
   // this wave's list exactly (ascending j, LUT still in LDS), re-rank them by exact value and
@@ -1395,6 +1552,55 @@ __global__ __launch_bounds__(512) void scan_merge_refine_kernel(ScanArgs a) {
   if (wave == 0) finalize_and_write<R, RES>(a, q, top, a.ws_delta[q]);
 }
 
+// pool mode, phase 2: the query's n_lists sorted lists of exact candidates (64 RX entries each, pads last) are
+// merged BY RANK in LDS (rank_merge: fixed-step binary searches, eight lists in flight per lane) and the best k
+// written out.  A flagged query (a pool or a list overflowed) is left to the exact kernel.
+constexpr int kPoolMergeThreads = 512;
+template <int NW>
+__global__ __launch_bounds__(kPoolMergeThreads) void scan_pool_merge_kernel(ScanArgs a) {
+  constexpr int RX = NW == 4 ? 8 : 4, LEN = 64 * RX;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int q = blockIdx.x;
+  if (a.flags[q] == a.epoch) return;
+  const int L = a.n_split * NW;
+  unsigned* mhi = reinterpret_cast<unsigned*>(smem);
+  unsigned* mlo = mhi + L * LEN;
+  unsigned* ohi = mlo + L * LEN;
+  const int kcap = (a.k + 63) / 64 * 64;
+  unsigned* olo = ohi + kcap;
+  for (int l = threadIdx.x >> 6; l < L; l += kPoolMergeThreads / 64) {
+    const int64_t o = ((int64_t)q * L + l) * a.pool_cap;
+    for (int e = threadIdx.x & 63; e < LEN; e += 64) {
+      mhi[l * LEN + e] = a.pool_hi[o + e];
+      mlo[l * LEN + e] = a.pool_lo[o + e];
+    }
+  }
+  const Key pad = pad_key();
+  for (int i = threadIdx.x; i < kcap; i += kPoolMergeThreads) {
+    ohi[i] = pad.hi;
+    olo[i] = pad.lo;
+  }
+  __syncthreads();
+  rank_merge<LEN>(mhi, mlo, L, ohi, olo, kcap, (int)threadIdx.x, kPoolMergeThreads);
+  __syncthreads();
+  for (int e = threadIdx.x; e < a.k; e += kPoolMergeThreads) {
+    const Key kk{ohi[e], olo[e]};
+    const int idx = key_index(kk);
+    const bool p = idx == kPadIdx;
+    const int64_t o = (int64_t)q * a.k + e;
+    a.out_vals[o] = p ? -INFINITY : key_value(kk);
+    a.out_addr[o] = p ? -1 : (int64_t)idx;
+    if (a.out_ids) a.out_ids[o] = p ? -1 : a.address2id[idx];
+  }
+}
+// splits per query the ranking kernel's LDS (64 KiB) can take
+static int pool_max_split(int m, int k) {
+  const int nw = packed_waves(m), len = 64 * (nw == 4 ? 8 : 4);
+  const int kcap = (k + 63) / 64 * 64;
+  int s = (int)((65536 - (size_t)kcap * 8) / ((size_t)nw * len * 8));
+  return s < 1 ? 1 : s;
+}
+
 // ---- host side -----------------------------------------------------------------------------
 
 static int pow2_ceil(int r) {
@@ -1432,6 +1638,14 @@ static int list_regs_scan(int k, int m, int max_nprobe, int64_t slots_hint) {
   return rl;
 }
 
+// pool mode (k > 248): registers of the threshold list (the wave's ceil(k / NW) best) and entries per pool
+static int pool_list_regs(int k, int m) {
+  const int nw = packed_waves(m);
+  return pow2_ceil(((k + nw - 1) / nw + 63) / 64);
+}
+static int pool_capacity(int k) { return k <= 512 ? 1024 : 2048; }  // (16 / 32 registers per lane at read-back)
+static size_t pool_ws_bytes(int nq, int k, int n_lists);
+
 static size_t scan_lds_bytes_ref(int m, int R, int max_nprobe, int fused_floats) {
   const int lut_bytes = m * 1024;
   const int list_bytes = kScanWaves * R * 64 * 8;
@@ -1462,7 +1676,8 @@ static bool fuse_fits(int m, int RM) {
 #define TPQ_PACKED_M_LIST(X) \
   X(4) X(8) X(12) X(16) X(20) X(24) X(28) X(32) X(40) X(48) X(56) X(64) X(96) X(120) X(128)
 #define TPQ_DECLARE_PACKED(M) \
-  int dispatch_packed_##M(const ScanArgs& a, const ResidualArgs* ra, int RL, int R, hipStream_t st);
+  int dispatch_packed_##M(const ScanArgs& a, const ResidualArgs* ra, int RL, int R, hipStream_t st); \
+  int dispatch_pool_##M(const ScanArgs& a, int RL, hipStream_t st);
 TPQ_PACKED_M_LIST(TPQ_DECLARE_PACKED)
 #undef TPQ_DECLARE_PACKED
 
@@ -1483,6 +1698,23 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // kernel, only when n_split > 1) or n_split * waves-per-workgroup (packed kernel, always)
 static size_t ws_bytes_for(int nq, int R, int n_lists) {
   return 2 * align256((size_t)nq * 4) + (size_t)nq * n_lists * R * 64 * 8;
+}
+
+// pool mode workspace: [flags][delta][pool hi nq*n_lists*cap][pool lo ...][counts nq*n_lists]
+static size_t pool_ws_bytes(int nq, int k, int n_lists) {
+  return 2 * align256((size_t)nq * 4) + (size_t)nq * n_lists * pool_capacity(k) * 8 +
+         align256((size_t)nq * n_lists * 4);
+}
+static void fill_ws_pool(ScanArgs& a, void* workspace, int n_lists) {
+  char* p = reinterpret_cast<char*>(workspace);
+  a.flags = reinterpret_cast<int*>(p);
+  a.ws_delta = reinterpret_cast<float*>(p + align256((size_t)a.nq * 4));
+  char* pools = p + 2 * align256((size_t)a.nq * 4);
+  a.pool_cap = pool_capacity(a.k);
+  const size_t n = (size_t)a.nq * n_lists * a.pool_cap;
+  a.pool_hi = reinterpret_cast<unsigned*>(pools);
+  a.pool_lo = reinterpret_cast<unsigned*>(pools + n * 4);
+  a.pool_cnt = reinterpret_cast<int*>(pools + n * 8);
 }
 
 static void fill_ws(ScanArgs& a, void* workspace, int R, int n_lists) {

@@ -46,6 +46,26 @@ static int launch_packed(ScanArgs a, ResidualArgs ra, hipStream_t st) {
   return TPQ_OK;
 }
 
+// pool mode (k > 248): scan with threshold lists of RL registers + pools (RM = -1: 1 024 entries per wave, -2: 2 048),
+// then the ranking kernel
+template <int RL, int M, int RM>
+static int launch_pool(ScanArgs a, hipStream_t st) {
+  const size_t lds = scan_lds_bytes_packed(M, RL, a.max_nprobe, fused_floats_of(a), false);
+  int rc = set_lds(scan_packed_kernel<RL, M, false, RM>, lds, "scan_packed_kernel (pool mode)");
+  if (rc) return rc;
+  const float delta_rel = 1.05f * 2.0f * 5.9604645e-8f * (float)(M - 1);
+  hipLaunchKernelGGL((scan_packed_kernel<RL, M, false, RM>), dim3((unsigned)a.nq * a.n_split),
+                     dim3(packed_waves(M) * 64), lds, st, a, ResidualArgs{}, delta_rel);
+  TPQ_LAUNCH_CHECK("scan_packed_kernel (pool mode)");
+  constexpr int NW = packed_waves(M), LEN = 64 * (NW == 4 ? 8 : 4);
+  const size_t mlds = (size_t)a.n_split * NW * LEN * 8 + (size_t)((a.k + 63) / 64 * 64) * 8;
+  rc = set_lds(scan_pool_merge_kernel<NW>, mlds, "scan_pool_merge_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL((scan_pool_merge_kernel<NW>), dim3(a.nq), dim3(kPoolMergeThreads), mlds, st, a);
+  TPQ_LAUNCH_CHECK("scan_pool_merge_kernel");
+  return TPQ_OK;
+}
+
 template <int M, bool RES>
 static int dispatch_r(const ScanArgs& a, const ResidualArgs& ra, int RL, int R, hipStream_t st) {
   if (RL == R) {
@@ -68,6 +88,18 @@ static int dispatch_r(const ScanArgs& a, const ResidualArgs& ra, int RL, int R, 
 
 #define TPQ_CAT2(a, b) a##b
 #define TPQ_CAT(a, b) TPQ_CAT2(a, b)
+
+int TPQ_CAT(dispatch_pool_, TPQ_PACKED_M)(const ScanArgs& a, int RL, hipStream_t st) {
+  const bool big = a.pool_cap > 1024;
+  switch (RL) {
+    case 1: return big ? launch_pool<1, TPQ_PACKED_M, -2>(a, st) : launch_pool<1, TPQ_PACKED_M, -1>(a, st);
+    case 2: return big ? launch_pool<2, TPQ_PACKED_M, -2>(a, st) : launch_pool<2, TPQ_PACKED_M, -1>(a, st);
+    case 4: return big ? launch_pool<4, TPQ_PACKED_M, -2>(a, st) : launch_pool<4, TPQ_PACKED_M, -1>(a, st);
+    default: break;
+  }
+  set_error("scan_packed (pool mode): no instantiation for %d list registers", RL);
+  return TPQ_ERR_UNSUPPORTED;
+}
 
 int TPQ_CAT(dispatch_packed_, TPQ_PACKED_M)(const ScanArgs& a, const ResidualArgs* ra, int RL, int R,
                                             hipStream_t st) {
