@@ -9,7 +9,9 @@
  *   - all pointers are DEVICE pointers owned by the caller (torch's caching
  *     allocator in the Python host); the library never allocates, frees or
  *     keeps device memory between calls, holds no state between calls and
- *     reads no environment variable (every entry point is re-entrant);
+ *     reads no environment variable (every entry point is re-entrant; the one
+ *     third-party exception: tpq_get_ioa sorts with rocPRIM's radix sort, which
+ *     consults ROCPRIM_USE_ATOMIC_BLOCK_ID and caches the device architecture);
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*;
  *     NULL = the null stream) and never synchronises;
  *   - tensors are dense, row-major, in the reference's layouts;
