@@ -50,7 +50,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--mode", default="selection", choices=["selection", "cascade"])
+    ap.add_argument("--mode", default="selection", choices=["selection", "cascade", "probe"])
     ap.add_argument("--trace", action="store_true", help="print every case before it runs and synchronise after it")
     ap.add_argument("--only-case", type=int, default=-1, help="cascade mode: run this case alone (same random stream)")
     ap.add_argument("--big", action="store_true", help="cascade mode: up to 200 000 points x 20 000 centroids")
@@ -59,6 +59,8 @@ def main():
     dev = "cuda:0"
     if a.mode == "cascade":
         return cascade_soak(a, rng, dev)
+    if a.mode == "probe":
+        return probe_soak(a, rng, dev)
     bad, log = [], {"coarse": 0, "select": 0, "rechecked_share_max": 0.0}
     for c in range(a.cases):
         kind = KINDS[c % len(KINDS)]
@@ -84,6 +86,34 @@ def main():
         log["select"] += 1
         if not torch.equal(got, want):
             bad.append(("select", kind, l, d2, m, n2, dist, int((got != want).sum())))
+    log["mismatching_cases"] = bad
+    print(json.dumps(log))
+    sys.exit(1 if bad else 0)
+
+
+def probe_soak(a, rng, dev):
+    """the coarse step of search(): fp16 selection + exact candidates (route "fp16", prepared block or not) against the
+    fp32-MFMA route -- sims, cells, extents and probe counts must be equal, bit for bit"""
+    bad, log = [], {"cases": 0, "skipped_unsupported": 0}
+    for c in range(a.cases):
+        kind = KINDS[c % len(KINDS)]
+        d = int(rng.integers(1, 129))
+        nq = int(rng.integers(1, 3000))
+        n_cells = 32 * int(rng.integers(8, 600 if a.big else 200))
+        n_probe = int(min(n_cells, rng.choice([1, 2, 7, 16, 33, 64, 100, 128, 200, 500])))
+        A, B = make(rng, kind, d, nq, n_cells, dev)          # queries [d, nq], centroids [d, n_cells]
+        sizes = torch.randint(0, 300, (n_cells,), device=dev)
+        start = torch.cumsum(sizes + 3, 0) - sizes - 3
+        smart = 30.0 if c % 2 else None
+        want = K.CoarseProbeHip(route="fp32")(A, B, start, sizes, n_probe, smart)
+        prep = K.CoarseProbeHip.prepare(B) if c % 3 else None
+        got = K.CoarseProbeHip(route="fp16")(A, B, start, sizes, n_probe, smart, prepared=prep)
+        log["cases"] += 1
+        # rows whose similarities are NaN have no defined order on either route
+        ok = ~torch.isnan(want[0]).any(dim=1)
+        if not all(torch.equal(x[ok], y[ok]) for x, y in zip(want, got)):
+            bad.append((kind, d, nq, n_cells, n_probe, smart is not None, prep is not None,
+                        int((want[1][ok] != got[1][ok]).any(dim=1).sum())))
     log["mismatching_cases"] = bad
     print(json.dumps(log))
     sys.exit(1 if bad else 0)
