@@ -717,7 +717,10 @@ class LloydStepHip:
         maxsims, labels, new_centroids = step(centroids)
 
     labels are MaxSimHip's (fp32), bit for bit; maxsims are the selection's fast maxima (exact for
-    re-checked points); new_centroids = ComputeCentroidsHip()(data, labels, k)."""
+    re-checked points); new_centroids are the means of the labelled points summed from the fp16 pieces (h + m, two
+    ulps of fp32 per element): within ~2e-7 of the scale of ComputeCentroidsHip()(data, labels, k), not bit-equal --
+    a fit() that takes this path (MultiKMeans.lloyd_min_work / lloyd_min_iter) and one that does not agree to that
+    tolerance per iteration."""
 
     @staticmethod
     def supported(l, d, m, n):
@@ -736,7 +739,11 @@ class LloydStepHip:
         lib = load()
         nbytes = lib.tpq_lloyd_prepared_bytes(l, d, m)
         self.prepared = torch.empty(nbytes, device=data.device, dtype=torch.uint8)
-        self._ws = None
+        # the step workspace (two l x m int lists, the sums) is allocated HERE, with the prepared copy: a caller
+        # that guards the construction against torch.cuda.OutOfMemoryError (MultiKMeans.fit) then never meets one
+        # inside its Lloyd loop
+        self._ws = torch.empty(max(lib.tpq_lloyd_step_workspace_bytes(l, d, m, n), 1), device=data.device,
+                               dtype=torch.uint8)
         with torch.cuda.device(data.device):
             check(lib.tpq_lloyd_prepare(ptr(self.data), ptr(centroids0), ptr(self.prepared), nbytes, l, d, m, n,
                                         stream_ptr(data.device)), "tpq_lloyd_prepare")

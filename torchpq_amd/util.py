@@ -34,9 +34,12 @@ def check_device(tensor, *device):
 
 def tensor_version(t):
     """In-place-write counter of `t`, or None where PyTorch keeps none: tensors created under
-    torch.inference_mode() raise on `._version` ("Inference tensors do not track version counter").
-    Callers that cache on (identity, data_ptr, version) then fall back to identity + data_ptr --
-    inference tensors cannot be written in place outside inference mode anyway."""
+    torch.inference_mode() raise on `._version`.  Callers that cache on (identity, data_ptr, version) then
+    fall back to identity + data_ptr.  Inference tensors CAN be written in place inside inference mode, so the
+    library does not rely on the counter for its own mutations: load_state_dict re-registers every buffer (a new
+    tensor object), train() installs new tensors, add() / remove() / expand() bump CellContainer._codes_version
+    (which GraphedSearch snapshots).  What goes unseen is a FOREIGN in-place write to a buffer under inference
+    mode (e.g. `index._is_trained.fill_(...)`): do not do that to an index whose search is captured in a graph."""
     if t is None:
         return None
     return None if t.is_inference() else t._version
