@@ -258,8 +258,10 @@ def test_wide_codes_beyond_the_instantiated_scan_layouts(m):
 # large k (k > 248 leaves the one-launch finish; reference: fn/IVFPQTopk.py:64-104 serves k <= 1024)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m", [4, 8, 12, 16, 24, 32, 40, 64, 96, 120, 128])
-@pytest.mark.parametrize("k,n_split", [(300, 1), (500, 3), (1000, 1), (1016, 2), (249, 5)])
+@pytest.mark.parametrize("k,n_split", [(300, 1), (500, 3), (1000, 1), (1016, 2), (249, 5), (1000, 7), (700, 4)])
 def test_large_k_equals_the_oracle(K, m, k, n_split):
+    """k > 248 leaves the one-launch finish: sorted lists + merge kernel up to k = 504 (768 at m > 64), pool mode above
+    (csrc/scan_device.h; more splits than the ranking kernel's LDS takes are clamped inside the library)"""
     from test_gpu_kernels import _random_index
     rng = np.random.default_rng(m * 10007 + k)
     n_cells, nq, n_probe = 48, 7, 20
