@@ -303,3 +303,43 @@ def test_large_k_on_ascending_values(K, m, k):
     v, a = scan.topk(st, T(lut), T(is_empty), T(cs), T(sz), T(npl), n_candidates=k,
                      packed=K.PackCodesHip()(st), n_split=1)
     assert np.array_equal(N(v), ev) and np.array_equal(N(a), ea)
+
+
+# ---------------------------------------------------------------------------------------------
+# use_tensor_core: the coarse step selected on the fp16 matrix cores, through the index
+# ---------------------------------------------------------------------------------------------
+def test_use_tensor_core_changes_nothing_but_the_route():
+    """IVFPQIndex.use_tensor_core (reference: index/IVFPQIndex.py:98-125, an fp16 coarse GEMM with its errors): here
+    the knob forces the fp16 SELECTION pass; cells, similarities, probe counts and search results stay the fp32
+    route's bit for bit -- also through a captured graph, and after the codebook is replaced (the prepared block
+    follows it)"""
+    idx, sample = _build(64, 16, 2048, 80_000, seed=9)
+    idx.n_probe = 24
+    idx.use_smart_probing = True
+    xq = sample(700)
+    assert idx.use_tensor_core is False
+    idx._coarse_probe.route = "fp32"
+    want_probe = [t.clone() for t in idx.probe(xq)]
+    want = [t.clone() for t in idx.search(xq, k=10)]
+    idx.use_tensor_core = True
+    assert idx.use_tensor_core is True and idx._coarse_probe.route == "fp16"
+    for a, b in zip(want_probe, idx.probe(xq)):
+        assert torch.equal(a, b)
+    got = idx.search(xq, k=10)
+    assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
+    prepared_before = idx._probe_prepared()
+    assert prepared_before is not None and idx._probe_prepared() is prepared_before   # cached per codebook
+    g = idx.graphed_search(700, k=10)
+    gv, gi = g(xq)
+    assert torch.equal(gv, want[0]) and torch.equal(gi, want[1])
+    _check_against_oracle(idx, xq[:, :100].contiguous(), k=10, exact_cells=True)
+    # a new codebook tensor: the prepared block is rebuilt, results follow the new codebook
+    idx.vq_codec.kmeans.register_buffer("centroids", (idx.vq_codec.codebook * 1.01).contiguous())
+    assert idx._probe_prepared() is not prepared_before
+    idx._coarse_probe.route = "fp32"
+    w2 = [t.clone() for t in idx.probe(xq)]
+    idx.use_tensor_core = True
+    for a, b in zip(w2, idx.probe(xq)):
+        assert torch.equal(a, b)
+    idx.use_tensor_core = False
+    assert idx._coarse_probe.route == "auto"
