@@ -6,6 +6,9 @@
 
 namespace tpq {
 
+#ifndef TPQ_LUT_U
+#define TPQ_LUT_U 4  // fused LUT build, ds <= 2: entries (float4 groups) per thread whose codebook loads are issued together
+#endif
 constexpr int kScanWaves = 8;
 constexpr int kScanThreads = kScanWaves * 64;
 
@@ -462,7 +465,7 @@ __device__ __forceinline__ void stage_lut_blocked(const ScanArgs& a, int q, floa
     // fused table, short sub-vectors: a thread's entries come from 2 ds codebook loads each, and a plain loop
     // pays one L2 round trip per entry (8 entries per thread at m = 64: 4.6 of the 23 us a single-query
     // workgroup lives; 8.5 us when 512 workgroups stage at once).  All loads of U entries are issued first.
-    constexpr int U = 4;
+    constexpr int U = TPQ_LUT_U;
     const int ds = a.ds;
     for (int i0 = threadIdx.x; i0 < m * 64; i0 += U * n_threads) {
       float4 y[U][2];
