@@ -100,13 +100,16 @@ def test_coarse_probe_is_bit_exact(K, kind, d, nq, n_cells, n_probe, smart, rout
         assert np.array_equal(N(npl), np.full(nq, n_probe))
 
 
-@pytest.mark.parametrize("case", ["identical_cells", "nan_query", "huge_centroid", "tiny", "offset", "far_queries"])
-def test_coarse_probe_fp16_route_on_degenerate_data(K, case):
-    """the fp16 selection's exits: a candidate band that overflows its list (thousands of identical centroids),
+@pytest.mark.parametrize("n_probe", [8, 32])   # 8: the direct candidate list (2 k <= 32 groups); 32: the selector path
+@pytest.mark.parametrize("case", ["identical_cells", "nan_query", "huge_centroid", "tiny", "offset", "far_queries",
+                                  "near_ties", "mixed_norms"])
+def test_coarse_probe_fp16_route_on_degenerate_data(K, case, n_probe):
+    """the fp16 selection's exits: a candidate band that overflows its list (thousands of identical centroids: the
+    direct list overflows into the selector path, whose list overflows into the exact evaluation of every cell),
     queries / centroids the fp16 scale cannot hold (band = inf), magnitudes of 1e-18, a large common offset --
     the result is the fp32 route's, bit for bit"""
     rng = np.random.default_rng(len(case))
-    d, nq, n_cells, n_probe = 64, 400, 4096, 32
+    d, nq, n_cells = 64, 400, 4096
     x = (rng.standard_normal((d, nq)) * 3).astype(np.float32)
     c = (rng.standard_normal((d, n_cells)) * 3).astype(np.float32)
     if case == "identical_cells":
@@ -124,6 +127,11 @@ def test_coarse_probe_fp16_route_on_degenerate_data(K, case):
         c += 1.0e4
     elif case == "far_queries":      # beyond the range the centroids give the fp16 scale: those queries go exact
         x[:, ::7] *= 50.0
+    elif case == "near_ties":        # clusters of centroids closer than the fp16 rounding of the stored fast values
+        base = c[:, :n_cells // 4]
+        c = (np.repeat(base, 4, axis=1) * (1.0 + 2e-4 * rng.standard_normal((d, n_cells)))).astype(np.float32)
+    elif case == "mixed_norms":      # every query has its own power-of-two scale for the stored values
+        x *= np.exp2(rng.integers(-6, 3, nq)).astype(np.float32)[None, :]
     z = np.zeros(n_cells, np.int64)
     want = K.CoarseProbeHip(route="fp32")(T(x), T(c), T(z), T(z), n_probe, 30.0)
     tc = T(c)

@@ -209,6 +209,23 @@ constexpr int kCm = 4;  // words per sub-problem in cmax2_bits: max N, max |c|^2
 // are two whole 2-KiB runs.  (Round 3's kernel gave a lane (point, half of a k-step): 128-byte reads, 32-byte
 // interleaved writes, 2.9 TB/s over 16 GB in + 16 GB out.)  Every element is seen here, so this is also where a
 // non-finite value, or one beyond the range the (sampled) scale leaves, flags its sub-problem.
+// The coarse probe's queries get the same pieces from probe_split_kernel (below), and three more things: the query as a
+// ROW (the select kernel's exact step reads a query's d values; from the [d][nq] operand that is d cache lines per
+// query), |x|^2 as the exact kernels sum it (fma chain over ascending k), and the query's candidate band and fp16
+// scale (probe_band).
+struct ProbeSplitOut {
+  float* xt;                   // [m][xt_stride] fp32 row copies
+  float* q2;                   // [m] |x|^2
+  float* band;                 // [m]
+  float* qscale;               // [m]
+  const unsigned* cmax2_bits;  // the prepared centroids' maxima (kCm words)
+  const int* cflag;
+  float eps, eps_exact, eta;
+  int xt_stride;
+};
+__device__ __forceinline__ void probe_band(const ProbeSplitOut& po, float s, float n2c, float n2r, float n2m, float& band,
+                                           float& qscale);
+
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ A, const float* __restrict__ mu,
                                                    const float* __restrict__ scale, u32x4* __restrict__ hi,
                                                    u32x4* __restrict__ mid, float2* __restrict__ norms,
@@ -2586,11 +2603,15 @@ static int run_cand_tail(const float* A, const float* B, float* vals, int64_t* i
 // 16-byte pieces of the query's row (rows 8 g + 4 half + j of a 32 x 32 tile are four consecutive cells), and the
 // maximum over each 128-cell group is kept for the row select's group filter.  grid (query blocks, 256-cell chunks);
 // a block walks n_wide wide tiles per wave (small query batches: one, so that 10 000 queries x 64 chunks are 1 280 blocks).
+// (see the epilogue of probe_sims_kernel)
+#define TPQ_STORE_PAD() asm volatile("s_nop 7" ::: "memory")
+
 struct ProbeSimsArgs {
   const u32x4* hi;
   const u32x4* frags;
-  float* sims;
-  float* gmax;
+  _Float16* sims;        // [nq][n_cells] f' x qscale[q], fp16
+  const float* qscale;   // [nq] the power of two that puts |f'| <= (|a'| + |c'|max)^2 of the query below 2^15
+  float* gmax;           // [nq][n_groups] maxima of the UNROUNDED f' (fp32, unscaled)
   int nq, n_cells, n_groups, n_wide;
   int64_t T;
   int chunk_frag_stride;
@@ -2654,7 +2675,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void probe_sims_kernel(ProbeSimsArg
   const int64_t rows_here = (a.nq - q_block0) < (int64_t)n_wide * kWaves * 64 ? (a.nq - q_block0) : (int64_t)n_wide * kWaves * 64;
   const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<char*>(a.sims + q_block0 * a.n_cells + chunk * 256), 0,
-      (int)(rows_here > 0 ? (rows_here - 1) * (int64_t)a.n_cells * 4 + (a.n_cells - chunk * 256) * 4 : 0), 0x00020000);
+      (int)(rows_here > 0 ? (rows_here - 1) * (int64_t)a.n_cells * 2 + (a.n_cells - chunk * 256) * 2 : 0), 0x00020000);
+  float qs[2];     // the lane's query's scale, per column tile
   int svoff[2];    // byte offset of the lane's row (and half) of each column tile inside that resource
   const int units_here = (a.n_cells - chunk * 256 + 31) / 32;  // (n_cells % 32 == 0: whole units)
 
@@ -2689,17 +2711,43 @@ __global__ __launch_bounds__(kWaves * 64, 2) void probe_sims_kernel(ProbeSimsArg
     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cfrag, bones, acc[1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     if (U < units_here) {  // wave-uniform (the last chunk of a cell count that is not a multiple of 256)
+      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+      u32x4 w[2][2];  // [column tile][pair of pieces]: eight consecutive cells of the lane's query, fp16
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         float mx = gm[ct][U >> 2];
+        uint32_t pk[4][2];  // the lane's four pieces (cells 8 g + 4 half + 0..3) as fp16 pairs
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 v = {acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]};
           mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srsrc, svoff[ct], (U * 32 + 8 * g) * 4, 0);
+          const f16x2 h0 = {(_Float16)(v[0] * qs[ct]), (_Float16)(v[1] * qs[ct])};
+          const f16x2 h1 = {(_Float16)(v[2] * qs[ct]), (_Float16)(v[3] * qs[ct])};
+          pk[g][0] = __builtin_bit_cast(uint32_t, h0);
+          pk[g][1] = __builtin_bit_cast(uint32_t, h1);
         }
         gm[ct][U >> 2] = mx;
+        // lanes l and l + 32 hold the two halves of the same eight cells of the same query: v_permlane32_swap gives the
+        // lower lane both halves of piece 2 p and the upper lane both halves of piece 2 p + 1 -- 16-byte stores of eight
+        // consecutive cells (as 8-byte stores the kernel is bound by the number of store instructions, not their bytes)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * p][0], pk[2 * p + 1][0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * p][1], pk[2 * p + 1][1], false, false);
+          w[ct][p] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+        }
       }
+      // The four stores last and back to back, then TPQ_STORE_PAD: on gfx950 a VALU instruction that overwrites a
+      // register of a 16-byte store's data two instructions after the store (all the wait the compiler's hazard rule
+      // asks for) reaches the register file before the store has read it -- measured here: with the stores in between
+      // the conversions, 9 % of the rows held a later group maximum in the first dword of a piece
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          __builtin_amdgcn_raw_buffer_store_b128(w[ct][p], srsrc, svoff[ct], (U * 32 + 16 * p) * 2, 0);
+      TPQ_STORE_PAD();
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -2711,7 +2759,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void probe_sims_kernel(ProbeSimsArg
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       const int64_t qi = (2 * wt + ct) * 32 + l31;
-      svoff[ct] = qi < a.nq ? (int)((qi - q_block0) * a.n_cells * 4) + half * 16 : 0x7ffffff0;
+      svoff[ct] = qi < a.nq ? (int)((qi - q_block0) * a.n_cells * 2) + half * 16 : 0x7ffffff0;
+      qs[ct] = a.qscale[qi < a.nq ? qi : 0];
       gm[ct][0] = gm[ct][1] = -INFINITY;
     }
     static_for<0, 8>([&](auto u_c) { unit(u_c, voff_next, xsb[CB], xsb[NX]); });
@@ -2739,25 +2788,118 @@ __global__ __launch_bounds__(kWaves * 64, 2) void probe_sims_kernel(ProbeSimsArg
 // band[q] = 2 delta' of query q: emit()'s level-1 bound (the pieces this query and the worst centroid actually drop, the
 // fp32 accumulation of the MFMA terms, the subnormal pieces, and the exact chain's own rounding), in f' units;
 // +inf when the queries or the centroids do not fit the fp16 scale (the select then evaluates the query exactly)
-__global__ __launch_bounds__(256) void probe_band_kernel(const float2* __restrict__ norms, const unsigned* __restrict__ cmax2_bits,
-                                                        const float* __restrict__ scale,
-                                                        const int* __restrict__ cflag, float* __restrict__ band, int nq,
-                                                        float eps, float eps_exact, float eta) {
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= nq) return;
-  const float s = scale[0];
-  const float cn = sqrtf(__uint_as_float(cmax2_bits[0])), cnr = sqrtf(__uint_as_float(cmax2_bits[1]));
-  const float c2 = sqrtf(__uint_as_float(cmax2_bits[2]));
-  const float2 n2 = norms[q];
-  float n2r, n2m;
-  unpack_bound_norms(n2.y, n2r, n2m);
-  const float an = sqrtf(n2.x), anr = sqrtf(n2r) * s;
+__device__ __forceinline__ void probe_band(const ProbeSplitOut& po, float s, float n2c, float n2r, float n2m, float& band,
+                                           float& qscale) {
+  const float cn = sqrtf(__uint_as_float(po.cmax2_bits[0])), cnr = sqrtf(__uint_as_float(po.cmax2_bits[1]));
+  const float c2 = sqrtf(__uint_as_float(po.cmax2_bits[2]));
+  const float an = sqrtf(n2c), anr = sqrtf(n2r) * s;
   const float t1 = an + cn, t2 = anr + cnr * s;
   const float a2 = sqrtf(n2m);
   const float dropped = a2 * (2.002f * cn + c2) + 1.001f * an * c2;
-  float delta = 1.26f * (dropped + eps * t1 * t1 + eta * (2.f * cn + an) + eps_exact * t2 * t2);
-  if (cflag[0] != 0 || !(delta < 3.0e38f)) delta = INFINITY;  // (a query beyond the scale: n2.x = inf -> delta = inf)
-  band[q] = 2.f * delta;
+  float delta = 1.26f * (dropped + po.eps * t1 * t1 + po.eta * (2.f * cn + an) + po.eps_exact * t2 * t2);
+  if (po.cflag[0] != 0 || !(delta < 3.0e38f)) delta = INFINITY;  // (a query beyond the scale: n2c = inf -> delta = inf)
+  // the fast values are STORED as fp16 of f' x 2^-e with |f'| <= (|a'| + |c'|max)^2 = t1^2 < 2^(e + 15): half the bytes
+  // of the matrix the select reads (and the sims kernel's time is its write).  The rounding of the stored values is
+  // the select kernel's to add to the band: it knows how large the values near the top of the row are
+  float sc = 0.f;
+  const float b = t1 * t1;
+  if (delta < INFINITY && b > 0.f) {
+    const int e = ilogbf(b) - 14;
+    if (e > -100 && e < 100) sc = ldexpf(1.f, -e);
+  }
+  if (!(sc > 0.f)) {  // (all-zero or astronomically scaled data: evaluated exactly)
+    sc = 1.f;
+    if (b > 0.f) delta = INFINITY;
+  }
+  qscale = sc;
+  band = 2.f * delta * sc;  // in STORED units
+}
+
+// split_kernel for a search batch.  There a lane walks all of its point's dimensions, 32 at a time: four dependent
+// rounds of strided loads, and 10 000 queries are 40 blocks -- 16 us of latency on a mostly idle chip.  Here a block is
+// 64 queries x 4 waves and WAVE w takes k-quarter w: one round of loads per wave, all in flight together.  The raw
+// values also go to LDS, from which wave 0 sums |x|^2 as the exact kernels do (one fma chain over ascending k -- the
+// one quantity here whose rounding is part of the result) and derives the band; |a'|^2 and |a' - ah|^2 only enter
+// bounds and are summed per quarter.  No norms are written: nothing on the probe's path reads them.
+__global__ __launch_bounds__(256) void probe_split_kernel(const float* __restrict__ A, const float* __restrict__ mu,
+                                                         const float* __restrict__ scale, u32x4* __restrict__ hi,
+                                                         u32x4* __restrict__ mid, int d, int64_t m, int64_t T, int KS,
+                                                         ProbeSplitOut po) {
+  __shared__ float xs[128 * 64];      // [k][query]
+  __shared__ float part[4][2][64];    // per quarter: |a'|^2, |a' - ah|^2
+  __shared__ int bad_s[4][64];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t tile = i >> 5;
+  const int l31 = (int)(i & 31);
+  const bool iv = i < m;
+  const int Q = (KS + 1) / 2;
+  const float s = scale[0];
+  if (w < Q) {
+    const int q = w;
+    const float* Ab = A + (iv ? i : 0);
+    float x[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int k = 32 * q + j;
+      x[j] = (iv && k < d) ? Ab[(int64_t)k * m] : 0.f;
+    }
+    if (iv) {
+      float4* xr = reinterpret_cast<float4*>(po.xt + i * po.xt_stride + 32 * q);
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (32 * q + 4 * c < po.xt_stride) xr[c] = make_float4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
+    }
+    float n2c = 0.f, n2m = 0.f;
+    int bad = 0;
+    const int64_t fo = ((tile * Q) + q) * 128 + l31 * 4;  // in 16-byte chunks
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f16x8 h, mm;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 32 * q + 8 * c + j;
+        const float xv = x[8 * c + j];
+        xs[k * 64 + lane] = xv;
+        const float a = (iv && k < d) ? (xv - mu[k]) * s : 0.f;
+        bad |= !(fabsf(a) < 16384.f);
+        const _Float16 hh = (_Float16)a;
+        const float r = a - (float)hh;
+        h[j] = hh;
+        mm[j] = (_Float16)r;
+        n2c = fmaf(a, a, n2c);
+        n2m = fmaf(r, r, n2m);
+      }
+      if (tile < T) {
+        hi[fo + c] = __builtin_bit_cast(u32x4, h);
+        mid[fo + c] = __builtin_bit_cast(u32x4, mm);
+      }
+    }
+    part[q][0][lane] = n2c;
+    part[q][1][lane] = n2m;
+    bad_s[q][lane] = bad;
+  }
+  __syncthreads();
+  if (w == 0 && iv) {
+    float n2r = 0.f, n2c = 0.f, n2m = 0.f;
+    int bad = 0;
+#pragma unroll 16
+    for (int k = 0; k < 32 * Q; ++k) {
+      const float xv = xs[k * 64 + lane];
+      n2r = fmaf(xv, xv, n2r);
+    }
+    for (int q = 0; q < Q; ++q) {
+      n2c += part[q][0][lane];
+      n2m += part[q][1][lane];
+      bad |= bad_s[q][lane];
+    }
+    // (the quarter sums round differently from one chain: a few ulps, under the bounds' own 1.001 factors)
+    float band, qs;
+    probe_band(po, s, bad ? INFINITY : n2c * 1.000001f, n2r, n2m * 1.000001f, band, qs);
+    po.q2[i] = n2r;
+    po.band[i] = band;
+    po.qscale[i] = qs;
+  }
 }
 
 // the centroids as rows, and |C|^2 as the exact kernels sum it (ascending k, fma)
@@ -2816,7 +2958,8 @@ struct ProbeLayout {
   PrepLayout P;
   ProbePrepared C;
   int KS, n_groups;
-  size_t prep_off, flag_off, sims_off, gmax_off, band_off, prepared_off, total;
+  int xt_stride;
+  size_t prep_off, flag_off, sims_off, gmax_off, band_off, qscale_off, q2_off, xt_off, prepared_off, total;
 };
 static ProbeLayout probe_layout(int d, int nq, int n_cells) {
   ProbeLayout L;
@@ -2828,9 +2971,13 @@ static ProbeLayout probe_layout(int d, int nq, int n_cells) {
   L.prep_off = 0;
   L.flag_off = up(L.P.total);
   L.sims_off = L.flag_off + 256;
-  L.gmax_off = up(L.sims_off + (size_t)nq * n_cells * 4);
+  L.gmax_off = up(L.sims_off + (size_t)nq * n_cells * 2);
   L.band_off = up(L.gmax_off + (size_t)nq * L.n_groups * 4);
-  L.prepared_off = up(L.band_off + (size_t)nq * 4);   // (used when the caller passes no prepared block)
+  L.qscale_off = up(L.band_off + (size_t)nq * 4);
+  L.q2_off = up(L.qscale_off + (size_t)nq * 4);
+  L.xt_stride = (d + 3) / 4 * 4;
+  L.xt_off = up(L.q2_off + (size_t)nq * 4);
+  L.prepared_off = up(L.xt_off + (size_t)nq * L.xt_stride * 4);   // (used when the caller passes no prepared block)
   L.total = L.prepared_off + L.C.total;
   return L;
 }
@@ -2872,22 +3019,23 @@ static int run_probe_sims(const float* query, const char* prepared, int d, int n
   const ProbePrepared& C = L.C;
   char* p = ws + L.prep_off;
   int* flag = reinterpret_cast<int*>(ws + L.flag_off);   // (queries beyond the scale carry it in their norm)
-  float* sims = reinterpret_cast<float*>(ws + L.sims_off);
+  _Float16* sims = reinterpret_cast<_Float16*>(ws + L.sims_off);
   float* gmax = reinterpret_cast<float*>(ws + L.gmax_off);
   float* band = reinterpret_cast<float*>(ws + L.band_off);
+  float* qscale = reinterpret_cast<float*>(ws + L.qscale_off);
   const float* mu = reinterpret_cast<const float*>(prepared + C.mu_off);
   const float* scale = reinterpret_cast<const float*>(prepared + C.scale_off);
   const int* cflag = reinterpret_cast<const int*>(prepared + C.cflag_off);
   const unsigned* cmax = reinterpret_cast<const unsigned*>(prepared + C.cmax_off);
   const u32x4* frags = reinterpret_cast<const u32x4*>(prepared + C.frags_off);
-  hipLaunchKernelGGL(split_kernel, dim3((unsigned)((P.T + 7) / 8), 1), dim3(256), 0, st, query, mu, scale,
-                     reinterpret_cast<u32x4*>(p + P.hi_off), reinterpret_cast<u32x4*>(p + P.mid_off),
-                     reinterpret_cast<float2*>(p + P.norms_off), flag, d, (int64_t)nq, P.T, KS);
-  TPQ_LAUNCH_CHECK("lloyd split_kernel");
-  hipLaunchKernelGGL(probe_band_kernel, dim3((nq + 255) / 256), dim3(256), 0, st,
-                     reinterpret_cast<const float2*>(p + P.norms_off), cmax, scale, cflag, band, nq,
-                     level_eps(KS, 16 * KS, 1), (float)(d + 4) / 16777216.0f, sqrtf((float)(16 * KS)) / 8192.0f);
-  TPQ_LAUNCH_CHECK("probe_band_kernel");
+  float* q2 = reinterpret_cast<float*>(ws + L.q2_off);
+  float* xt = reinterpret_cast<float*>(ws + L.xt_off);
+  const ProbeSplitOut po{xt, q2, band, qscale, cmax, cflag, level_eps(KS, 16 * KS, 1), (float)(d + 4) / 16777216.0f,
+                         sqrtf((float)(16 * KS)) / 8192.0f, L.xt_stride};
+  hipLaunchKernelGGL(probe_split_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, st, query, mu, scale,
+                     reinterpret_cast<u32x4*>(p + P.hi_off), reinterpret_cast<u32x4*>(p + P.mid_off), d, (int64_t)nq, P.T, KS,
+                     po);
+  TPQ_LAUNCH_CHECK("probe_split_kernel");
   const size_t lds = (size_t)8 * (KS + 1) * 1024;
   auto kernel = probe_sims_kernel<KS>;
   int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2898,12 +3046,12 @@ static int run_probe_sims(const float* query, const char* prepared, int d, int n
   int n_wide = (int)((wide * C.chunks) / ((int64_t)kWaves * 1024));
   n_wide = n_wide < 1 ? 1 : (n_wide > kWide ? kWide : n_wide);
   const int64_t per_block = (int64_t)kWaves * n_wide;
-  ProbeSimsArgs pa{reinterpret_cast<const u32x4*>(p + P.hi_off), frags, sims, gmax, nq, n_cells, L.n_groups, n_wide,
+  ProbeSimsArgs pa{reinterpret_cast<const u32x4*>(p + P.hi_off), frags, sims, qscale, gmax, nq, n_cells, L.n_groups, n_wide,
                    P.T, 8 * (2 * KS + 1) * 64};
   hipLaunchKernelGGL(kernel, dim3((unsigned)((wide + per_block - 1) / per_block), C.chunks), dim3(kWaves * 64), lds, st,
                      pa);
   TPQ_LAUNCH_CHECK("probe_sims_kernel");
-  *out = ProbeFastBuffers{sims, gmax, band, reinterpret_cast<const float*>(prepared + C.ct_off),
+  *out = ProbeFastBuffers{sims, gmax, band, qscale, xt, q2, L.xt_stride, reinterpret_cast<const float*>(prepared + C.ct_off),
                           reinterpret_cast<const float*>(prepared + C.c2_off), L.n_groups};
   return TPQ_OK;
 }

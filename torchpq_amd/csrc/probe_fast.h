@@ -11,9 +11,15 @@
 
 namespace tpq {
 struct ProbeFastBuffers {
-  const float* sims;  // [nq][n_cells] fast values f' = 2 a'.c' - |c'|^2 (centred, scaled: per query a monotone image of the similarity)
-  const float* gmax;  // [nq][n_groups] maxima of f' over groups of 128 cells
-  const float* band;  // [nq] 2 delta': width of the candidate band in f' units; +inf: the query is evaluated exactly
+  const _Float16* sims;  // [nq][n_cells] fast values f' = 2 a'.c' - |c'|^2 (centred, scaled: per query a monotone image of
+                         // the similarity), stored as fp16 of f' x qscale[q]
+  const float* gmax;     // [nq][n_groups] maxima of the unrounded f' over groups of 128 cells (fp32, not scaled)
+  const float* band;     // [nq] 2 delta' x qscale: the candidate band in STORED units before the rounding of the stored
+                         // values (which the select kernel adds); +inf: the query is evaluated exactly
+  const float* qscale;   // [nq] power of two
+  const float* xt;       // [nq][xt_stride] the queries as rows (fp32, as given)
+  const float* q2;       // [nq] |x|^2 as the exact kernels sum it (fma chain over ascending k)
+  int xt_stride;         // multiple of 4
   const float* ct;    // [n_cells][d] the centroids as rows
   const float* c2;    // [n_cells] |C|^2, ascending-k fma chain
   int n_groups;

@@ -214,6 +214,8 @@ __global__ __launch_bounds__(kSelWaves * 64) void topk_select_kernel(const float
 //      topk_select_kernel's output, bit for bit.
 // A list full of candidates (an entry may have been evicted), or band = +inf (queries / centroids beyond the fp16 scale):
 // the wave evaluates ALL cells of its query exactly -- slow, and normally never taken.
+constexpr int kCandCap = 256;  // candidate cells a wave keeps without selecting (direct path)
+
 template <int R>
 __global__ __launch_bounds__(kSelWaves * 64) void probe_select_fast_kernel(ProbeFastBuffers fb, const float* __restrict__ x,
                                                                           float* __restrict__ vals,
@@ -222,18 +224,40 @@ __global__ __launch_bounds__(kSelWaves * 64) void probe_select_fast_kernel(Probe
   __shared__ float qv[kSelWaves * 64];
   __shared__ int qi[kSelWaves * 64];
   __shared__ float xq_all[kSelWaves * 128];
+  __shared__ int cand[kSelWaves * kCandCap];
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int row = blockIdx.x * kSelWaves + wave;
   if (row >= nq) return;
   float* xq = xq_all + wave * 128;
-  for (int t = lane; t < d; t += 64) xq[t] = x[(int64_t)t * nq + row];
+  // everything the wave needs first, issued together: its query's row (d <= 128 floats), |x|^2, band, scale and the
+  // first group maxima
+  const float4 xrow = lane * 4 < d ? reinterpret_cast<const float4*>(fb.xt + (int64_t)row * fb.xt_stride)[lane]
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float q2 = fb.q2[row];
+  const float band0 = fb.band[row];
+  const float qs = fb.qscale[row];
+  const float* __restrict__ gm = fb.gmax + (int64_t)row * fb.n_groups;   // f' (fp32): scaled on the fly
+  float gm0[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) gm0[u] = 64 * u + lane < fb.n_groups ? gm[64 * u + lane] : -INFINITY;
+  if (lane * 4 < d) reinterpret_cast<float4*>(xq)[lane] = xrow;  // (d % 4 != 0: the row copy is zero-padded to xt_stride)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  float q2 = 0.f;
-  for (int t = 0; t < d; ++t) q2 = fmaf(xq[t], xq[t], q2);
   auto exact = [&](int c) -> float {  // the fp32 kernels' value of (query, cell c)
     const float4* __restrict__ cr = reinterpret_cast<const float4*>(fb.ct + (int64_t)c * d);
     float acc = 0.f;
     int t = 0;
+    for (; t + 32 <= d; t += 32) {  // (each candidate's row is a lane's own: eight loads in flight, four round trips at d = 128)
+      float4 y[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) y[u] = cr[(t >> 2) + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc = fmaf(y[u].x, xq[t + 4 * u], acc);
+        acc = fmaf(y[u].y, xq[t + 4 * u + 1], acc);
+        acc = fmaf(y[u].z, xq[t + 4 * u + 2], acc);
+        acc = fmaf(y[u].w, xq[t + 4 * u + 3], acc);
+      }
+    }
     for (; t + 16 <= d; t += 16) {
       float4 y[4];
 #pragma unroll
@@ -252,29 +276,111 @@ __global__ __launch_bounds__(kSelWaves * 64) void probe_select_fast_kernel(Probe
     v = v - fb.c2[c];
     return v + 0.0f;
   };
-  const float band = fb.band[row];
+#ifdef TPQ_SELECT_STOP
+#define TPQ_STOP_AT(n, val) if (TPQ_SELECT_STOP == n) { if (lane == 0) vals[(int64_t)row * k] = (val); return; }
+#else
+#define TPQ_STOP_AT(n, val)
+#endif
+  TPQ_STOP_AT(1, q2)
   WaveTopK<R> ex;
-  bool slow = !(band < INFINITY);
+  bool slow = !(band0 < INFINITY);
   if (!slow) {
     WaveSelector<R> sel;
     sel.init(qv + wave * 64, qi + wave * 64, k);
-    sel.margin = band;
-    const float* __restrict__ xr = fb.sims + (int64_t)row * n_cells;
-    const float* __restrict__ gm = fb.gmax + (int64_t)row * fb.n_groups;
+    sel.margin = band0;
+    const _Float16* __restrict__ xr = fb.sims + (int64_t)row * n_cells;  // stored units: f' x qs, fp16
+    const uint32_t* __restrict__ xr2 = reinterpret_cast<const uint32_t*>(xr);  // (rows are 64-byte aligned: n_cells % 32 == 0)
     // phase 1: the k-th largest group maximum (a lower bound of the k-th largest fast value)
     for (int base = 0; base < fb.n_groups; base += 64) {
       const int g = base + lane;
-      const float v = g < fb.n_groups ? gm[g] + 0.0f : -INFINITY;
-      sel.push(g < fb.n_groups && (v >= sel.tau - band), v, g);
+      const float gv = base < 128 ? gm0[(base >> 6) & 1] : (g < fb.n_groups ? gm[g] : -INFINITY);
+      const float v = g < fb.n_groups ? gv * qs + 0.0f : -INFINITY;
+      sel.push(g < fb.n_groups && (v >= sel.tau - band0), v, g);
     }
     sel.flush();
-    const float tau0 = sel.top.kth_value(k) - band;  // -inf while there are fewer than k groups
+    // The stored values are fp16: u = f' x qs rounded to nearest, |stored - u| <= 2^-11 |u| (+ 2^-25 where the result is
+    // subnormal).  A cell that belongs to the exact top k has u in [G_k - band0, M_1] (G_k the k-th largest group
+    // maximum -- a lower bound of the k-th largest u --, M_1 the largest; both unrounded), so its stored value is within
+    // eps = 2^-11 (max(|M_1|, |G_k|) + band0) of u; and the k-th largest stored value is within eps of the k-th largest u
+    // (rounding is monotone, the k-th largest u lies in [G_k, M_1]).  Band in stored values: band0 + 2 eps.  |u| < 2^15
+    // by the choice of qs: eps <= 16 whatever the row holds (fewer than k groups: G_k = -inf).
+    const float gk = sel.top.kth_value(k);
+    const float mag = fmaxf(fabsf(sel.top.kth_value(1)), fabsf(gk)) + band0;
+    const float eps = fminf(16.f, mag * 4.8828125e-4f) * 1.001f + 5.9604645e-8f;
+    const float band = band0 + 2.f * eps;
+    const float tau0 = gk - band;  // -inf while there are fewer than k groups
+    TPQ_STOP_AT(2, tau0)
+    // phase 2, direct: EVERY cell of a hot group whose stored value reaches tau0 is kept -- a superset of the candidates
+    // (cut >= tau0: the k-th largest stored value is not below G_k - eps) that costs a ballot and an LDS append per 64
+    // cells instead of the selector's queue, sorts and merges; the exact top k is among them whatever else is, so the
+    // exact values of all of them, sorted once, are the answer.  More than kCandCap of them (k close to or beyond the
+    // number of groups: G_k is a poor bound or none) and the selector path below finds the cut itself.
+    int* cl = cand + wave * kCandCap;
+    int n_cand = 0;  // wave-uniform
+    bool direct = gk > -INFINITY && 2 * k <= fb.n_groups;  // (k-th of fewer than 2 k maxima: too low a bound to try)
+    if (direct) {
+      for (int base = 0; base < fb.n_groups && n_cand <= kCandCap; base += 64) {
+        const int g = base + lane;
+        const float gv = base < 128 ? gm0[(base >> 6) & 1] : (g < fb.n_groups ? gm[g] : -INFINITY);
+        const bool hot = g < fb.n_groups && (gv * qs >= tau0);
+        unsigned long long mask = __ballot(hot);
+        while (mask != 0ull) {
+          // eight hot groups a round, a group (128 cells, 256 bytes) one dword load: the loop is a chain of memory round
+          // trips, and there are as many of them as rounds
+          int gs[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            gs[u] = -1;
+            if (mask != 0ull) {
+              gs[u] = base + (int)__builtin_ctzll(mask);
+              mask &= mask - 1ull;
+            }
+          }
+          uint32_t vw[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int c = gs[u] * 128 + 2 * lane;   // (n_cells is even: a pair is inside the row or beyond it)
+            vw[u] = (gs[u] >= 0 && c < n_cells) ? xr2[c >> 1] : 0xfc00fc00u;  // (-inf, -inf)
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (gs[u] >= 0) {  // wave-uniform
+              typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+              const f16x2 hv = __builtin_bit_cast(f16x2, vw[u]);
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                const int c = gs[u] * 128 + 2 * lane + e;
+                const bool keep = (float)hv[e] >= tau0;  // (beyond the row: -inf; tau0 is finite on this path)
+                const unsigned long long b = __ballot(keep);
+                const int pos = n_cand + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+                if (keep && pos < kCandCap) cl[pos] = c;
+                n_cand += __popcll(b);
+              }
+            }
+          }
+          if (n_cand > kCandCap) mask = 0ull;
+        }
+      }
+      direct = n_cand <= kCandCap;
+    }
+    TPQ_STOP_AT(3, (float)n_cand)
+    if (direct) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // (the wave's own LDS appends)
+      ex.init();
+      for (int base = 0; base < n_cand; base += 64) {
+        const bool want = base + lane < n_cand;
+        const int c = want ? cl[base + lane] : 0;
+        const float e = want ? exact(c) : -INFINITY;
+        ex.insert_unsorted(want ? make_key(e, c) : pad_key());
+      }
+      TPQ_STOP_AT(4, ex.kth_value(1))
+    } else {
     sel.init(qv + wave * 64, qi + wave * 64, k);
     sel.margin = band;
     // phase 2: the groups that can hold a candidate, four (eight loads) at a time
     for (int base = 0; base < fb.n_groups; base += 64) {
       const int g = base + lane;
-      const bool hot = g < fb.n_groups && (gm[g] >= tau0);
+      const bool hot = g < fb.n_groups && (gm[g] * qs >= tau0);
       unsigned long long mask = __ballot(hot);
       while (mask != 0ull) {
         int gs[4];
@@ -290,7 +396,7 @@ __global__ __launch_bounds__(kSelWaves * 64) void probe_select_fast_kernel(Probe
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int c = gs[u >> 1] * 128 + 64 * (u & 1) + lane;
-          va[u] = (gs[u >> 1] >= 0 && c < n_cells) ? xr[c] : -INFINITY;
+          va[u] = (gs[u >> 1] >= 0 && c < n_cells) ? (float)xr[c] : -INFINITY;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -316,6 +422,7 @@ __global__ __launch_bounds__(kSelWaves * 64) void probe_select_fast_kernel(Probe
         const float e = want ? exact(c) : -INFINITY;
         ex.insert_unsorted(want ? make_key(e, c) : pad_key());
       }
+    }
     }
   }
   if (slow) {  // every cell, exactly
