@@ -2617,8 +2617,9 @@ struct ProbeSimsArgs {
   int chunk_frag_stride;
 };
 
-template <int KS>
+template <int KS, int GSH>   // GSH: log2 of the cells per group of the maxima (5: one unit, 7: four)
 __global__ __launch_bounds__(kWaves * 64, 2) void probe_sims_kernel(ProbeSimsArgs a) {
+  constexpr int NG = 256 >> GSH;   // groups per 256-cell chunk
   constexpr int FPU = 2 * KS + 1;  // fragments per unit in global memory
   constexpr int FL = KS + 1;       // ... in LDS
   constexpr int Q = (KS + 1) / 2;
@@ -2666,7 +2667,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void probe_sims_kernel(ProbeSimsArg
     bones[1] = (__bf16)1.0f;
     bones[2] = (__bf16)1.0f;
   }
-  float gm[2][2];  // [column tile][group of the chunk]
+  float gm[2][NG];  // [column tile][group of the chunk]
   // the sims rows of this block's queries as ONE buffer resource (base: the block's first query, the chunk's first
   // cell): a lane's stores are buffer_store_dwordx4 at a 32-bit offset -- its row, its half -- plus a compile-time
   // constant; rows beyond nq get an offset beyond the resource's range and are dropped by the hardware (64-bit
@@ -2715,7 +2716,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void probe_sims_kernel(ProbeSimsArg
       u32x4 w[2][2];  // [column tile][pair of pieces]: eight consecutive cells of the lane's query, fp16
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
-        float mx = gm[ct][U >> 2];
+        float mx = gm[ct][U >> (GSH - 5)];
         uint32_t pk[4][2];  // the lane's four pieces (cells 8 g + 4 half + 0..3) as fp16 pairs
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -2726,7 +2727,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void probe_sims_kernel(ProbeSimsArg
           pk[g][0] = __builtin_bit_cast(uint32_t, h0);
           pk[g][1] = __builtin_bit_cast(uint32_t, h1);
         }
-        gm[ct][U >> 2] = mx;
+        gm[ct][U >> (GSH - 5)] = mx;
         // lanes l and l + 32 hold the two halves of the same eight cells of the same query: v_permlane32_swap gives the
         // lower lane both halves of piece 2 p and the upper lane both halves of piece 2 p + 1 -- 16-byte stores of eight
         // consecutive cells (as 8-byte stores the kernel is bound by the number of store instructions, not their bytes)
@@ -2761,16 +2762,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void probe_sims_kernel(ProbeSimsArg
       const int64_t qi = (2 * wt + ct) * 32 + l31;
       svoff[ct] = qi < a.nq ? (int)((qi - q_block0) * a.n_cells * 2) + half * 16 : 0x7ffffff0;
       qs[ct] = a.qscale[qi < a.nq ? qi : 0];
-      gm[ct][0] = gm[ct][1] = -INFINITY;
+#pragma unroll
+      for (int gg = 0; gg < NG; ++gg) gm[ct][gg] = -INFINITY;
     }
     static_for<0, 8>([&](auto u_c) { unit(u_c, voff_next, xsb[CB], xsb[NX]); });
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       const int64_t qi = (2 * wt + ct) * 32 + l31;
 #pragma unroll
-      for (int gg = 0; gg < 2; ++gg) {
+      for (int gg = 0; gg < NG; ++gg) {
         const float m2 = fmaxf(gm[ct][gg], __shfl_xor(gm[ct][gg], 32, 64));  // the two halves hold disjoint cells
-        const int grp = chunk * 2 + gg;
+        const int grp = chunk * NG + gg;
         if (half == 0 && qi < a.nq && grp < a.n_groups) a.gmax[qi * a.n_groups + grp] = m2;
       }
     }
@@ -2957,7 +2959,7 @@ static ProbePrepared probe_prepared_layout(int d, int n_cells) {
 struct ProbeLayout {
   PrepLayout P;
   ProbePrepared C;
-  int KS, n_groups;
+  int KS, n_groups, gshift;
   int xt_stride;
   size_t prep_off, flag_off, sims_off, gmax_off, band_off, qscale_off, q2_off, xt_off, prepared_off, total;
 };
@@ -2966,7 +2968,10 @@ static ProbeLayout probe_layout(int d, int nq, int n_cells) {
   L.C = probe_prepared_layout(d, n_cells);
   L.KS = L.C.KS;
   L.P = prep_layout(1, 16 * L.KS, nq);
-  L.n_groups = (n_cells + 127) / 128;
+  // group maxima: of 32 cells up to 8 192 cells, of 64 up to 16 384 (<= 256 groups, which the select prefetches whole;
+  // its direct list needs 2 n_probe <= groups), of 128 beyond
+  L.gshift = n_cells <= 8192 ? 5 : (n_cells <= 16384 ? 6 : 7);
+  L.n_groups = (n_cells + (1 << L.gshift) - 1) >> L.gshift;
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   L.prep_off = 0;
   L.flag_off = up(L.P.total);
@@ -3037,7 +3042,7 @@ static int run_probe_sims(const float* query, const char* prepared, int d, int n
                      po);
   TPQ_LAUNCH_CHECK("probe_split_kernel");
   const size_t lds = (size_t)8 * (KS + 1) * 1024;
-  auto kernel = probe_sims_kernel<KS>;
+  auto kernel = L.gshift == 5 ? probe_sims_kernel<KS, 5> : (L.gshift == 6 ? probe_sims_kernel<KS, 6> : probe_sims_kernel<KS, 7>);
   int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds), "probe_sims_kernel attr");
   if (rc) return rc;
@@ -3052,7 +3057,7 @@ static int run_probe_sims(const float* query, const char* prepared, int d, int n
                      pa);
   TPQ_LAUNCH_CHECK("probe_sims_kernel");
   *out = ProbeFastBuffers{sims, gmax, band, qscale, xt, q2, L.xt_stride, reinterpret_cast<const float*>(prepared + C.ct_off),
-                          reinterpret_cast<const float*>(prepared + C.c2_off), L.n_groups};
+                          reinterpret_cast<const float*>(prepared + C.c2_off), L.n_groups, L.gshift};
   return TPQ_OK;
 }
 

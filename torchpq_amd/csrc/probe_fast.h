@@ -13,7 +13,7 @@ namespace tpq {
 struct ProbeFastBuffers {
   const _Float16* sims;  // [nq][n_cells] fast values f' = 2 a'.c' - |c'|^2 (centred, scaled: per query a monotone image of
                          // the similarity), stored as fp16 of f' x qscale[q]
-  const float* gmax;     // [nq][n_groups] maxima of the unrounded f' over groups of 128 cells (fp32, not scaled)
+  const float* gmax;     // [nq][n_groups] maxima of the unrounded f' over groups of 2^gshift cells (fp32, not scaled)
   const float* band;     // [nq] 2 delta' x qscale: the candidate band in STORED units before the rounding of the stored
                          // values (which the select kernel adds); +inf: the query is evaluated exactly
   const float* qscale;   // [nq] power of two
@@ -23,6 +23,7 @@ struct ProbeFastBuffers {
   const float* ct;    // [n_cells][d] the centroids as rows
   const float* c2;    // [n_cells] |C|^2, ascending-k fma chain
   int n_groups;
+  int gshift;            // log2 of the cells per group (5 or 7)
 };
 int lloyd_probe_supported(int d, int nq, int n_cells);
 size_t lloyd_probe_workspace_bytes(int d, int nq, int n_cells);

@@ -215,6 +215,7 @@ __global__ __launch_bounds__(kSelWaves * 64) void topk_select_kernel(const float
 // A list full of candidates (an entry may have been evicted), or band = +inf (queries / centroids beyond the fp16 scale):
 // the wave evaluates ALL cells of its query exactly -- slow, and normally never taken.
 constexpr int kCandCap = 256;  // candidate cells a wave keeps without selecting (direct path)
+constexpr int kHotCap = 512;   // hot groups a wave lists
 
 template <int R>
 __global__ __launch_bounds__(kSelWaves * 64) void probe_select_fast_kernel(ProbeFastBuffers fb, const float* __restrict__ x,
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(kSelWaves * 64) void probe_select_fast_kernel(Probe
   __shared__ int qi[kSelWaves * 64];
   __shared__ float xq_all[kSelWaves * 128];
   __shared__ int cand[kSelWaves * kCandCap];
+  __shared__ int hot[kSelWaves * kHotCap];
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int row = blockIdx.x * kSelWaves + wave;
   if (row >= nq) return;
@@ -237,9 +239,9 @@ __global__ __launch_bounds__(kSelWaves * 64) void probe_select_fast_kernel(Probe
   const float band0 = fb.band[row];
   const float qs = fb.qscale[row];
   const float* __restrict__ gm = fb.gmax + (int64_t)row * fb.n_groups;   // f' (fp32): scaled on the fly
-  float gm0[2];
+  float gm0[4];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) gm0[u] = 64 * u + lane < fb.n_groups ? gm[64 * u + lane] : -INFINITY;
+  for (int u = 0; u < 4; ++u) gm0[u] = 64 * u + lane < fb.n_groups ? gm[64 * u + lane] : -INFINITY;
   if (lane * 4 < d) reinterpret_cast<float4*>(xq)[lane] = xrow;  // (d % 4 != 0: the row copy is zero-padded to xt_stride)
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   auto exact = [&](int c) -> float {  // the fp32 kernels' value of (query, cell c)
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(kSelWaves * 64) void probe_select_fast_kernel(Probe
     // phase 1: the k-th largest group maximum (a lower bound of the k-th largest fast value)
     for (int base = 0; base < fb.n_groups; base += 64) {
       const int g = base + lane;
-      const float gv = base < 128 ? gm0[(base >> 6) & 1] : (g < fb.n_groups ? gm[g] : -INFINITY);
+      const float gv = base < 256 ? gm0[(base >> 6) & 3] : (g < fb.n_groups ? gm[g] : -INFINITY);
       const float v = g < fb.n_groups ? gv * qs + 0.0f : -INFINITY;
       sel.push(g < fb.n_groups && (v >= sel.tau - band0), v, g);
     }
@@ -310,6 +312,49 @@ __global__ __launch_bounds__(kSelWaves * 64) void probe_select_fast_kernel(Probe
     const float band = band0 + 2.f * eps;
     const float tau0 = gk - band;  // -inf while there are fewer than k groups
     TPQ_STOP_AT(2, tau0)
+    // the hot groups -- those whose maximum reaches tau0 -- as a list in LDS, then their cells two per lane (a dword of
+    // the fp16 row; a 32-cell group is 16 lanes of a load, a 128-cell group all 64), eight loads a round: the walk is a
+    // chain of memory round trips and there are as many of them as rounds
+    int* hl = hot + wave * kHotCap;
+    int n_hot = 0;  // wave-uniform
+    for (int base = 0; base < fb.n_groups; base += 64) {
+      const int g = base + lane;
+      const float gv = base < 256 ? gm0[(base >> 6) & 3] : (g < fb.n_groups ? gm[g] : -INFINITY);
+      const bool is_hot = g < fb.n_groups && (gv * qs >= tau0);
+      const unsigned long long b = __ballot(is_hot);
+      const int pos = n_hot + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+      if (is_hot && pos < kHotCap) hl[pos] = g;
+      n_hot += __popcll(b);
+    }
+    const bool hot_listed = n_hot <= kHotCap;  // (more groups than the list holds: only beyond 65 536 cells; exact then)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // (the wave's own LDS appends)
+    const int lpg_shift = fb.gshift - 1;                    // lanes per group: a lane holds two cells
+    const int sub = lane >> lpg_shift, lig = lane & ((1 << lpg_shift) - 1);
+    const int gpl = 64 >> lpg_shift;                        // groups per load
+    auto walk = [&](auto&& consume, auto&& go_on) {
+      for (int h0 = 0; h0 < n_hot && go_on(); h0 += 8 * gpl) {
+        uint32_t vw[8];
+        int cb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int hi = h0 + u * gpl + sub;
+          const int g = hi < n_hot ? hl[hi] : -1;
+          const int c = (g << fb.gshift) + 2 * lig;   // (n_cells is even: a pair is inside the row or beyond it)
+          const bool ok = g >= 0 && c < n_cells;
+          vw[u] = ok ? xr2[c >> 1] : 0xfc00fc00u;      // (-inf, -inf)
+          cb[u] = ok ? c : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (h0 + u * gpl < n_hot) {  // wave-uniform
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            const f16x2 hv = __builtin_bit_cast(f16x2, vw[u]);
+            consume(cb[u] >= 0, cb[u], (float)hv[0]);
+            consume(cb[u] >= 0, cb[u] + 1, (float)hv[1]);
+          }
+        }
+      }
+    };
     // phase 2, direct: EVERY cell of a hot group whose stored value reaches tau0 is kept -- a superset of the candidates
     // (cut >= tau0: the k-th largest stored value is not below G_k - eps) that costs a ballot and an LDS append per 64
     // cells instead of the selector's queue, sorts and merges; the exact top k is among them whatever else is, so the
@@ -317,50 +362,17 @@ __global__ __launch_bounds__(kSelWaves * 64) void probe_select_fast_kernel(Probe
     // number of groups: G_k is a poor bound or none) and the selector path below finds the cut itself.
     int* cl = cand + wave * kCandCap;
     int n_cand = 0;  // wave-uniform
-    bool direct = gk > -INFINITY && 2 * k <= fb.n_groups;  // (k-th of fewer than 2 k maxima: too low a bound to try)
+    bool direct = hot_listed && gk > -INFINITY && 2 * k <= fb.n_groups;  // (k-th of fewer than 2 k maxima: too low a bound to try)
     if (direct) {
-      for (int base = 0; base < fb.n_groups && n_cand <= kCandCap; base += 64) {
-        const int g = base + lane;
-        const float gv = base < 128 ? gm0[(base >> 6) & 1] : (g < fb.n_groups ? gm[g] : -INFINITY);
-        const bool hot = g < fb.n_groups && (gv * qs >= tau0);
-        unsigned long long mask = __ballot(hot);
-        while (mask != 0ull) {
-          // eight hot groups a round, a group (128 cells, 256 bytes) one dword load: the loop is a chain of memory round
-          // trips, and there are as many of them as rounds
-          int gs[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            gs[u] = -1;
-            if (mask != 0ull) {
-              gs[u] = base + (int)__builtin_ctzll(mask);
-              mask &= mask - 1ull;
-            }
-          }
-          uint32_t vw[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int c = gs[u] * 128 + 2 * lane;   // (n_cells is even: a pair is inside the row or beyond it)
-            vw[u] = (gs[u] >= 0 && c < n_cells) ? xr2[c >> 1] : 0xfc00fc00u;  // (-inf, -inf)
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            if (gs[u] >= 0) {  // wave-uniform
-              typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-              const f16x2 hv = __builtin_bit_cast(f16x2, vw[u]);
-#pragma unroll
-              for (int e = 0; e < 2; ++e) {
-                const int c = gs[u] * 128 + 2 * lane + e;
-                const bool keep = (float)hv[e] >= tau0;  // (beyond the row: -inf; tau0 is finite on this path)
-                const unsigned long long b = __ballot(keep);
-                const int pos = n_cand + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
-                if (keep && pos < kCandCap) cl[pos] = c;
-                n_cand += __popcll(b);
-              }
-            }
-          }
-          if (n_cand > kCandCap) mask = 0ull;
-        }
-      }
+      walk(
+          [&](bool valid, int c, float v) {
+            const bool keep = valid && v >= tau0;
+            const unsigned long long b = __ballot(keep);
+            const int pos = n_cand + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+            if (keep && pos < kCandCap) cl[pos] = c;
+            n_cand += __popcll(b);
+          },
+          [&]() { return n_cand <= kCandCap; });
       direct = n_cand <= kCandCap;
     }
     TPQ_STOP_AT(3, (float)n_cand)
@@ -374,40 +386,17 @@ __global__ __launch_bounds__(kSelWaves * 64) void probe_select_fast_kernel(Probe
         ex.insert_unsorted(want ? make_key(e, c) : pad_key());
       }
       TPQ_STOP_AT(4, ex.kth_value(1))
+    } else if (!hot_listed) {
+      slow = true;
     } else {
     sel.init(qv + wave * 64, qi + wave * 64, k);
     sel.margin = band;
-    // phase 2: the groups that can hold a candidate, four (eight loads) at a time
-    for (int base = 0; base < fb.n_groups; base += 64) {
-      const int g = base + lane;
-      const bool hot = g < fb.n_groups && (gm[g] * qs >= tau0);
-      unsigned long long mask = __ballot(hot);
-      while (mask != 0ull) {
-        int gs[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          gs[u] = -1;
-          if (mask != 0ull) {
-            gs[u] = base + (int)__builtin_ctzll(mask);
-            mask &= mask - 1ull;
-          }
-        }
-        float va[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int c = gs[u >> 1] * 128 + 64 * (u & 1) + lane;
-          va[u] = (gs[u >> 1] >= 0 && c < n_cells) ? (float)xr[c] : -INFINITY;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (gs[u >> 1] >= 0) {  // wave-uniform
-            const int c = gs[u >> 1] * 128 + 64 * (u & 1) + lane;
-            const float v = va[u] + 0.0f;
-            sel.push(c < n_cells && (v >= sel.tau - band), v, c);
-          }
-        }
-      }
-    }
+    // phase 2 through the selector: the k best stored values with their band
+    walk([&](bool valid, int c, float v0) {
+           const float v = v0 + 0.0f;
+           sel.push(valid && (v >= sel.tau - band), v, c);
+         },
+         [&]() { return true; });
     sel.flush();
     const float cut = sel.top.kth_value(k) - band;
     const Key last = readlane_key(sel.top.k[R - 1], 63);
