@@ -9,6 +9,10 @@ namespace tpq {
 #ifndef TPQ_LUT_U
 #define TPQ_LUT_U 4  // fused LUT build, ds <= 2: entries (float4 groups) per thread whose codebook loads are issued together
 #endif
+// pool mode: the counting rounds that tighten the cut before the exact evaluation pay beyond this k (same box, m = 64, ms
+// per 10 000 queries, 0 / 1 / 3 rounds COMPILED IN: k = 600: 4.79 / 5.14 / 5.27, k = 800: 5.19 / 5.50 / 5.68, k = 1000:
+// 6.66 / 6.70 / 6.08; three rounds compiled in and none executed: 5.48 at k = 600 -- hence a kernel of its own, RM = -3)
+constexpr int kPoolRoundsFromK = 900;
 constexpr int kScanWaves = 8;
 constexpr int kScanThreads = kScanWaves * 64;
 
@@ -581,6 +585,73 @@ __device__ __forceinline__ float exact_from_packed(const uint8_t* __restrict__ p
   return exact_from_chunks<M>(w, idx, active, scratch, row_id, lutfn, init);
 }
 
+// The same value with EVERY lane evaluating a slot of its own and no LDS row (plain PQ, LUT in LDS).  The packed layout
+// stores sub-quantizer j of slot s at byte position j ^ (s mod block) so that the scan's lanes read 64 different LUT
+// rows at a time; 64 candidates summed in sub-quantizer order would all read the SAME row at a time (one bank, 64-way).
+// So, sixteen sub-quantizers at a time: the lane picks the four code dwords that hold them (the XOR's high bits move
+// whole groups of 16: a select among the block's groups), fetches their LUT entries in POSITION order -- the XOR's low
+// four bits spread the lanes over 16 rows --, brings the VALUES (not the codes) into sub-quantizer order with a butterfly
+// of conditional swaps on those four bits, and adds them ascending j: the reference's order, hence its bits.  One pass
+// for 64 candidates where the LDS-row form took 64 / refine_rows passes of a 64-step dependent LDS chain each (~3 us a
+// pass); sixteen values live at a time (all 64 at once spilled registers into the scan's tile loop).  Used by the pool
+// mode's drains (64 candidates at a time).  NOT by the short lists' refinement: at k = 100 a wave has ~10 candidates and
+// one LDS-row pass is the faster form; carrying both forms put 25 more scratch reloads into every query's finish of the
+// k <= 248 kernels -- 3 % at C2, 8-15 % on the reference grid's short cells, same box (k = 500: +7 %).  (Not code size:
+// the same kernels without their in-kernel redo, 53 -> 39 KB, run no faster.)
+template <int M, int BASE>
+__device__ __forceinline__ float exact_lane_blocks(const typename scan_layout::Layout<M>::chunk_t (&w)[scan_layout::Layout<M>::kChunks],
+                                                   int idx, const float* __restrict__ lut, float v) {
+  using L = scan_layout::Layout<M>;
+  if constexpr (BASE >= M) {
+    return v;
+  } else {
+    constexpr int S = scan_layout::block_of(M, BASE).size;
+    constexpr int GS = S < 16 ? S : 16;   // sub-quantizers per group
+    constexpr int NG = S / GS;            // groups in the block
+    constexpr int DW = GS / 4;            // dwords per group
+    const int xs = idx & (S - 1);
+    const int xg = xs / GS, xl = xs & (GS - 1);
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      // sub-quantizers BASE + GS q ... + GS - 1 live at positions of group q ^ xg
+      uint32_t cd[DW];
+#pragma unroll
+      for (int t = 0; t < DW; ++t) {
+        cd[t] = L::word(w, BASE / 4 + (q ^ 0) * DW + t);
+#pragma unroll
+        for (int x = 1; x < NG; ++x) cd[t] = (xg == x) ? L::word(w, BASE / 4 + (q ^ x) * DW + t) : cd[t];
+      }
+      float val[GS];
+#pragma unroll
+      for (int p = 0; p < GS; ++p) {
+        const uint32_t c = (cd[p >> 2] >> (8 * (p & 3))) & 255u;
+        // position GS (q ^ xg) + p holds sub-quantizer BASE + GS q + (p ^ xl): lut_dword(M, that, c)
+        val[p] = lut[BASE * 256 + (int)c * S + GS * q + (p ^ xl)];
+      }
+#pragma unroll
+      for (int b = 1; b < GS; b <<= 1) {
+        const bool sw = (xl & b) != 0;
+#pragma unroll
+        for (int p = 0; p < GS; ++p) {
+          if ((p & b) == 0) {
+            const float lo = val[p], hi = val[p | b];
+            val[p] = sw ? hi : lo;
+            val[p | b] = sw ? lo : hi;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < GS; ++j) v += val[j];
+    }
+    return exact_lane_blocks<M, BASE + S>(w, idx, lut, v);
+  }
+}
+template <int M>
+__device__ __forceinline__ float exact_lane(const typename scan_layout::Layout<M>::chunk_t (&w)[scan_layout::Layout<M>::kChunks],
+                                            int idx, const float* __restrict__ lut) {
+  return exact_lane_blocks<M, 0>(w, idx, lut, 0.f);
+}
+
 // phase 2, wave-level: the merged list already carries EXACT values; write the best k and raise
 // the overflow flag when the list is so full of near-ties that a member of the exact top-k may
 // have been evicted from a wave's list (see the header comment of this section)
@@ -1104,7 +1175,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
         return x;
       };
 #pragma unroll 1
-      for (int round = 0; round < 3; ++round) {
+      for (int round = 0; round < (RM == -3 ? 0 : 3); ++round) {
         unsigned my_t = 0;
         if (round == 0) {
           if (lane < NW) my_t = f2key(reinterpret_cast<volatile float*>(wave_q)[lane]);
@@ -1153,14 +1224,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       typename L::chunk_t cw[L::kChunks] = {};
       if (act) L::load(a.packed, a.n_slots, idx, cw);
-      float e = -INFINITY;
-#pragma unroll 1
-      for (int pass = 0; pass * RR < qn; ++pass) {
-        const bool mine = act && ((lane / RR) == pass);
-        const float ep = exact_from_chunks<M>(cw, idx, mine, scratch, lane % RR, LdsLut<M>{lut});
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        e = mine ? ep : e;
-      }
+      const float e = exact_lane<M>(cw, idx, lut);
       ex.insert_unsorted(act ? make_key(e + 0.0f, idx) : pad_key());
       n_out += qn;
       qn = 0;

@@ -92,9 +92,16 @@ static int dispatch_r(const ScanArgs& a, const ResidualArgs& ra, int RL, int R, 
 int TPQ_CAT(dispatch_pool_, TPQ_PACKED_M)(const ScanArgs& a, int RL, hipStream_t st) {
   const bool big = a.pool_cap > 1024;
   switch (RL) {
-    case 1: return big ? launch_pool<1, TPQ_PACKED_M, -2>(a, st) : launch_pool<1, TPQ_PACKED_M, -1>(a, st);
-    case 2: return big ? launch_pool<2, TPQ_PACKED_M, -2>(a, st) : launch_pool<2, TPQ_PACKED_M, -1>(a, st);
-    case 4: return big ? launch_pool<4, TPQ_PACKED_M, -2>(a, st) : launch_pool<4, TPQ_PACKED_M, -1>(a, st);
+    // (-3: the large pool without the counting rounds -- see kPoolRoundsFromK)
+#define TPQ_POOL_CASE(RL)                                                                              \
+  case RL:                                                                                             \
+    return !big ? launch_pool<RL, TPQ_PACKED_M, -1>(a, st)                                             \
+                : (a.k <= kPoolRoundsFromK ? launch_pool<RL, TPQ_PACKED_M, -3>(a, st)                  \
+                                           : launch_pool<RL, TPQ_PACKED_M, -2>(a, st));
+    TPQ_POOL_CASE(1)
+    TPQ_POOL_CASE(2)
+    TPQ_POOL_CASE(4)
+#undef TPQ_POOL_CASE
     default: break;
   }
   set_error("scan_packed (pool mode): no instantiation for %d list registers", RL);
