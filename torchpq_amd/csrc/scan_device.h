@@ -13,6 +13,10 @@ namespace tpq {
 // per 10 000 queries, 0 / 1 / 3 rounds COMPILED IN: k = 600: 4.79 / 5.14 / 5.27, k = 800: 5.19 / 5.50 / 5.68, k = 1000:
 // 6.66 / 6.70 / 6.08; three rounds compiled in and none executed: 5.48 at k = 600 -- hence a kernel of its own, RM = -3)
 constexpr int kPoolRoundsFromK = 900;
+// pool mode from list_regs_packed(k) = 16 on, i.e. k > 504 (from k > 248, same box, ms per 10 000 queries, lists -> pool
+// without rounds: m = 64, k = 300 / 400 / 500: 3.57 / 3.79 / 3.96 -> 3.76 / 3.95 / 4.09; m = 32, k = 400 / 500: 3.73 / 3.97 ->
+// 3.11 / 6.37 (pools of 1 024 overflow); m = 16, k = 500: 2.56 -> 3.01)
+constexpr int kPoolMinListRegs = 16;
 constexpr int kScanWaves = 8;
 constexpr int kScanThreads = kScanWaves * 64;
 
