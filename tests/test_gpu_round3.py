@@ -67,6 +67,9 @@ def _probe_data(kind, d, nq, n_cells, rng):
     (128, 300, 16384, 128, False),   # ... and IVF16384 at its largest n_probe
     (100, 513, 2052, 40, True),      # ragged everywhere: d, queries, cells (a multiple of 4 only)
     (64, 1000, 3000, 1000, False),   # n_probe close to the candidate list's limit
+    (64, 500, 12320, 24, True),      # fp16 route: group maxima of 64 cells, the last group half full
+    (32, 400, 17440, 40, False),     # ... of 128 cells, the last group a quarter full
+    (48, 300, 4128, 64, True),       # ... of 32 cells, 2 n_probe = the number of groups - 1: the direct list's edge
 ])
 @pytest.mark.parametrize("route", ["auto", "fp32", "fp16"])
 def test_coarse_probe_is_bit_exact(K, kind, d, nq, n_cells, n_probe, smart, route):

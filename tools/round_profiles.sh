@@ -21,7 +21,7 @@ python tools/probe_bench.py --n-cells 1024,4096,16384 --n-probe 1,16,32,64,128 >
   done
   echo "]}"
 } > "$OUT/${TAG}_small_batches.json"
-python tools/selection_soak.py --mode probe --cases 240 --seed 11 > "$OUT/${TAG}_soak_probe.json" 2>/dev/null
+python tools/selection_soak.py --mode probe --cases 240 --seed 11 --big > "$OUT/${TAG}_soak_probe.json" 2>/dev/null
 python tools/selection_soak.py --mode cascade --cases 120 --seed 12 > "$OUT/${TAG}_soak_cascade.json" 2>/dev/null
 python tools/build_100m.py > "$OUT/${TAG}_build_100m.json" 2> /dev/null
 tail -3 "$OUT/${TAG}_profile_bench.log"

@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--mode", default="selection", choices=["selection", "cascade", "probe"])
     ap.add_argument("--trace", action="store_true", help="print every case before it runs and synchronise after it")
     ap.add_argument("--only-case", type=int, default=-1, help="cascade mode: run this case alone (same random stream)")
-    ap.add_argument("--big", action="store_true", help="cascade mode: up to 200 000 points x 20 000 centroids")
+    ap.add_argument("--big", action="store_true", help="cascade mode: up to 200 000 points x 20 000 centroids; probe mode: up to 19 168 cells")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     dev = "cuda:0"
