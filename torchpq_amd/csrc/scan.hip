@@ -82,7 +82,7 @@ extern "C" size_t tpq_ivfpq_scan_workspace_bytes(int nq, int k, int n_split, int
   int R = list_regs_packed(k) > list_regs(k) ? list_regs_packed(k) : list_regs(k);
   if (R > 16) R = 16;
   const size_t lists = ws_bytes_for(nq, R, n_split * packed_waves(m));  // covers both kernels
-  const size_t pools = list_regs_packed(k) >= kPoolMinListRegs ? pool_ws_bytes(nq, k, n_split * packed_waves(m)) : 0;  // pool mode
+  const size_t pools = list_regs_packed(k) >= pool_min_list_regs(m) ? pool_ws_bytes(nq, k, m, n_split * packed_waves(m)) : 0;  // pool mode
   return lists > pools ? lists : pools;
 }
 
@@ -255,13 +255,13 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
   // (measured against the sorted lists of the three-launch path, C2 shape, 10 000 queries: m = 64, k = 600 / 1000:
   // 6.1 / 6.9 ms against 7.1 / 8.3; m = 120 (1 000 queries), k = 1000: 2.0 against 3.4 -- and k = 600: 1.9 against 1.6;
   // m = 16, 32: within 2 %; k = 300, 500 at m = 64: 4.1 / 4.5 against 3.6 / 4.0)
-  if (!ra && R >= kPoolMinListRegs && (packed_waves(m) < 16 || k > 768) && fuse_enabled()) {
+  if (!ra && R >= pool_min_list_regs(m) && (packed_waves(m) < 16 || k > 768) && fuse_enabled()) {
     // the largest k, plain PQ: pool mode (scan_device.h) -- threshold lists of ceil(k / waves) entries, unsorted pools,
     // one ranking kernel per query; flagged queries (a pool or the ranking buffer overflowed) redone exactly
     // (the ranking kernel takes a query's lists into LDS: fewer workgroups per query when they would not fit)
     if (a.n_split > pool_max_split(m, k)) a.n_split = pool_max_split(m, k);
     const int n_lists_p = a.n_split * packed_waves(m);
-    rc = need_ws(workspace, workspace_bytes, pool_ws_bytes(nq, k, n_lists_p), "ivfpq_scan_packed");
+    rc = need_ws(workspace, workspace_bytes, pool_ws_bytes(nq, k, m, n_lists_p), "ivfpq_scan_packed");
     if (rc) return rc;
     fill_ws_pool(a, workspace, n_lists_p);
     a.epoch = fresh_epoch();

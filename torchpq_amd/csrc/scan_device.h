@@ -13,10 +13,14 @@ namespace tpq {
 // per 10 000 queries, 0 / 1 / 3 rounds COMPILED IN: k = 600: 4.79 / 5.14 / 5.27, k = 800: 5.19 / 5.50 / 5.68, k = 1000:
 // 6.66 / 6.70 / 6.08; three rounds compiled in and none executed: 5.48 at k = 600 -- hence a kernel of its own, RM = -3)
 constexpr int kPoolRoundsFromK = 900;
-// pool mode from list_regs_packed(k) = 16 on, i.e. k > 504 (from k > 248, same box, ms per 10 000 queries, lists -> pool
-// without rounds: m = 64, k = 300 / 400 / 500: 3.57 / 3.79 / 3.96 -> 3.76 / 3.95 / 4.09; m = 32, k = 400 / 500: 3.73 / 3.97 ->
-// 3.11 / 6.37 (pools of 1 024 overflow); m = 16, k = 500: 2.56 -> 3.01)
+// pool mode from list_regs_packed(k) = 16 on, i.e. k > 504 (eight waves, from k > 248 with pools of 1 024 and no rounds,
+// same box, ms per 10 000 queries, lists -> pool: m = 64, k = 300 / 400 / 500: 3.57 / 3.79 / 3.96 -> 3.76 / 3.95 / 4.09)
 constexpr int kPoolMinListRegs = 16;
+// ... and, with four waves per workgroup (m <= 32), from list_regs_packed(k) = 8 on (k > 248, where the fused finish of the
+// sorted lists ends): lists -> pools of 2 048 without rounds, same box, ms per 10 000 queries: m = 32, k = 300 / 400 / 500:
+// 3.49 / 3.72 / 3.96 -> 2.67 / 2.83 / 2.97; m = 16, k = 300 / 500: 2.27 / 2.55 -> 1.65 / 1.82; m = 8, k = 400: 2.32 -> 1.45;
+// IVF4096 cells, m = 32, k = 400: 3.33 -> 1.99.  (k <= 248 stays with the lists: m = 32, k = 248: 2.04 against 2.40.)
+static int pool_min_list_regs(int m) { return m <= 32 ? 8 : kPoolMinListRegs; }
 constexpr int kScanWaves = 8;
 constexpr int kScanThreads = kScanWaves * 64;
 
@@ -797,7 +801,7 @@ constexpr int packed_aux_bytes(int /*R*/, int M) {
 // workgroup.  One launch instead of three (scan, scan_merge_refine_kernel, the flagged redo): at one query
 // the two extra launches were 25 of 64 us.  RM = registers of the merged list (list_regs_packed(k)).
 //
-// RM < 0 ("pool mode", k > 504, plain PQ; scan.hip holds the rule): folding 64 candidates into a sorted list of k + 8 (or even 2k / NW)
+// RM < 0 ("pool mode", k > 504 -- k > 248 at m <= 32 --, plain PQ; scan.hip holds the rule): folding 64 candidates into a sorted list of k + 8 (or even 2k / NW)
 // entries is what made large k slow -- at k = 1000 the tile loop ran 275 us per query against 106 at k = 100.
 // Here the sorted per-wave list (R registers) only serves the ADMISSION THRESHOLD: it holds the wave's
 // ceil(k / NW) best (bound (b) below needs no more), and every admitted candidate is also appended to an
@@ -1714,8 +1718,10 @@ static int pool_list_regs(int k, int m) {
   const int nw = packed_waves(m);
   return pow2_ceil(((k + nw - 1) / nw + 63) / 64);
 }
-static int pool_capacity(int k) { return k <= 512 ? 1024 : 2048; }  // (16 / 32 registers per lane at read-back)
-static size_t pool_ws_bytes(int nq, int k, int n_lists);
+static int pool_capacity(int k, int m) {  // (16 / 32 registers per lane at read-back; four waves share a query's admissions)
+  return (k <= 512 && m > 32) ? 1024 : 2048;
+}  // (16 / 32 registers per lane at read-back)
+static size_t pool_ws_bytes(int nq, int k, int m, int n_lists);
 
 static size_t scan_lds_bytes_ref(int m, int R, int max_nprobe, int fused_floats) {
   const int lut_bytes = m * 1024;
@@ -1772,8 +1778,8 @@ static size_t ws_bytes_for(int nq, int R, int n_lists) {
 }
 
 // pool mode workspace: [flags][delta][pool hi nq*n_lists*cap][pool lo ...][counts nq*n_lists]
-static size_t pool_ws_bytes(int nq, int k, int n_lists) {
-  return 2 * align256((size_t)nq * 4) + (size_t)nq * n_lists * pool_capacity(k) * 8 +
+static size_t pool_ws_bytes(int nq, int k, int m, int n_lists) {
+  return 2 * align256((size_t)nq * 4) + (size_t)nq * n_lists * pool_capacity(k, m) * 8 +
          align256((size_t)nq * n_lists * 4);
 }
 static void fill_ws_pool(ScanArgs& a, void* workspace, int n_lists) {
@@ -1781,7 +1787,7 @@ static void fill_ws_pool(ScanArgs& a, void* workspace, int n_lists) {
   a.flags = reinterpret_cast<int*>(p);
   a.ws_delta = reinterpret_cast<float*>(p + align256((size_t)a.nq * 4));
   char* pools = p + 2 * align256((size_t)a.nq * 4);
-  a.pool_cap = pool_capacity(a.k);
+  a.pool_cap = pool_capacity(a.k, a.m);
   const size_t n = (size_t)a.nq * n_lists * a.pool_cap;
   a.pool_hi = reinterpret_cast<unsigned*>(pools);
   a.pool_lo = reinterpret_cast<unsigned*>(pools + n * 4);
