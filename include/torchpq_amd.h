@@ -242,8 +242,9 @@ int tpq_ivfpq_coarse_probe(const float* query, const float* centroids,
  * rigorous error bound around the n_probe-th best, and the fp32 chain's own value for every candidate (d <= 128,
  * n_cells % 32 == 0; other shapes take the fp32 kernels on every route).
  *   TPQ_PROBE_ROUTE_AUTO  what tpq_ivfpq_coarse_probe does: the fp16 selection from 2 048 cells on (batches of more
- *                         than 256 queries, n_probe <= 112) and from 1 024 cells on for batches of >= 4 096 queries with
- *                         n_probe <= 32, the fp32 kernels otherwise
+ *                         than 256 queries; n_probe <= 112, or up to half the number of cell groups the pass keeps
+ *                         maxima of -- 128 probes of 16 384 cells) and from 1 024 cells on for batches of >= 4 096
+ *                         queries with n_probe <= 32, the fp32 kernels otherwise
  *   TPQ_PROBE_ROUTE_FP32  the fp32-MFMA similarity kernels
  *   TPQ_PROBE_ROUTE_FP16  the fp16 selection whenever the shape allows it
  * workspace: tpq_ivfpq_coarse_probe_route_workspace_bytes(d, nq, n_cells, route). */

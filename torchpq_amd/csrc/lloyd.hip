@@ -2963,6 +2963,7 @@ struct ProbeLayout {
   int xt_stride;
   size_t prep_off, flag_off, sims_off, gmax_off, band_off, qscale_off, q2_off, xt_off, prepared_off, total;
 };
+static int probe_gshift(int n_cells) { return n_cells <= 8192 ? 5 : (n_cells <= 16384 ? 6 : 7); }
 static ProbeLayout probe_layout(int d, int nq, int n_cells) {
   ProbeLayout L;
   L.C = probe_prepared_layout(d, n_cells);
@@ -2970,7 +2971,7 @@ static ProbeLayout probe_layout(int d, int nq, int n_cells) {
   L.P = prep_layout(1, 16 * L.KS, nq);
   // group maxima: of 32 cells up to 8 192 cells, of 64 up to 16 384 (<= 256 groups, which the select prefetches whole;
   // its direct list needs 2 n_probe <= groups), of 128 beyond
-  L.gshift = n_cells <= 8192 ? 5 : (n_cells <= 16384 ? 6 : 7);
+  L.gshift = probe_gshift(n_cells);
   L.n_groups = (n_cells + (1 << L.gshift) - 1) >> L.gshift;
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   L.prep_off = 0;
@@ -3067,6 +3068,10 @@ static int run_probe_sims(const float* query, const char* prepared, int d, int n
 int lloyd_probe_supported(int d, int nq, int n_cells) {
   if (!(d >= 1 && d <= 128 && nq >= 1 && n_cells >= 256 && (n_cells & 31) == 0 && n_cells <= (1 << 22))) return 0;
   return (int64_t)nq * n_cells < (1LL << 36) ? 1 : 0;
+}
+int lloyd_probe_groups(int n_cells) {
+  const int gs = lloyd::probe_gshift(n_cells);
+  return (n_cells + (1 << gs) - 1) >> gs;
 }
 size_t lloyd_probe_workspace_bytes(int d, int nq, int n_cells) {
   return lloyd_probe_supported(d, nq, n_cells) ? lloyd::probe_layout(d, nq, n_cells).total : 0;

@@ -26,6 +26,8 @@ struct ProbeFastBuffers {
   int gshift;            // log2 of the cells per group (5 or 7)
 };
 int lloyd_probe_supported(int d, int nq, int n_cells);
+// groups of cells whose maxima the fast pass keeps (32 cells up to 8 192, 64 up to 16 384, 128 beyond)
+int lloyd_probe_groups(int n_cells);
 size_t lloyd_probe_workspace_bytes(int d, int nq, int n_cells);
 // the part that depends on the centroids alone (mean, scale, fp16 fragments, row copies, |C|^2): once per codebook
 size_t lloyd_probe_prepared_bytes(int d, int n_cells);

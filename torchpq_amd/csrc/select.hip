@@ -902,7 +902,10 @@ static bool probe_fast_route(int d, int nq, int n_cells, int n_probe, int route)
   if (route == TPQ_PROBE_ROUTE_FP16) return true;
   // (beyond 112 probes the candidate list takes four registers per lane and the fast select's folds cost more than
   // the fp32 GEMM saves: 16 384 cells, 128 probes: 1.15 ms against 0.83; 64 probes: 0.38 against 0.67)
-  if (n_cells >= kProbeFastMinCells) return nq > kProbeSmallMaxQ && n_probe <= 112;
+  // ... unless the direct candidate list applies (2 n_probe <= groups of cells: 16 384 cells in 256 groups, 128 probes:
+  // 0.41 ms against 0.77)
+  if (n_cells >= kProbeFastMinCells)
+    return nq > kProbeSmallMaxQ && (n_probe <= 112 || 2 * n_probe <= lloyd_probe_groups(n_cells));
   // (1 024 cells, 10 000 queries: 0.054-0.079 ms against 0.082-0.090 up to 32 probes; 1 000 queries: 0.035 against 0.025)
   return n_cells >= 1024 && nq >= 4096 && n_probe <= 32;
 }
