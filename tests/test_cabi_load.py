@@ -56,6 +56,31 @@ def test_ticket_and_route_entry_points_validate():
     assert rc == -1 and "null pointer" in _lib.last_error()
 
 
+def test_coarse_probe_workspace_and_prepared_sizes():
+    """host arithmetic only: the fp16 selection pass stores its fast matrix as fp16 (2 bytes per pair) plus row copies,
+    group maxima and the per-query scalars; shapes it does not serve (d > 128, cells not a multiple of 32) size the
+    fp32 route on every route and have no prepared block"""
+    from torchpq_amd import _lib
+    lib = _lib.load()
+    nq, d = 10000, 128
+    for n_cells in (1024, 4096, 16384, 32768):
+        fp32 = lib.tpq_ivfpq_coarse_probe_route_workspace_bytes(d, nq, n_cells, _lib.PROBE_ROUTE_FP32)
+        fp16 = lib.tpq_ivfpq_coarse_probe_route_workspace_bytes(d, nq, n_cells, _lib.PROBE_ROUTE_FP16)
+        auto = lib.tpq_ivfpq_coarse_probe_route_workspace_bytes(d, nq, n_cells, _lib.PROBE_ROUTE_AUTO)
+        assert fp32 >= nq * n_cells * 4                       # the fp32 similarity matrix
+        assert fp16 >= fp32 and auto == fp16                   # (a workspace sized for a route serves the fp32 one too)
+        assert lib.tpq_ivfpq_coarse_probe_workspace_bytes(nq, n_cells) == auto
+        prepared = lib.tpq_ivfpq_coarse_probe_prepared_bytes(d, n_cells)
+        assert prepared >= n_cells * d * 4                     # at least the row copies of the centroids
+        # what the fp16 pass itself needs beyond the prepared block: fp16 matrix + row copies + pieces -- well under
+        # the fp32 matrix it replaces
+        assert nq * n_cells * 2 <= fp16 - 0 and (fp16 - prepared) < fp32 + nq * d * 16
+    for bad_d, bad_cells in ((960, 4096), (128, 4100), (128, 128)):
+        assert lib.tpq_ivfpq_coarse_probe_prepared_bytes(bad_d, bad_cells) == 0
+        assert (lib.tpq_ivfpq_coarse_probe_route_workspace_bytes(bad_d, 1000, bad_cells, _lib.PROBE_ROUTE_FP16)
+                == lib.tpq_ivfpq_coarse_probe_route_workspace_bytes(bad_d, 1000, bad_cells, _lib.PROBE_ROUTE_FP32))
+
+
 def test_argument_validation_without_a_gpu():
     """Validation happens before any HIP call, so it can be exercised on the CPU box."""
     from torchpq_amd import _lib
