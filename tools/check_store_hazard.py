@@ -1,16 +1,18 @@
 #!/usr/bin/env python
 """Look for the store-data overwrite pattern in the compiled kernels.
 
-Measured on gfx950 (round 4, probe_sims_kernel): a 16-byte buffer store whose data registers are overwritten by
-a VALU instruction two instructions later -- the distance hipcc's hazard recognizer leaves (its rule for stores
-of more than 8 bytes is a wait of two) -- stored the NEW value in 9 % of the rows of a 10 000 x 4 096 matrix;
-with the overwrite further away (or an s_nop after the store) the rows were right every time.  This tool
+Measured on gfx950 (round 4, probe_sims_kernel): a 16-byte buffer store whose first data register a VALU
+instruction overwrote three instructions later -- hipcc's own schedule -- stored the NEW value in 9 % of the rows
+of a 10 000 x 4 096 matrix; with the overwrite further away (or an s_nop after the store) the rows were right every
+time.  (In isolation -- tools/experiments/store_hazard -- only distances of one and two instructions reproduce
+it; the spill stores and assign_prep_kernel's stores this tool lists at distance three are clean in their soaks.)  This tool
 compiles each translation unit to assembly and lists every store of more than 8 bytes whose data registers a
 vector instruction writes within --window instructions (default 3) of the store, in straight-line code.
 
     python tools/check_store_hazard.py [--window 3] [unit.hip ...]
 
-Exit status 1 when a hit is found (kernels that have one carry an explicit pad; see TPQ_STORE_PAD).
+Exit status 1 when a hit is found: a list to look at, not a verdict (probe_sims_kernel carries an explicit pad,
+TPQ_STORE_PAD).
 """
 import argparse
 import os
@@ -68,6 +70,11 @@ def check(path, window, extra):
         subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + extra + [path, "-o", out],
                               stderr=subprocess.DEVNULL)
         lines = open(out).read().splitlines()
+    return scan_lines(lines, window)
+
+
+def scan_lines(lines, window):
+    """the hits in one assembly listing: (kernel, line number, store, distance, overwriting instruction)"""
     hits = []
     kernel = "?"
     pending = []  # (data regs, instructions seen since, store text, line number)
