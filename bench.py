@@ -27,6 +27,7 @@ under the key "secondary" of the same JSON line, each with its own roofline:
   c3           GIST1M-shaped search() (d=960, m=120, n_probe=64, 1000 queries)
   c4           100 M-slot scan (n_cells=16384, m=64, n_probe=64; 6.4 GB of codes: the DRAM test)
   c5           MultiKMeans assign / update per Lloyd iteration (64 x 64 x 1 M, k=256)
+  c1           configs[0]: the oracle's CPU train / add / search beside the same index on the GPU
 """
 from __future__ import annotations
 
@@ -61,7 +62,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix-core peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix-core peak (MI355X_MICROARCH.md; not the 2:1-sparsity figure)
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 
 # ---------------------------------------------------------------------------------------------
@@ -202,41 +203,97 @@ def scanned_bytes(idx, queries, m):
     return tot * m
 
 
-def time_search(idx, queries, k, steps, warmup, dist=None):
+def time_search(idx, queries, k, steps, warmup, barrier=None):
     """W untimed + K timed search() calls, barrier + synchronize on both sides; (wall seconds,
-    mean scan-kernel ms from HIP events on the launch stream, last result)"""
+    mean scan-kernel ms per step from HIP events on the launch stream, query batches per step,
+    last result, per-step statistics of the scan kernel)"""
     scan = idx._ivfpq_topk._scan
     for _ in range(warmup):
         idx.search(queries, k=k)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    if barrier is not None:
+        barrier()
     scan.record_events = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         vals, ids = idx.search(queries, k=k)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    if barrier is not None:
+        barrier()
     dt = time.perf_counter() - t0
     events = scan.record_events
     scan.record_events = None
     nb = max(1, len(events) // max(steps, 1))  # query batches per search() call
-    scan_ms = float(np.sum([a.elapsed_time(b) for a, b in events])) / max(steps, 1) if events else float("nan")
-    return dt, scan_ms, nb, vals, ids
+    per_launch = [a.elapsed_time(b) for a, b in events]
+    scan_ms = float(np.sum(per_launch)) / max(steps, 1) if events else float("nan")
+    per_step = [float(np.sum(per_launch[i * nb:(i + 1) * nb])) for i in range(len(per_launch) // nb)]
+    stats = {"n_split": scan.last_n_split, "queries_redone_exactly": None}
+    if per_step:
+        med = float(np.median(per_step))
+        # one slow step (a clock dip, a page fault, another tenant) must be visible as such, not
+        # averaged into the rate: the mean stays the quoted figure, the spread goes on the record
+        stats.update({"kernel_ms_median": round(med, 4), "kernel_ms_min": round(min(per_step), 4),
+                      "kernel_ms_max": round(max(per_step), 4),
+                      "steps_slower_than_1p3x_median": int(sum(t > 1.3 * med for t in per_step))})
+    # queries that took the in-kernel exact redo (the candidate band overflowed): one more,
+    # untimed, search with the workspace kept.  Defined for the one-launch finish only
+    # (k <= 248, one workgroup per query); "slow and normally never taken" -- here it is counted.
+    if k <= 248 and scan.last_n_split == 1 and nb == 1 and not idx.pq_use_residual:
+        scan.keep_workspace = True
+        try:
+            idx.search(queries, k=k)
+            torch.cuda.synchronize()
+            stats["queries_redone_exactly"] = scan.last_redone(queries.shape[1])
+        finally:
+            scan.keep_workspace = False
+            scan.last_workspace = None
+    return dt, scan_ms, nb, vals, ids, stats
 
 
-def hbm_roofline(algo_bytes, kernel_ms, kernel, stream_peak=None, **extra):
+INFINITY_CACHE_BYTES = 256 << 20  # MI355X_MICROARCH.md: 256 MiB MALL in front of the HBM stacks
+
+
+def hbm_roofline(algo_bytes, kernel_ms, kernel, stream_peak=None, resident_bytes=None, stats=None, **extra):
+    """`frac` per SURVEY 8(d): algorithmic bytes / kernel time / 8 TB/s.  `fed_by` names the level that
+    can have fed it: an array that fits the 256 MiB Infinity Cache is served from there across steps
+    (its rate may exceed the DRAM stream peak and says nothing about HBM); the DRAM evidence is the
+    100 M-slot workload (c4)."""
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
     r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": kernel,
          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes)}
+    if resident_bytes is not None:
+        r["code_bytes_resident"] = int(resident_bytes)
+        r["fed_by"] = "infinity_cache" if resident_bytes <= INFINITY_CACHE_BYTES else "hbm"
     if stream_peak:
         r["stream_peak"] = round(stream_peak, 1)
         r["frac_of_stream_peak"] = round(achieved / stream_peak, 4)
+    if stats:
+        r.update(stats)
     r.update(extra)
     return r
+
+
+def cross_check_profile(roofline, name, kernel_prefix):
+    """the tracked rocprofv3 --kernel-trace --stats summary of the same workload: its average duration
+    of the dominant kernel must agree with this run's HIP-event figure; > 10 % apart is flagged on the
+    line itself (`profile_mismatch`), so a record and the profile quoted for it cannot silently differ"""
+    prof = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{name}.json")
+    try:
+        pj = json.load(open(prof))
+        rows = [k for k in pj.get("kernels", []) if kernel_prefix in k["name"]]
+        if not rows:
+            return
+        top = max(rows, key=lambda k: k["avg_us"] * k["calls"])
+        launches = max(1, int(roofline.get("launches_per_step", 1)))
+        roofline["kernel_ms_profile"] = round(top["avg_us"] * launches / 1e3, 4)
+        roofline["kernel_ms_profile_source"] = f"profiles/{PROFILE_TAG}_{name}.json ({top['calls']} calls)"
+        roofline["profile_mismatch"] = bool(
+            abs(roofline["kernel_ms"] / roofline["kernel_ms_profile"] - 1.0) > 0.10)
+    except Exception as e:  # a missing / malformed summary must not break the bench line
+        roofline["kernel_ms_profile"] = None
+        roofline["profile_note"] = f"{type(e).__name__}: {e}"[:200]
 
 
 def source_fingerprint():
@@ -349,7 +406,7 @@ def cpu_baseline(idx, queries, k, n_sample):
 # ---------------------------------------------------------------------------------------------
 # secondary pass: BASELINE.json configs[2..4] + the box's stream peak (N=1, rank 0, time-boxed)
 # ---------------------------------------------------------------------------------------------
-def secondary_c3(device, stream_peak, steps=10):
+def secondary_c3(device, stream_peak, steps=20):
     """configs[2]: GIST1M-shaped index built through train/add on synthetic d=960 data in [0,1]"""
     from torchpq_amd.index import IVFPQIndex
     d, m, n_cells, n, nq, n_probe, k = 960, 120, 1024, 1_000_000, 1000, 64, 100
@@ -379,14 +436,15 @@ def secondary_c3(device, stream_peak, steps=10):
     t_add = time.time() - t0
     idx.n_probe, idx.use_smart_probing = n_probe, False
     queries = sample(nq)
-    dt, scan_ms, _, vals, ids = time_search(idx, queries, k, steps, 2)
+    dt, scan_ms, nb, vals, ids, stats = time_search(idx, queries, k, steps, 3)
     algo = scanned_bytes(idx, queries, m)
     return {"workload": f"GIST1M-like d={d} n={n} IVFPQ n_cells={n_cells} m={m} nprobe={n_probe} k={k}, "
                         f"{nq} queries, search() end to end",
             "value": round(nq * steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / steps * 1e3, 4),
             "train_s": round(t_train, 2), "add_s": round(t_add, 2),
-            "roofline": hbm_roofline(algo, scan_ms, "scan_packed_kernel<.,120,.> + merge", stream_peak,
-                                     bytes_per_query=round(algo / nq, 1))}
+            "roofline": hbm_roofline(algo, scan_ms, "scan_packed_kernel<1,120,false,2> (one launch: scan + merge + "
+                                     "write)", stream_peak, resident_bytes=idx._storage.numel(), stats=stats,
+                                     launches_per_step=nb, bytes_per_query=round(algo / nq, 1))}
 
 
 def secondary_c4(device, stream_peak, steps=5):
@@ -397,13 +455,103 @@ def secondary_c4(device, stream_peak, steps=5):
     g = torch.Generator(device=device)
     g.manual_seed(4236)
     queries = torch.randn(d, nq, generator=g, device=device)
-    dt, scan_ms, _, vals, ids = time_search(idx, queries, k, steps, 1)
+    dt, scan_ms, nb, vals, ids, stats = time_search(idx, queries, k, steps, 1)
     algo = scanned_bytes(idx, queries, m)
     return {"workload": f"synthetic codes d={d} n={n} IVFPQ n_cells={n_cells} m={m} nprobe={n_probe} k={k}, "
                         f"{nq} queries per GPU, search() end to end (coarse probe + fused LUT + scan)",
             "value": round(nq * steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / steps * 1e3, 4),
-            "code_bytes_resident": int(idx._storage.numel()),
-            "roofline": hbm_roofline(algo, scan_ms, "scan_packed_kernel<1,64,false> + merge", stream_peak,
+            "roofline": hbm_roofline(algo, scan_ms, "scan_packed_kernel<1,64,false,2> (one launch: scan + merge + "
+                                     "write)", stream_peak, resident_bytes=idx._storage.numel(), stats=stats,
+                                     launches_per_step=nb, bytes_per_query=round(algo / nq, 1))}
+
+
+def secondary_c1(device, stream_peak):
+    """configs[0] ("plumbing, no GPU"): d=128 n=100k n_cells=256 m=16 n_probe=8 k=10, x ~ N(0,1)
+    (SURVEY 8d).  CPU leg = the ORACLE's train / add / search -- the restated reference CPU path
+    (KMeans.fit + get_labels + compute_centroids, clustering/KMeans.py:323-438; CellContainer.add,
+    container/CellContainer.py:313-367; the search restatement) -- timed on the host cores.  GPU leg =
+    that very index (the oracle's codebooks, codes and cell table, loaded through load_state_dict) searched
+    by IVFPQIndex.search(), ids / values compared; and the same data trained / added / searched by the
+    GPU path for the rates."""
+    from oracle import c_oracle
+    from oracle import ivfpq_oracle as orc
+    from torchpq_amd.index import IVFPQIndex
+    d, n, nq, n_cells, m, n_probe, k = 128, 100_000, 1000, 256, 16, 8, 10
+    cores = os.cpu_count() or 1
+    g = torch.Generator()
+    g.manual_seed(0)
+    x = torch.randn(d, n, generator=g).numpy()
+    q = torch.randn(d, nq, generator=g).numpy()
+
+    def assign(a, b):
+        return c_oracle.max_sim(a, b, "euclidean", "direct", n_threads=cores)
+
+    # ---- CPU leg (the oracle) ----
+    np.random.seed(0)
+    t0 = time.time()
+    vq, _, _, vq_steps = orc.kmeans_fit_redo(x[None], None, 1, 15, 1e-4, n_cells, assign=assign)
+    xs = np.ascontiguousarray(x.reshape(m, d // m, n))
+    pq, _, _, pq_steps = orc.kmeans_fit_redo(xs, None, 1, 25, 1e-4, 256, assign=assign)
+    t1 = time.time()
+    cells = assign(x[None], vq)[1][0]
+    codes = assign(xs, pq)[1].astype(np.uint8)
+    cont = orc.ContainerState(code_size=m, n_cells=n_cells, initial_size=2 * n // n_cells)
+    cont.add(codes, cells)
+    t2 = time.time()
+    cv, ci, _, _, _ = orc.search(q, vq[0], pq, cont.storage, cont.is_empty, cont.cell_start, cont.cell_size,
+                                 cont.address2id, k, n_probe, use_smart_probing=False,
+                                 scan_fn=lambda *a: c_oracle.scan_topk(*a, n_threads=cores))
+    t3 = time.time()
+
+    # ---- GPU leg 1: the oracle-built index searched by the HIP path ----
+    idx = IVFPQIndex(d_vector=d, n_subvectors=m, n_cells=n_cells, initial_size=1, device=str(device))
+    sd = idx.state_dict()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    new = {"_storage": dev(cont.storage), "_cell_start": dev(cont.cell_start), "_cell_size": dev(cont.cell_size),
+           "_cell_capacity": dev(cont.cell_capacity), "_is_empty": dev(cont.is_empty),
+           "_address2id": dev(cont.address2id),
+           "vq_codec._is_trained": torch.tensor(True, device=device),
+           "pq_codec._is_trained": torch.tensor(True, device=device),
+           "vq_codec.kmeans.centroids": dev(vq[0]), "pq_codec.kmeans.centroids": dev(pq)}
+    for key in set(sd) - set(new):
+        new[key] = sd[key]
+    idx.load_state_dict(new)
+    idx.n_probe, idx.use_smart_probing = n_probe, False
+    xq = dev(q)
+    dt, scan_ms, _, gv, gi, stats = time_search(idx, xq, k, 20, 3)
+    gv, gi = gv.cpu().numpy(), gi.cpu().numpy()
+    ids_equal = float((gi == ci).mean())
+    finite = np.isfinite(cv)
+    val_err = float(np.max(np.abs(gv[finite] - cv[finite]) / np.maximum(np.abs(cv[finite]), 1e-30))) if finite.any() else 0.0
+
+    # ---- GPU leg 2: the same data through the GPU train / add (rates only: training is not bit-reproducible) ----
+    np.random.seed(0)
+    xg = dev(x)
+    idx2 = IVFPQIndex(d_vector=d, n_subvectors=m, n_cells=n_cells, initial_size=2 * n // n_cells, device=str(device))
+    torch.cuda.synchronize()
+    g0 = time.time()
+    idx2.train(xg)
+    torch.cuda.synchronize()
+    g1 = time.time()
+    idx2.add(xg)
+    torch.cuda.synchronize()
+    g2 = time.time()
+    algo = scanned_bytes(idx, xq, m)
+    return {"workload": f"d={d} n={n} IVFPQ n_cells={n_cells} m={m} nprobe={n_probe} k={k}, {nq} queries, x ~ N(0,1) "
+                        "(BASELINE.json configs[0])",
+            "cpu": {"kind": "port", "cores": cores, "train_s": round(t1 - t0, 3), "add_s": round(t2 - t1, 3),
+                    "search_s": round(t3 - t2, 3), "search_queries_per_s": round(nq / (t3 - t2), 1),
+                    "kmeans_steps": {"vq": vq_steps, "pq": pq_steps},
+                    "what": "oracle/: kmeans_fit_redo (VQ 15 / PQ 25 iterations, direct -(a-b)^2 assign in C/OpenMP, "
+                            "numpy update), max_sim encode, ContainerState.add, search (numpy coarse + C/OpenMP scan)"},
+            "gpu": {"search_queries_per_s": round(nq * 20 / dt, 1), "ms_per_step": round(dt / 20 * 1e3, 4),
+                    "train_s": round(g1 - g0, 3), "add_s": round(g2 - g1, 3),
+                    "what": "IVFPQIndex.search() on the oracle-built index (load_state_dict); train/add of the same "
+                            "data by the GPU path"},
+            "value": round(nq * 20 / dt, 1), "unit": "queries/s",
+            "ids_equal_to_oracle": round(ids_equal, 6), "values_max_rel_diff_vs_oracle": val_err,
+            "roofline": hbm_roofline(algo, scan_ms, "scan_packed_kernel<.,16,.>", stream_peak,
+                                     resident_bytes=idx._storage.numel(), stats=stats,
                                      bytes_per_query=round(algo / nq, 1))}
 
 
@@ -552,7 +700,8 @@ def secondary_pass(device, budget_s, only=None):
     except Exception as e:
         sp = None
         out["stream_peak"] = {"error": repr(e)[:300]}
-    for name, fn in (("c4", secondary_c4), ("c3", secondary_c3), ("c5", secondary_c5), ("wide", secondary_wide)):
+    for name, fn in (("c4", secondary_c4), ("c3", secondary_c3), ("c5", secondary_c5), ("wide", secondary_wide),
+                     ("c1", secondary_c1)):
         if only and name not in only:
             continue
         if time.time() - t_start > budget_s:
@@ -561,11 +710,14 @@ def secondary_pass(device, budget_s, only=None):
         t0 = time.time()
         try:
             free, _ = torch.cuda.mem_get_info()
-            if free < 48 * 2 ** 30:
+            if name != "c1" and free < 48 * 2 ** 30:
                 out[name] = {"skipped": f"needs ~40 GB of HBM, {free >> 30} GiB free"}
                 continue
             out[name] = fn(device, sp)
             attach_traffic(out[name]["roofline"], name)
+            prefix = {"c3": "scan_packed_kernel<1, 120", "c4": "scan_packed_kernel<1, 64"}.get(name)
+            if prefix:
+                cross_check_profile(out[name]["roofline"], name, prefix)
         except Exception as e:
             out[name] = {"error": repr(e)[:300]}
         out[name]["wall_s"] = round(time.time() - t0, 1)
@@ -624,8 +776,12 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--secondary-only", default=None, help="comma list of c3,c4,c5,wide (profiling)")
+    ap.add_argument("--secondary-only", default=None, help="comma list of c1,c3,c4,c5,wide (profiling)")
     ap.add_argument("--secondary-budget", type=float, default=60.0)
+    ap.add_argument("--dist-timeout", type=float, default=300.0,
+                    help="N > 1: timeout of the process groups (rendezvous, RCCL probe, broadcast)")
+    ap.add_argument("--deadline", type=float, default=900.0,
+                    help="N > 1: seconds after which rank 0 prints a JSON line with `error` and every rank exits")
     args = ap.parse_args(argv)
     c4 = args.workload == "c4"
     args.n_base = args.n_base or (100_000_000 if c4 else 1_000_000)
@@ -634,34 +790,76 @@ def parse_args(argv=None):
     return args
 
 
+def error_line(args, world, msg):
+    """what rank 0 prints when the distributed run cannot complete: ONE JSON line, never a hang"""
+    return json.dumps({"metric": "queries/sec + recall@100, SIFT1M IVFPQ d=128 m=64 nprobe=32", "value": None,
+                       "unit": "queries/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                       "error": msg[:600], "world_size_seen": world})
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
-
-    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    done = {"ok": False}
+    if world > 1:
+        # deadline: a collective that never returns (a dead peer, a transport that hangs) must end in one JSON
+        # line with `error`, not in the driver's own timeout
+        import threading
+
+        def deadline():
+            time.sleep(args.deadline)
+            if not done["ok"]:
+                if rank == 0:
+                    print(error_line(args, world, f"deadline of {args.deadline:.0f} s passed (stage: "
+                                                  f"{done.get('stage', '?')})"), flush=True)
+                os._exit(3)
+        threading.Thread(target=deadline, daemon=True).start()
+    try:
+        run(args, world, rank, done)
+        done["ok"] = True
+    except BaseException as e:  # noqa: BLE001
+        if isinstance(e, SystemExit) and not e.code:
+            return
+        if world == 1:
+            raise
+        import traceback
+        traceback.print_exc()
+        if rank == 0:
+            print(error_line(args, world, f"stage {done.get('stage', '?')}: {type(e).__name__}: {e}"), flush=True)
+        done["ok"] = True
+        os._exit(4)   # (not sys.exit: a half-dead process group must not block interpreter shutdown)
+
+
+def run(args, world, rank, done):
+    import torch.distributed as dist
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     # TPQ_BENCH_ONE_DEVICE=1 is a validation hook for 1-GPU boxes: every rank uses cuda:0 and the
-    # rendezvous runs over gloo (RCCL refuses two ranks on one device); never set by the driver
+    # bulk plane stays on gloo (RCCL refuses two ranks on one device); never set by the driver.
+    # TPQ_BENCH_FAIL_RCCL=1 (same hook family): the RCCL probe raises, as a broken transport would
     one_device = os.environ.get("TPQ_BENCH_ONE_DEVICE", "0") == "1"
     if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    backend = None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "gloo" if one_device else "nccl"
-        if one_device:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=device)
-
     from torchpq_amd import distributed as tpd
     from torchpq_amd.index import IVFPQIndex
+    backend, groups, barrier = None, None, None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        done["stage"] = "rendezvous (gloo control plane) + RCCL probe"
+        probe = create = None
+        if os.environ.get("TPQ_BENCH_FAIL_RCCL", "0") == "1":
+            def probe(_group):
+                raise RuntimeError("TPQ_BENCH_FAIL_RCCL=1 (validation hook)")
+            create = lambda: None  # noqa: E731
+        groups = tpd.init_groups(device, want_rccl=(not one_device) or probe is not None,
+                                 timeout_s=args.dist_timeout, probe=probe, create=create)
+        backend = groups.bulk_backend
+        barrier = tpd.host_barrier
 
     # ---- secondary pass first (N=1 only): it needs the HBM the headline index does not -------
     secondary, stream_peak = None, None
@@ -700,12 +898,14 @@ def main():
                          device=str(device))
     t_bcast, bcast_bytes = 0.0, 0
     if world > 1:
+        done["stage"] = f"index broadcast over {backend}"
         torch.cuda.synchronize()
-        dist.barrier()
+        barrier()
         t0 = time.time()
-        tpd.replicate_index(idx, src=0)  # the one collective: RCCL broadcast at load
+        # the one collective: the index buffers, <= 1 GiB per call, over RCCL (gloo when the probe failed)
+        tpd.replicate_index(idx, src=0, bulk_group=groups.bulk)
         torch.cuda.synchronize()
-        dist.barrier()
+        barrier()
         t_bcast = time.time() - t0
         bcast_bytes = int(getattr(idx, "replicated_bytes", 0))
     idx.n_probe = args.n_probe
@@ -729,15 +929,16 @@ def main():
     def timed(mode):
         """K timed steps in `mode`: (max-over-ranks seconds, per-rank seconds, scan ms, results, queries)"""
         q = make_queries(mode)
-        dt_, scan_ms_, _, v_, i_ = time_search(idx, q, args.k, args.steps, args.warmup,
-                                               dist if world > 1 else None)
+        done["stage"] = f"timed region ({mode} scaling)"
+        dt_, scan_ms_, nb_, v_, i_, stats_ = time_search(idx, q, args.k, args.steps, args.warmup, barrier)
+        stats_["launches_per_step"] = nb_
         per_rank = [dt_]
-        if world > 1:
-            t = torch.tensor([dt_], device=device, dtype=torch.float64)
+        if world > 1:  # (control plane: CPU tensors over gloo)
+            t = torch.tensor([dt_], dtype=torch.float64)
             allt = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(allt, t)
             per_rank = [float(x.item()) for x in allt]
-        return max(per_rank), per_rank, scan_ms_, v_, i_, q
+        return max(per_rank), per_rank, scan_ms_, v_, i_, q, stats_
 
     def mode_summary(mode, dt_, per_rank):
         total_q = args.nq * (world if mode == "weak" else 1)
@@ -749,20 +950,22 @@ def main():
     other = None
     if world > 1:  # the mode `value` is NOT quoted in, first: the headline region runs last
         om = "strong" if args.scaling == "weak" else "weak"
-        odt, oper, _, _, _, _ = timed(om)
+        odt, oper, _, _, _, _, _ = timed(om)
         other = mode_summary(om, odt, oper)
-    dt, per_rank_dt, scan_ms, vals, ids, queries = timed(args.scaling)
+    dt, per_rank_dt, scan_ms, vals, ids, queries, scan_stats = timed(args.scaling)
     headline = mode_summary(args.scaling, dt, per_rank_dt)
 
     # ---- roofline of the dominant kernel (the list scan) --------------------------------------
     algo_bytes = scanned_bytes(idx, queries, args.m)  # uint8 codes only: the irreducible read
     kernel = "scan_packed_kernel" if args.layout == "packed" else "scan_ref_kernel"
     roofline = hbm_roofline(
-        algo_bytes, scan_ms, kernel, stream_peak, bytes_per_query=round(algo_bytes / queries.shape[1], 1),
+        algo_bytes, scan_ms, kernel, stream_peak, resident_bytes=idx._storage.numel(), stats=scan_stats,
+        bytes_per_query=round(algo_bytes / queries.shape[1], 1),
         cell_imbalance=round(float((idx._cell_size.double() ** 2).sum().item()) * args.n_cells
                              / float(idx._cell_size.sum().item()) ** 2, 3))
     if args.layout == "packed" and args.workload == "c2":
         attach_traffic(roofline, "bench_scan_packed")
+        cross_check_profile(roofline, "bench_scan_packed", "scan_packed_kernel<1, 64")
 
     shape = "SIFT1M" if real is not None else ("SIFT1M-like" if args.workload == "c2" else "synthetic")
     out = {
@@ -778,13 +981,28 @@ def main():
                    "codes": "u8 (8-bit PQ)", "arithmetic": "f32 LUT entries, f32 sums, exact ids",
                    "use_smart_probing": False, "parallelism": f"query-sharded x{world}, replicated index",
                    "collective_backend": backend, "world_size_seen": world,
+                   "collective_fallback_reason": groups.bulk_error if groups is not None else None,
                    "index_broadcast_s": round(t_bcast, 3), "index_broadcast_bytes": bcast_bytes,
+                   "index_broadcast_GBps": round(bcast_bytes / t_bcast / 1e9, 2) if t_bcast > 0 else None,
                    "ms_per_step_rank_min": headline["ms_per_step_rank_min"],
                    "ms_per_step_rank_max": headline["ms_per_step_rank_max"]},
         "roofline": roofline,
     }
     if other is not None:
         out["other_scaling"] = other
+    if world == 1 and args.workload == "c2" and not args.no_secondary:
+        # strong scaling on N GPUs searches nq / N queries per GPU: the rate a 1/N batch reaches on ONE GPU,
+        # relative to the full batch, is the efficiency strong scaling can reach at N (no collective in the path)
+        pred = {}
+        for ng in (2, 4, 8):
+            qs = queries[:, :max(1, queries.shape[1] // ng)].contiguous()
+            dtn = time_search(idx, qs, args.k, max(5, args.steps // 2), 2)[0]
+            pred[str(ng)] = round((qs.shape[1] * max(5, args.steps // 2) / dtn) / headline["value"], 4)
+        out["strong_scaling_prediction"] = {
+            "efficiency_at_n_gpus": pred,
+            "what": f"rate of a {queries.shape[1]}/N-query batch on this one GPU over the rate of the full batch: "
+                    "the ceiling of --scaling strong at N GPUs (weak scaling, the default `value`, keeps "
+                    "the full batch per GPU)"}
     if rank == 0:
         out["train_s"] = round(t_train, 3)
         out["add_s"] = round(t_add, 3)

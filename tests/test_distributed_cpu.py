@@ -66,3 +66,53 @@ def test_shard_bounds_cover_and_balance():
             assert all(b[r][1] == b[r + 1][0] for r in range(w - 1))
             sizes = [e - s for s, e in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _groups_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(world)
+    from torchpq_amd import distributed as tpd
+
+    # the bulk plane's probe fails on ONE rank only: every rank must learn it and fall back together
+    def probe(_group):
+        if rank == 1:
+            raise RuntimeError("transport down on rank 1")
+
+    def no_rccl_here(*a, **k):  # (this container has no GPU: creating the RCCL group is what fails first)
+        raise RuntimeError("no RCCL in this test")
+
+    g = tpd.init_groups("cpu", want_rccl=True, timeout_s=60, probe=probe,
+                        create=(lambda: None) if ret["mode"] == "probe" else no_rccl_here)
+    assert g.bulk is None and g.bulk_backend == "gloo" and g.bulk_error
+    tpd.host_barrier()
+    # chunked broadcast: 1000 bytes per call over a 10 KB + a bool + an empty tensor
+    state = {}
+    if rank == 0:
+        gen = torch.Generator().manual_seed(5)
+        state = {"a": torch.randint(0, 255, (7, 1501), generator=gen, dtype=torch.uint8),
+                 "b": torch.randn(33, 65, generator=gen), "flag": torch.tensor(True),
+                 "i": torch.arange(700, dtype=torch.int64), "empty": torch.empty(0, 4)}
+    out = tpd.broadcast_state(state, src=0, device="cpu", bulk_group=g.bulk, chunk_bytes=1000)
+    gen = torch.Generator().manual_seed(5)
+    exp = {"a": torch.randint(0, 255, (7, 1501), generator=gen, dtype=torch.uint8),
+           "b": torch.randn(33, 65, generator=gen), "flag": torch.tensor(True),
+           "i": torch.arange(700, dtype=torch.int64), "empty": torch.empty(0, 4)}
+    ok = all(torch.equal(out[k], exp[k]) and out[k].dtype == exp[k].dtype for k in exp)
+    ret[f"ok{rank}"] = bool(ok)
+    ret[f"err{rank}"] = g.bulk_error
+    dist.destroy_process_group()
+
+
+def test_rccl_probe_failure_on_one_rank_falls_back_on_all_and_chunked_broadcast():
+    for mode in ("probe", "create"):
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        ret["mode"] = mode
+        port = 29500 + ((os.getpid() + 7 + len(mode)) % 2000)
+        mp.spawn(_groups_worker, args=(2, port, ret), nprocs=2, join=True)
+        assert ret.get("ok0") is True and ret.get("ok1") is True
+        assert ret["err0"] and ret["err1"]
+        if mode == "probe":
+            assert "rank 1" in ret["err1"] and "another rank" in ret["err0"]

@@ -94,6 +94,7 @@ def test_bench_gpus2_self_launches_under_the_one_device_hook():
     # on the same line, with the per-rank spread and the broadcast volume
     cfg = rec["config"]
     assert cfg["n_query_per_rank"] == 512 and cfg["index_broadcast_bytes"] > 60000 * 64
+    assert cfg["index_broadcast_GBps"] > 0 and cfg["collective_fallback_reason"] is None
     assert 0 < cfg["ms_per_step_rank_min"] <= cfg["ms_per_step_rank_max"] == rec["ms_per_step"]
     other = rec["other_scaling"]
     assert other["scaling"] == "strong" and other["queries_per_step_all_ranks"] == 512 and other["value"] > 0
@@ -115,3 +116,34 @@ def test_bench_gpus2_strong_scaling_is_the_headline_when_asked():
     assert rec["other_scaling"]["scaling"] == "weak"
     assert rec["other_scaling"]["queries_per_step_all_ranks"] == 2 * 511
     assert abs(rec["value"] - 511 * 2 / (rec["ms_per_step"] * 2e-3)) / rec["value"] < 0.01
+
+
+def _bench2(extra_env, *extra_args, timeout=600):
+    env = dict(os.environ, TPQ_BENCH_ONE_DEVICE="1", **extra_env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+         "--nq", "512", "--n-base", "60000", "--n-train", "20000", "--n-cells", "64", "--n-probe", "8",
+         *extra_args], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_rccl_probe_failure_falls_back_to_gloo_and_says_so():
+    """the first 8-GPU run happens unattended: a broken RCCL transport must end in a measured line over the
+    gloo-staged broadcast with the reason on the record -- not in a hang (searching needs no collective)"""
+    out = _bench2({"TPQ_BENCH_FAIL_RCCL": "1"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0
+    assert rec["config"]["collective_backend"] == "gloo"
+    assert "TPQ_BENCH_FAIL_RCCL" in rec["config"]["collective_fallback_reason"] \
+        or "another rank" in rec["config"]["collective_fallback_reason"]
+
+
+def test_bench_deadline_prints_one_error_line_instead_of_hanging():
+    out = _bench2({}, "--deadline", "0.05")
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode != 0
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["value"] is None and "deadline" in rec["error"] and rec["world_size_seen"] == 2

@@ -1,0 +1,77 @@
+"""GPU, round 5: records that must hold on the driver's own command.
+
+* the GIST-shaped scan (configs[2]) keeps its rate when the 100 M-slot workload (configs[3]) ran before it in the
+  same process -- the order of bench.py's secondary pass -- and takes no in-kernel exact redo;
+* the bench line carries what is needed to tell when it does not (per-step spread, redone queries, n_split,
+  the level that fed the scan, the tracked profile's kernel time and a mismatch flag).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _secondary(only):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--secondary-only", only], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["secondary"]
+
+
+def test_gist_shape_after_the_100m_scan_in_one_process():
+    alone = _secondary("c3")["c3"]["roofline"]
+    both = _secondary("c4,c3")
+    after = both["c3"]["roofline"]
+    assert "error" not in both["c4"] and both["c4"]["roofline"]["queries_redone_exactly"] == 0
+    for r in (alone, after):
+        assert r["queries_redone_exactly"] == 0 and r["n_split"] == 1
+        assert r["fed_by"] == "infinity_cache"          # 120 MB of codes
+        assert r["kernel_ms_min"] <= r["kernel_ms_median"] <= r["kernel_ms_max"]
+    assert both["c4"]["roofline"]["fed_by"] == "hbm"    # 6.4 GB of codes
+    assert after["kernel_ms"] <= 1.3 * alone["kernel_ms"], (alone["kernel_ms"], after["kernel_ms"])
+    assert after["frac"] >= 0.6, after
+
+
+def test_c1_record_oracle_cpu_leg_and_the_same_index_on_the_gpu():
+    c1 = _secondary("c1")["c1"]
+    assert "error" not in c1, c1
+    assert c1["ids_equal_to_oracle"] == 1.0 and c1["values_max_rel_diff_vs_oracle"] <= 1e-4
+    assert c1["cpu"]["cores"] >= 1 and c1["cpu"]["train_s"] > 0 and c1["cpu"]["search_queries_per_s"] > 0
+    assert c1["gpu"]["search_queries_per_s"] > c1["cpu"]["search_queries_per_s"]
+
+
+# ---------------------------------------------------------------------------------------------
+# probe_sims_kernel's 32-bit buffer resource at very many cells; float4 reads of ragged rows
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,nq,n_cells,n_probe", [
+    (32, 9000, 262144, 16),     # a block of 8 192 rows x 262 144 cells x 2 B was 4 GiB: num_records truncated to 0
+    (16, 4500, 524288, 8),      # ... 524 288 cells with >= 4 096 queries
+    (30, 600, 2048, 16),        # d % 4 != 0: the fp16 route's float4 row reads -- must take the fp32 kernels
+])
+def test_coarse_probe_fp16_route_equals_fp32_route_at_very_many_cells(d, nq, n_cells, n_probe):
+    import numpy as np
+    import torch
+    import torchpq_amd.kernels as K
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(d + n_cells)
+    c = torch.randn(d, n_cells, generator=g, device="cuda:0") * 20
+    x = c[:, torch.randint(0, n_cells, (nq,), generator=g, device="cuda:0")] \
+        + torch.randn(d, nq, generator=g, device="cuda:0") * 6
+    sizes = torch.randint(0, 500, (n_cells,), generator=g, device="cuda:0")
+    start = torch.cumsum(sizes + 3, 0) - sizes - 3
+    ref = K.CoarseProbeHip(route="fp32")(x, c, start, sizes, n_probe, None)
+    for route in ("fp16", "auto"):
+        got = K.CoarseProbeHip(route=route)(x, c, start, sizes, n_probe, None)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b), route
+    # the planted centroid is the nearest cell of (nearly) every query: the probe really looked at all cells
+    assert (ref[1][:, 0] >= 0).all() and int(ref[1].max()) < n_cells

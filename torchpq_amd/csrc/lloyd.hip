@@ -3051,6 +3051,17 @@ static int run_probe_sims(const float* query, const char* prepared, int d, int n
   const int64_t wide = (P.T + 1) / 2;
   int n_wide = (int)((wide * C.chunks) / ((int64_t)kWaves * 1024));
   n_wide = n_wide < 1 ? 1 : (n_wide > kWide ? kWide : n_wide);
+  // the block's sims rows are ONE buffer resource addressed with 32-bit offsets (probe_sims_kernel): its
+  // rows x n_cells x 2 bytes must stay below the out-of-range sentinel 0x7ffffff0 (at 262 144 cells a block of
+  // 8 192 rows was 4 GiB: num_records truncated to 0, row offsets wrapped).  lloyd_probe_supported() keeps one
+  // wide tile per wave inside the range; here the tiles per wave are cut to what fits.
+  const int64_t row_bytes = (int64_t)n_cells * 2, rows_per_wide = (int64_t)kWaves * 64;
+  const int64_t fit = (int64_t)0x7ffffff0 / (row_bytes * rows_per_wide);
+  if (fit < 1) {
+    set_error("probe_sims: %d cells: one block's rows exceed the 2 GiB buffer resource", n_cells);
+    return TPQ_ERR_UNSUPPORTED;
+  }
+  n_wide = n_wide > fit ? (int)fit : n_wide;
   const int64_t per_block = (int64_t)kWaves * n_wide;
   ProbeSimsArgs pa{reinterpret_cast<const u32x4*>(p + P.hi_off), frags, sims, qscale, gmax, nq, n_cells, L.n_groups, n_wide,
                    P.T, 8 * (2 * KS + 1) * 64};
@@ -3066,7 +3077,12 @@ static int run_probe_sims(const float* query, const char* prepared, int d, int n
 
 // hooks for tpq_ivfpq_coarse_probe (select.hip, probe_fast.h): euclidean, d <= 128, whole 16-byte pieces per row
 int lloyd_probe_supported(int d, int nq, int n_cells) {
-  if (!(d >= 1 && d <= 128 && nq >= 1 && n_cells >= 256 && (n_cells & 31) == 0 && n_cells <= (1 << 22))) return 0;
+  // d % 4: probe_select_fast_kernel reads the centroid rows (stride d floats) as float4.
+  // n_cells <= 2^20: the 512 rows of one wide tile per wave (kWaves x 64) x n_cells x 2 bytes must fit the 32-bit
+  // buffer resource of probe_sims_kernel (run_probe_sims cuts the tiles per wave to what fits).
+  if (!(d >= 4 && d <= 128 && (d & 3) == 0 && nq >= 1 && n_cells >= 256 && (n_cells & 31) == 0 && n_cells <= (1 << 20)))
+    return 0;
+  if ((int64_t)n_cells * 2 * lloyd::kWaves * 64 > (int64_t)0x7ffffff0) return 0;
   return (int64_t)nq * n_cells < (1LL << 36) ? 1 : 0;
 }
 int lloyd_probe_groups(int n_cells) {

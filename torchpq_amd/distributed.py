@@ -1,8 +1,8 @@
 """Multi-GPU search: queries shard across ranks, the index is replicated.
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" in the CPU
-tests).  The only collective is a broadcast of the index buffers at load time; searching
-needs no communication -- every query touches read-only state, results stay on the owning
+tests).  The only collective is a broadcast of the index buffers at load time (RCCL, probed;
+staged over gloo when the probe fails -- init_groups); searching needs no communication -- every query touches read-only state, results stay on the owning
 rank (optionally gathered for the caller).
 """
 from __future__ import annotations
@@ -26,16 +26,83 @@ def shard_queries(x, rank=None, world_size=None):
     return x[:, b:e].contiguous()
 
 
-def broadcast_state(state, src=0, device=None, group=None):
+# ---- process groups -----------------------------------------------------------------------------
+# Two planes.  CONTROL (rendezvous, barriers, metadata, timings): gloo, CPU tensors -- it cannot hang on
+# a GPU transport problem.  BULK (the one collective of the path: the index broadcast at load): RCCL over
+# xGMI, created eagerly, PROBED with a small all-reduce, and used only when every rank's probe came back;
+# otherwise the broadcast is staged through the hosts over gloo and the record says so.  Searching needs
+# neither plane.
+class Groups:
+    def __init__(self, control=None, bulk=None, bulk_backend="gloo", bulk_error=None):
+        self.control, self.bulk, self.bulk_backend, self.bulk_error = control, bulk, bulk_backend, bulk_error
+
+
+def host_barrier(group=None):
+    """barrier on the control plane (a 1-element CPU all-reduce): callers synchronize their device first"""
+    t = torch.zeros(1, dtype=torch.int32)
+    dist.all_reduce(t, group=group)
+
+
+def init_groups(device=None, want_rccl=True, timeout_s=300.0, probe=None, create=None):
+    """default process group = gloo (control plane); plus, when `want_rccl`, an RCCL group bound to `device`
+    and verified by `probe(group)` (default: an all-reduce of one int32 on the device).  Every rank learns
+    whether ALL probes succeeded (a MIN over the control plane) -- a transport that fails on one rank only
+    must not leave the others waiting inside a collective.  `create` / `probe` replace the group's
+    creation / its check (validation hooks of bench.py and the CPU tests)."""
+    from datetime import timedelta
+    to = timedelta(seconds=timeout_s)
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", timeout=to)
+    g = Groups(control=None)
+    if not want_rccl:
+        return g
+    err = None
+    bulk = None
+    try:
+        if create is not None:  # (tests: stand-in for the RCCL group)
+            bulk = create()
+        else:
+            bulk = dist.new_group(backend="nccl", timeout=to, device_id=torch.device(device))
+        if probe is None:
+            t = torch.ones(1, dtype=torch.int32, device=device)
+            dist.all_reduce(t, group=bulk)
+            torch.cuda.synchronize(device)
+            if int(t.item()) != dist.get_world_size():
+                raise RuntimeError(f"RCCL probe all-reduce returned {int(t.item())}")
+        else:
+            probe(bulk)
+    except Exception as e:  # noqa: BLE001 -- any transport error: fall back, keep the message
+        err = f"{type(e).__name__}: {e}"[:300]
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        g.bulk, g.bulk_backend = bulk, "nccl"
+    else:
+        g.bulk_error = err or "the RCCL probe failed on another rank"
+    return g
+
+
+def _broadcast_chunked(t, src, group, chunk_bytes):
+    """broadcast a contiguous tensor in pieces of <= chunk_bytes (flat byte view): bounded staging
+    buffers whatever the transport does internally, and a 6.4 GB code array never rides on one call"""
+    flat = t.view(-1).view(torch.uint8) if t.dtype != torch.bool else t.view(-1)
+    n = flat.numel()
+    for b in range(0, n, chunk_bytes):
+        dist.broadcast(flat[b:min(n, b + chunk_bytes)], src=src, group=group)
+
+
+def broadcast_state(state, src=0, device=None, group=None, bulk_group=None, chunk_bytes=1 << 30):
     """Broadcast a flat {name: tensor} dict from `src`.  Shapes differ per index (buffers grow),
-    so rank `src` first announces (name, shape, dtype), then every tensor is broadcast into a
-    freshly allocated buffer on `device`.  Returns the dict on every rank."""
+    so rank `src` first announces (name, shape, dtype) on `group` (the control plane), then every tensor
+    is broadcast -- over `bulk_group` (RCCL) when given, else over `group` -- into a freshly allocated
+    buffer on `device`, in chunks of <= chunk_bytes.  Returns the dict on every rank."""
     rank = dist.get_rank(group)
     meta = [None]
     if rank == src:
         meta[0] = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in state.items()
                    if v is not None]
-    dist.broadcast_object_list(meta, src=src, group=group)
+    dist.broadcast_object_list(meta, src=src, group=group, device=torch.device("cpu"))
+    data_group = bulk_group if bulk_group is not None else group
     out = {}
     for name, shape, dtype in meta[0]:
         dt = getattr(torch, dtype)
@@ -46,26 +113,28 @@ def broadcast_state(state, src=0, device=None, group=None):
             t = torch.empty(shape, dtype=dt, device=device)
         if t.dtype == torch.bool:  # not every backend broadcasts bool
             u = t.to(torch.uint8)
-            dist.broadcast(u, src=src, group=group)
+            if u.numel():
+                _broadcast_chunked(u, src, data_group, chunk_bytes)
             t = u.to(torch.bool)
         elif t.numel():
-            dist.broadcast(t, src=src, group=group)
+            _broadcast_chunked(t, src, data_group, chunk_bytes)
         out[name] = t
     return out
 
 
-def replicate_index(index, src=0, group=None):
-    """Make every rank's `index` a replica of rank `src`'s (one broadcast per buffer; at the 100 M
-    configuration ~7.3 GB, per-link bound on xGMI -- tens of ms, paid once at load)."""
+def replicate_index(index, src=0, group=None, bulk_group=None, chunk_bytes=1 << 30):
+    """Make every rank's `index` a replica of rank `src`'s (one broadcast per buffer, <= 1 GiB per call; at the
+    100 M configuration ~7.3 GB, per-link bound on xGMI -- tens of ms, paid once at load)."""
     sd = index.state_dict() if dist.get_rank(group) == src else {}
-    sd = broadcast_state(sd, src=src, device=index.device, group=group)
+    sd = broadcast_state(sd, src=src, device=index.device, group=group, bulk_group=bulk_group,
+                         chunk_bytes=chunk_bytes)
     # bytes that crossed the links, for the record (bench.py `index_broadcast_bytes`)
     index.replicated_bytes = int(sum(v.numel() * v.element_size() for v in sd.values()))
     extra = [None]
     if dist.get_rank(group) == src:
         extra[0] = {"n_probe": index.n_probe, "use_smart_probing": index.use_smart_probing,
                     "smart_probing_temperature": index._smart_probing_temperature}
-    dist.broadcast_object_list(extra, src=src, group=group)
+    dist.broadcast_object_list(extra, src=src, group=group, device=torch.device("cpu"))
     if dist.get_rank(group) != src:
         index.load_state_dict(sd)
     index.n_probe = extra[0]["n_probe"]

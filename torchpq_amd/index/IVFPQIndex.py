@@ -379,8 +379,10 @@ class IVFPQIndex(CellContainer):
         cb = self.vq_codec.codebook
         key = (cb.data_ptr(), tuple(cb.shape), util.tensor_version(cb))
         cached = getattr(self, "_probe_prep_cache", None)
-        if cached is None or cached[0] != key or cb.is_inference():
-            self._probe_prep_cache = cached = (key, self._coarse_probe.prepare(cb))
+        # (the entry HOLDS the codebook tensor and is matched by identity: a later codebook allocated at the freed
+        # address with the same shape and version -- train, search, train, train, search -- must not hit it)
+        if cached is None or cached[0] != key or cached[2] is not cb or cb.is_inference():
+            self._probe_prep_cache = cached = (key, self._coarse_probe.prepare(cb), cb)
         return cached[1]
 
     def probe(self, x):
