@@ -83,6 +83,19 @@ def main():
         print(f"  {FUSED_PHASES[11]:32s} {((tf[:, 12] - tf[:, 11]) / 1e3).mean():7.2f} us")
         print(f"  kernel span {(raw_t[:, :13].max() - raw_t[:, 0].min()) / 1e3:.1f} us")
         return
+    if bool((raw_t[:, 6] > 0).any()) and not bool((raw_t[:, 7] > 0).any()):
+        # dump mode (large batches, m = 64): the workgroup ends after the loop; scan_finish_exact_kernel does the rest
+        t = raw_t[:, :7]
+        d = (t[:, 1:] - t[:, :-1]) / 1e3
+        total = (t[:, 6] - t[:, 0]) / 1e3
+        slots = 1024
+        print(f"m={m} nq={nq} n_probe={args.n_probe} blocks={n_blocks} (dump mode)  mean block lifetime {total.mean():.1f} us")
+        for i, name in enumerate(["start->probe loads issued", "table computed, quantised, staged (+barriers)", "error bound",
+                                  "scan loop", "final flush", "store the list"]):
+            print(f"  {name:44s} {d[:, i].mean():7.2f} us  {100 * d[:, i].mean() / total.mean():5.1f} %")
+        span = (t[:, 6].max() - t[:, 0].min()) / 1e3
+        print(f"  kernel span {span:.1f} us; sum of block lifetimes / ({slots} slots) = {total.sum() / slots:.1f} us")
+        return
     t = raw_t[:, :10]
     d = (t[:, 1:] - t[:, :-1]) / 1e3  # us
     total = (t[:, 9] - t[:, 0]) / 1e3

@@ -116,6 +116,20 @@ static int fresh_epoch() {
   return (int)(((uint32_t)(ns ^ (ns >> 29)) * 0x9e3779b1u) | 1u);
 }
 
+// large batches of plain PQ at m = 64, k <= 248: dump mode over the 16-bit table (scan_device.h).
+// (variants: TPQ_SCAN_DUMP=0 keeps the one-launch finish)
+static bool dump_route(const ScanArgs& a, bool residual, int R) {
+  if (residual || R > kFuseMaxR || a.n_split != 1) return false;
+  // the finish kernel recomputes the survivors' table entries from the codebook, held in LDS next to nothing else:
+  // fused calls (query + codebook) only, m * ds <= 128
+  if (a.lut || a.m != 64 || a.ds > 2) return false;
+  // (it takes a query's lists as at most 8 chunks of 64 keys: four waves x RL <= 2)
+  if (list_regs_scan(a.k, a.m, a.max_nprobe, a.slots_hint, 4) > 2) return false;
+  const char* e = TPQ_AB_ENV("TPQ_SCAN_DUMP");
+  if (e && atoi(e) == 0) return false;
+  return a.nq >= kDumpMinQueries;
+}
+
 static bool has_packed_kernel(int m) {
 #define TPQ_IS_M(M) if (m == M) return true;
   TPQ_PACKED_M_LIST(TPQ_IS_M)
@@ -282,6 +296,33 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
     b.n_split = 1;
     b.only_flagged = a.flags;
     return dispatch_ref(b, list_regs(k), st);
+  }
+  // large batches of plain PQ at m = 64, k <= 248: dump mode (scan_device.h) -- the scan workgroups stream over the
+  // 16-bit table (32 KiB: four workgroups per CU) and end with their lists of fast values, one wave per query finishes
+  {
+    if (dump_route(a, ra != nullptr, R)) {
+      const bool sel16 = true;
+      const int nw = 4;
+      const int RLd = list_regs_scan(k, m, a.max_nprobe, a.slots_hint, nw);
+      rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, RLd, n_split * nw), "ivfpq_scan_packed");
+      if (rc) return rc;
+      fill_ws(a, workspace, RLd, n_split * nw);
+      a.epoch = fresh_epoch();
+      a.fuse = 0;
+      a.tickets = nullptr;
+      a.small_lists = 0;
+      switch (m) {
+#define TPQ_CASE_M(M) case M: rc = dispatch_dump_##M(a, RLd, R, sel16 ? 1 : 0, st); break;
+        TPQ_PACKED_M_LIST(TPQ_CASE_M)
+#undef TPQ_CASE_M
+        default: rc = TPQ_ERR_UNSUPPORTED; break;
+      }
+      if (rc) return rc;
+      ScanArgs b = a;  // exact redo of the (normally zero) flagged queries
+      b.n_split = 1;
+      b.only_flagged = a.flags;
+      return dispatch_ref(b, list_regs(k), st);
+    }
   }
   // registers of the per-wave lists (<= R)
   const int RL = list_regs_scan(k, m, a.max_nprobe, a.slots_hint);

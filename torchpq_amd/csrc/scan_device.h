@@ -60,7 +60,16 @@ struct ScanArgs {
   unsigned* pool_lo;
   int* pool_cnt;             // [nq][n_lists] exact candidates the list holds after the scan kernel
   int pool_cap;
+  // dump mode (scan_packed_kernel RM <= kDumpF32): [nq][n_lists] 1 = the wave's list may have evicted a candidate
+  int* list_evict;
 };
+
+// scan_packed_kernel modes beyond the fused finish (RM > 0) and the pools (RM = -1, -2, -3): "dump" -- the scan
+// workgroup ends with its waves' lists of FAST values; scan_finish_exact_kernel (one wave per query, full occupancy)
+// merges them, evaluates the band's survivors exactly from global memory and writes the result.
+constexpr int kDumpF32 = -8;     // fp32 table in LDS (m KiB), the permuted-order fp32 sum as the selection key
+constexpr int kDumpSel16 = -16;  // 16-bit fixed-point table (m / 2 KiB), an exact integer sum as the selection key
+constexpr int kDumpMinQueries = 1024;  // batches that fill the chip's 4 x 256 workgroup slots at least once
 
 #ifdef TPQ_SCAN_PROFILE
 #define TPQ_PROF(a, q, i)                                                        \
@@ -660,6 +669,112 @@ __device__ __forceinline__ float exact_lane(const typename scan_layout::Layout<M
   return exact_lane_blocks<M, 0>(w, idx, lut, 0.f);
 }
 
+// ---- the 16-bit selection table ("sel16") -------------------------------------------------------------
+// T[j][c] = round((LUT[j][c] + A_j) * inv), A_j = max_c |LUT[j][c]|, inv = 65535 / (2 max_j A_j): u16, laid out by
+// scan_layout::lut16_halfword.  F(slot) = sum_j T[j][code_j] is an EXACT integer (< 2^24: carried as a float), and
+// |F - (e_real + sum_j A_j) * inv| <= 0.51 m + 1 (per entry: the two fp32 roundings of (x + A_j) * inv, 0.008, and the
+// rounding to an integer, 0.5; + 1 for the rounding of inv itself), so the selection band of the fp32 fast value
+// carries over with delta = (0.51 m + 1) + (m - 1) u sum_j A_j * inv units.  Half the LDS of the fp32 table: four
+// workgroups per CU at m = 64 instead of two.
+// phase 1: the thread's M * 64 / NT float4 groups of entries (stage_lut_blocked's placement and, entry for entry, its
+// arithmetic) into registers; the per-sub-quantizer maxima of |x| as BIT PATTERNS (NaN and Inf order above every
+// finite value: the caller sees them in the maximum) into jmax
+template <int M, int NT>
+__device__ __forceinline__ void lut16_compute(const ScanArgs& a, int q, const float* xq, unsigned* jmax,
+                                              float4 (&ent)[M * 64 / NT]) {
+  constexpr int NE = M * 64 / NT;
+  static_assert(M * 64 % NT == 0, "whole groups per thread");
+  constexpr int JS = (M & 15) == 0 ? 4 : ((M & 7) == 0 ? 3 : 2);
+  constexpr int JB = 1 << JS, CB = 64 >> JS;
+  constexpr int jblocks = M >> JS;
+  auto place = [&](int i, int& j, int& c4) {
+    const int g = i >> 6, r = i & 63;
+    const int jb = g % jblocks, cb4 = g / jblocks;
+    j = jb * JB + (r & (JB - 1));
+    c4 = cb4 * CB + (r >> JS);
+  };
+  auto note = [&](int j, const float4& x) {
+    const unsigned b0 = __float_as_uint(x.x) & 0x7fffffffu, b1 = __float_as_uint(x.y) & 0x7fffffffu;
+    const unsigned b2 = __float_as_uint(x.z) & 0x7fffffffu, b3 = __float_as_uint(x.w) & 0x7fffffffu;
+    const unsigned m01 = b0 > b1 ? b0 : b1, m23 = b2 > b3 ? b2 : b3;
+    atomicMax(&jmax[j], m01 > m23 ? m01 : m23);
+  };
+  const float4* __restrict__ src = reinterpret_cast<const float4*>(a.lut);
+  if (!a.lut && a.ds <= 2) {
+    constexpr int U = 4;
+    static_assert(NE % U == 0, "batches of four");
+    const int ds = a.ds;
+#pragma unroll
+    for (int u0 = 0; u0 < NE; u0 += U) {
+      float4 y[U][2];
+      int j[U], c4[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        place((int)threadIdx.x + (u0 + u) * NT, j[u], c4[u]);
+        const float4* __restrict__ cb = reinterpret_cast<const float4*>(a.codebook) + (int64_t)j[u] * ds * 64 + c4[u];
+        y[u][0] = cb[0];
+        y[u][1] = ds > 1 ? cb[64] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float4 dot = make_float4(0.f, 0.f, 0.f, 0.f), c2 = dot;
+        float q2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          if (e >= ds) break;
+          const float4 yy = y[u][e];
+          const float x = xq[j[u] * ds + e];
+          q2 = fmaf(x, x, q2);
+          dot.x = fmaf(x, yy.x, dot.x); dot.y = fmaf(x, yy.y, dot.y);
+          dot.z = fmaf(x, yy.z, dot.z); dot.w = fmaf(x, yy.w, dot.w);
+          c2.x = fmaf(yy.x, yy.x, c2.x); c2.y = fmaf(yy.y, yy.y, c2.y);
+          c2.z = fmaf(yy.z, yy.z, c2.z); c2.w = fmaf(yy.w, yy.w, c2.w);
+        }
+        float4 v = dot;  // (fused_lut4's arithmetic, operation for operation)
+        if (a.euclid) {
+          v.x = 2.f * dot.x; v.y = 2.f * dot.y; v.z = 2.f * dot.z; v.w = 2.f * dot.w;
+          if (a.euclid != 2) {
+            v.x = v.x - q2; v.y = v.y - q2; v.z = v.z - q2; v.w = v.w - q2;
+            v.x = v.x - c2.x; v.y = v.y - c2.y; v.z = v.z - c2.z; v.w = v.w - c2.w;
+          }
+        }
+        ent[u0 + u] = v;
+        note(j[u], v);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    int j, c4;
+    place((int)threadIdx.x + u * NT, j, c4);
+    ent[u] = a.lut ? src[((int64_t)j * a.nq + q) * 64 + c4] : fused_lut4(a, j, c4, xq);
+    note(j, ent[u]);
+  }
+}
+// phase 2 (after a barrier: jmax is complete): quantise and store
+template <int M, int NT>
+__device__ __forceinline__ void lut16_store(const float4 (&ent)[M * 64 / NT], const unsigned* jmax, float inv,
+                                            uint16_t* lut16) {
+  constexpr int NE = M * 64 / NT;
+  constexpr int JS = (M & 15) == 0 ? 4 : ((M & 7) == 0 ? 3 : 2);
+  constexpr int JB = 1 << JS, CB = 64 >> JS;
+  constexpr int jblocks = M >> JS;
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    const int i = (int)threadIdx.x + u * NT;
+    const int g = i >> 6, r = i & 63;
+    const int j = (g % jblocks) * JB + (r & (JB - 1));
+    const int c = ((g / jblocks) * CB + (r >> JS)) * 4;
+    const float off = __uint_as_float(jmax[j]);
+    auto qz = [&](float x) -> uint16_t { return (uint16_t)(unsigned)fminf((x + off) * inv + 0.5f, 65535.f); };
+    lut16[scan_layout::lut16_halfword(M, j, c + 0)] = qz(ent[u].x);
+    lut16[scan_layout::lut16_halfword(M, j, c + 1)] = qz(ent[u].y);
+    lut16[scan_layout::lut16_halfword(M, j, c + 2)] = qz(ent[u].z);
+    lut16[scan_layout::lut16_halfword(M, j, c + 3)] = qz(ent[u].w);
+  }
+}
+
 // phase 2, wave-level: the merged list already carries EXACT values; write the best k and raise
 // the overflow flag when the list is so full of near-ties that a member of the exact top-k may
 // have been evicted from a wave's list (see the header comment of this section)
@@ -809,15 +924,22 @@ constexpr int packed_aux_bytes(int /*R*/, int M) {
 // rounds run over the pools, the entries at or above the cut are compacted through the wave's queue, re-evaluated
 // exactly and written back -- unsorted; scan_pool_merge_kernel ranks a query's ~k exact candidates in LDS.
 // A pool that fills up flags the query for the exact kernel.
+// RM <= kDumpF32 ("dump", large batches of plain PQ, k <= 248): the workgroup ENDS after the tile loop -- its waves store
+// their lists of fast values and scan_finish_exact_kernel does the rest at full occupancy (the end of a query -- barrier,
+// counting rounds, refinement, merge: 17 of the 43 us a 16-probe query of 244-slot cells lives -- held a 64-KiB-LDS
+// workgroup slot idle).  RM = kDumpSel16: the table is the 16-bit one (above), four waves per workgroup.
+constexpr int scan_waves(int M, int RM) { return RM == kDumpSel16 ? 4 : packed_waves(M); }
 template <int R, int M, bool RES, int RM = 0>
-__global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(ScanArgs a,
-                                                                                    ResidualArgs ra,
-                                                                                    float delta_rel) {
+__global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(ScanArgs a,
+                                                                                      ResidualArgs ra,
+                                                                                      float delta_rel) {
   using L = scan_layout::Layout<M>;
-  constexpr int NW = packed_waves(M);
+  constexpr bool DUMP = RM <= kDumpF32, SEL16 = RM == kDumpSel16, POOL = RM < 0 && !DUMP;
+  static_assert(!(DUMP && RES), "dump mode serves plain PQ");
+  constexpr int NW = scan_waves(M, RM);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int lut_bytes = M * 1024;
-  constexpr int aux_bytes = packed_aux_bytes(R, M);
+  constexpr int lut_bytes = SEL16 ? M * 512 : M * 1024;
+  constexpr int aux_bytes = DUMP ? 0 : packed_aux_bytes(R, M);
   float* lut = reinterpret_cast<float*>(smem);
   uint32_t* scratch_all = reinterpret_cast<uint32_t*>(smem + lut_bytes);
   float* qv_all = reinterpret_cast<float*>(smem + lut_bytes + aux_bytes);
@@ -856,8 +978,39 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
   TPQ_PROF(a, blockIdx.x, 1);
   const float* part1 = RES ? ra.part1 : nullptr;
   if (!a.lut && !part1) stage_query(a, q, xq, NW * 64);
-  stage_lut_blocked<M>(a, q, lut, NW * 64, jmax, xq, part1);
-  if (wave == 0) build_probe_table(a, q, n_probe, tab, packed_tile_shift(M), &probes0);
+  [[maybe_unused]] float inv16 = 0.f;  // SEL16: table units per unit of value
+  if constexpr (SEL16) {
+    float4 ent[M * 64 / (NW * 64)];
+    lut16_compute<M, NW * 64>(a, q, xq, jmax, ent);
+    if (wave == 0) build_probe_table(a, q, n_probe, tab, packed_tile_shift(M), &probes0);
+    __syncthreads();
+    unsigned jb = 0u;
+    float sum = 0.f;
+#pragma unroll
+    for (int j0 = 0; j0 < M; j0 += 64) {
+      if (j0 + lane < M) {
+        jb = jmax[j0 + lane] > jb ? jmax[j0 + lane] : jb;
+        sum += __uint_as_float(jmax[j0 + lane]);
+      }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      const unsigned o = (unsigned)__shfl_xor((int)jb, d, 64);
+      jb = o > jb ? o : jb;
+      sum += __shfl_xor(sum, d, 64);
+    }
+    const float J = __uint_as_float(jb);
+    // a table that cannot be scaled (NaN / Inf entries, overflow of 2 J or of the bound, all zeros): the exact kernel
+    // takes the query (scan.hip launches it over the flagged ones)
+    const bool scalable = jb < 0x7f800000u && J >= 1e-30f && J <= 1e37f && sum <= 1e37f;
+    if (threadIdx.x == 0 && part == 0) a.flags[q] = scalable ? 0 : a.epoch;
+    if (!scalable) return;  // (workgroup-uniform: every wave reduced the same words)
+    inv16 = 65535.f / (2.f * J);
+    lut16_store<M, NW * 64>(ent, jmax, inv16, reinterpret_cast<uint16_t*>(lut));
+  } else {
+    stage_lut_blocked<M>(a, q, lut, NW * 64, jmax, xq, part1);
+    if (wave == 0) build_probe_table(a, q, n_probe, tab, packed_tile_shift(M), &probes0);
+  }
   float probe_mx = 0.f;
   if constexpr (RES) {
     for (int pp = threadIdx.x; pp < n_probe; pp += NW * 64) {
@@ -895,14 +1048,24 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
     for (int w = 0; w < NW; ++w) mx = fmaxf(mx, red[NW + w]);
     bound += mx;
   }
-  const float delta2 = 2.f * delta_rel * bound;  // 2*delta: width of the candidate band
+  float delta2 = 2.f * delta_rel * bound;  // 2*delta: width of the candidate band
+  if constexpr (SEL16) {
+    // in table units: the quantisation (0.51 per entry, + 1) and the exact value's own distance from the real sum
+    // ((M - 1) u bound = delta_rel bound / 2.1, taken as delta_rel bound / 2)
+    delta2 = ceilf(2.f * (0.51f * (float)M + 1.f + 0.5f * delta_rel * bound * inv16)) + 1.f;
+  } else if constexpr (DUMP) {
+    // (a bound that is not finite: leave the query to the exact kernel, as the 16-bit table does)
+    const bool ok = bound <= 1e37f;
+    if (threadIdx.x == 0 && part == 0) a.flags[q] = ok ? 0 : a.epoch;
+    if (!ok) return;
+  }
   TPQ_PROF(a, blockIdx.x, 3);
 
   WaveSelector<R> sel;
   sel.init(qv_all + wave * 64, qi_all + wave * 64, a.k);
   sel.margin = delta2;
   typename WaveSelector<R>::Pool pool{nullptr, nullptr, 0, 0};
-  if constexpr (RM < 0) {
+  if constexpr (POOL) {
     const int64_t o = (((int64_t)q * a.n_split + part) * NW + wave) * a.pool_cap;
     pool = {a.pool_hi + o, a.pool_lo + o, 0, a.pool_cap};
   }
@@ -955,13 +1118,14 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
       bool live = t.valid;
       if (t.valid) {
         if (a.is_empty) live = (a.is_empty[t.s] == 0);
-        v = L::accumulate(w, t.s, lut);
+        if constexpr (SEL16) v = (float)L::accumulate16(w, t.s, reinterpret_cast<const uint16_t*>(lut));
+        else v = L::accumulate(w, t.s, lut);
         if constexpr (RES) v += t.add;
       }
       refresh_tau();
       const float tau_before = sel.tau;
       const int flushes_before = sel.n_flush;
-      if constexpr (RM < 0) sel.push_pool(pool, live && (v >= sel.tau - delta2), v, t.s);
+      if constexpr (POOL) sel.push_pool(pool, live && (v >= sel.tau - delta2), v, t.s);
       else sel.push(live && (v >= sel.tau - delta2), v, t.s);
       if (sel.n_flush != flushes_before) publish(tau_before);
     };
@@ -1050,7 +1214,8 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
         live[u] = 64 * u < t.rem;
         if (live[u]) {
           if (a.is_empty) live[u] = (a.is_empty[t.s + 64 * u] == 0);
-          v[u] = L::accumulate(w[u], t.s + 64 * u, lut);
+          if constexpr (SEL16) v[u] = (float)L::accumulate16(w[u], t.s + 64 * u, reinterpret_cast<const uint16_t*>(lut));
+          else v[u] = L::accumulate(w[u], t.s + 64 * u, lut);
           if constexpr (RES) v[u] += t.add + term[u];
         }
       }
@@ -1065,7 +1230,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
       for (int u = 0; u < S; ++u) {
         const float tau_before = sel.tau;
         const int flushes_before = sel.n_flush;
-        if constexpr (RM < 0) sel.push_pool(pool, live[u] && (v[u] >= sel.tau - delta2), v[u], t.s + 64 * u);
+        if constexpr (POOL) sel.push_pool(pool, live[u] && (v[u] >= sel.tau - delta2), v[u], t.s + 64 * u);
         else sel.push(live[u] && (v[u] >= sel.tau - delta2), v[u], t.s + 64 * u);
         if (sel.n_flush != flushes_before) publish(tau_before);
       }
@@ -1131,7 +1296,16 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
   }
   TPQ_PROF(a, blockIdx.x, 5);
 
-  if constexpr (RM < 0) {
+  if constexpr (DUMP) {
+    // ---- dump mode: the wave's list of fast values, whether it may have lost one, the band -- and out ----
+    // (a flush folds at most 64 candidates in: a list of 64 R entries that has seen no more than R flushes evicted nothing)
+    const int64_t li = ((int64_t)q * a.n_split + part) * NW + wave;
+    store_list<R>(sel.top, a.ws_vals + li * (R * 64), a.ws_idx + li * (R * 64));
+    if (lane == 0) a.list_evict[li] = sel.n_flush > R ? 1 : 0;
+    if (part == 0 && wave == 0 && lane == 0) a.ws_delta[q] = delta2;
+    TPQ_PROF(a, blockIdx.x, 6);
+    return;
+  } else if constexpr (POOL) {
     // ---- pool mode: cut, compaction, exact values ----
     static_assert(!RES, "pool mode serves plain PQ");
     __syncthreads();  // every wave has published its quantile
@@ -1257,7 +1431,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
     TPQ_PROF(a, blockIdx.x, 8);
     TPQ_PROF(a, blockIdx.x, 9);
     return;
-  }
+  } else {
 
   // End of query, per wave and without any barrier: re-evaluate the surviving candidates of
   // this wave's list exactly (ascending j, LUT still in LDS), re-rank them by exact value and
@@ -1556,6 +1730,7 @@ __global__ __launch_bounds__(packed_waves(M) * 64, 4) void scan_packed_kernel(Sc
     TPQ_PROF(a, blockIdx.x, 9);
     if (part == 0 && wave == 0 && lane == 0) a.ws_delta[q] = delta2;
   }
+  }  // (neither dump nor pool mode)
 }
 
 // ---- split merge ---------------------------------------------------------------------------
@@ -1625,6 +1800,165 @@ __global__ __launch_bounds__(512) void scan_merge_refine_kernel(ScanArgs a) {
     __syncthreads();
   }
   if (wave == 0) finalize_and_write<R, RES>(a, q, top, a.ws_delta[q]);
+}
+
+// dump modes, phase 2: ONE WAVE per query.  The query's lists of FAST values arrive as NCH chunks of 64 keys (n_split x
+// nw_scan lists of RL chunks, best first).  With F_k the k-th best fast value over all of them and `band` the scan's
+// 2 delta, every member of the exact top-k has F >= F_k - band.  F_k comes from a bit-wise binary search on the key
+// images (a ballot and a scalar popcount per chunk and step: the chunks never leave their registers, and most of the
+// work rides on the scalar unit); nothing at or above the cut may have been lost on the way -- a wave's list that evicted
+// (list_evict) and still ends at or above the cut, or more survivors than 64 RM, flags the query for the exact kernel.
+// The survivors are compacted through a small LDS queue, 64 per pass, and evaluated EXACTLY, one per lane: the
+// candidate's 64 packed bytes are brought into sub-quantizer order IN REGISTERS (a byte permute per dword for the low
+// two bits of its XOR mask, four rounds of conditional dword swaps for the others), then sub-quantizer by sub-quantizer,
+// the same j in every lane: entry = tpq_adc_lut's arithmetic on the codebook row (in LDS) and the query component
+// (v_readlane from a register: wave-uniform), added in ascending j -- the reference's order, hence its bits.  Sorted by
+// (value desc, address asc) and written.
+// The codebook lives in LDS: one persistent workgroup per CU copies it (m * ds KiB, query-independent) once and its
+// waves walk the queries.  (Entries fetched from global memory -- a different cache line per lane and look-up -- ran into
+// the address coalescer: 396 us per 10 000 queries at k = 100; from LDS with lane-varying sub-quantizers and a value
+// butterfly: 160 us, instruction-bound at ~6 000 VALU per query; this form: ~2 500.)  Nothing of a scan workgroup's
+// table slot is held while this runs, which is the point of the split: the end of a query idled that slot for 17 of
+// its 43 us.
+constexpr int kFinishWaves = 16;
+static size_t finish_lds_bytes(int m, int ds, int RM) {
+  return (size_t)m * ds * 1024 + (size_t)kFinishWaves * RM * 64 * 4;
+}
+template <int RM, int M, int DS, int NCH>
+__global__ __launch_bounds__(kFinishWaves * 64) void scan_finish_exact_kernel(ScanArgs a, int nw_scan, int RL) {
+  using L = scan_layout::Layout<M>;
+  static_assert(M == 64, "one 64-block: the in-register un-permute below");
+  static_assert(M * DS <= 128, "the query rides in two registers per lane");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  float* cb = reinterpret_cast<float*>(smem);  // [m][ds][256]
+  {
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(a.codebook);
+    float4* dst = reinterpret_cast<float4*>(cb);
+    for (int i = threadIdx.x; i < M * DS * 64; i += kFinishWaves * 64) dst[i] = src[i];
+  }
+  int* qi = reinterpret_cast<int*>(cb + M * DS * 256) + wave * (RM * 64);  // the wave's survivors (addresses)
+  __syncthreads();
+  const int n_lists = a.n_split * nw_scan;
+  const int T = n_lists * RL;  // chunks in use (<= NCH)
+  const bool euclid = a.euclid != 0;
+  for (int q = (int)blockIdx.x * kFinishWaves + wave; q < a.nq; q += (int)gridDim.x * kFinishWaves) {
+    if (a.flags[q] == a.epoch) continue;  // the scan left the query to the exact kernel
+    // the query: component i in lane i % 64 of register i / 64; |q_j|^2 (ascending-dimension fma chain) in lane j
+    float xv[2] = {0.f, 0.f}, q2v = 0.f;
+    if (lane < M * DS) xv[0] = a.query[(int64_t)lane * a.nq + q];
+    if (64 + lane < M * DS) xv[1] = a.query[(int64_t)(64 + lane) * a.nq + q];
+    if (lane < M) {
+#pragma unroll
+      for (int e = 0; e < DS; ++e) {
+        const float x = a.query[(int64_t)(lane * DS + e) * a.nq + q];
+        q2v = fmaf(x, x, q2v);
+      }
+    }
+    const unsigned* __restrict__ bv = reinterpret_cast<const unsigned*>(a.ws_vals) + (int64_t)q * T * 64;
+    const unsigned* __restrict__ bi = reinterpret_cast<const unsigned*>(a.ws_idx) + (int64_t)q * T * 64;
+    unsigned hi[NCH];
+    int ix[NCH];
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+      hi[t] = t < T ? bv[t * 64 + lane] : 0u;  // (0 < the image of -inf: never counted, never wanted)
+      ix[t] = t < T ? (int)~bi[t * 64 + lane] : kPadIdx;
+      if (ix[t] == kPadIdx) hi[t] = 0u;
+    }
+    int evict = 0;
+    if (lane < n_lists) evict = a.list_evict[(int64_t)q * n_lists + lane];
+    const float band = a.ws_delta[q];
+    // F_k: the largest key image t with at least k entries >= t (0 while fewer than k entries exist)
+    unsigned fk = 0u;
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned t = fk | (1u << bit);
+      int n = 0;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) n += __popcll(__ballot(hi[c] >= t));
+      fk = n >= a.k ? t : fk;
+    }
+    const float cut = (fk ? key2f(fk) : -INFINITY) - band;
+    const unsigned cutk = f2key(cut);
+    // survivors -> queue; a list that evicted and still ends at or above the cut lost one that mattered
+    int n_c = 0;
+    bool lost = false;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const bool want = hi[c] != 0u && hi[c] >= cutk;
+      const unsigned long long mask = __ballot(want);
+      const int n = __popcll(mask);
+      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+      if (want && n_c + rank < RM * 64) qi[n_c + rank] = ix[c];
+      n_c += n;
+      // (chunk c is rank chunk c % RL of list c / RL: its lane 63 is the list's last entry when c % RL == RL - 1)
+      const int l = c / (RL > 0 ? RL : 1);
+      const bool last_chunk = (c % (RL > 0 ? RL : 1)) == RL - 1;
+      const int ev = __builtin_amdgcn_readlane(evict, l < 64 ? l : 0);
+      lost = lost || (last_chunk && ev && ((mask >> 63) & 1ull));
+    }
+    lost = lost || n_c > RM * 64;
+    if (lost) {  // (wave-uniform)
+      if (lane == 0) a.flags[q] = a.epoch;
+      continue;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    WaveTopK<RM> ex;
+    ex.init();
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      if (r * 64 >= n_c) break;  // wave-uniform
+      const bool want = r * 64 + lane < n_c;
+      const int idx = want ? qi[r * 64 + lane] : 0;  // (idle lanes walk slot 0's bytes: in range)
+      typename L::chunk_t cw[L::kChunks];
+      L::load(a.packed, a.n_slots, idx, cw);
+      // sub-quantizer order: out dword D byte B = in dword D ^ (x >> 2), byte B ^ (x & 3), x = idx mod 64
+      const unsigned x = (unsigned)idx & 63u;
+      const unsigned sel = 0x03020100u ^ ((x & 3u) * 0x01010101u);
+      unsigned cd[16];
+#pragma unroll
+      for (int d = 0; d < 16; ++d) {
+        const unsigned wd = L::word(cw, d);
+        cd[d] = __builtin_amdgcn_perm(wd, wd, sel);
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const bool sw = ((x >> (2 + b)) & 1u) != 0u;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+          if ((d & (1 << b)) == 0) {
+            const unsigned lo = cd[d], up = cd[d | (1 << b)];
+            cd[d] = sw ? up : lo;
+            cd[d | (1 << b)] = sw ? lo : up;
+          }
+        }
+      }
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const unsigned c = (cd[j >> 2] >> (8 * (j & 3))) & 255u;
+        float dot = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < DS; ++e) {
+          constexpr int dummy = 0;
+          (void)dummy;
+          const int i = j * DS + e;
+          const float y = cb[i * 256 + (int)c];
+          const float xx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[i >> 6]), i & 63));
+          dot = fmaf(xx, y, dot);
+          c2 = fmaf(y, y, c2);
+        }
+        // (fused_lut4's arithmetic, operation for operation)
+        float val = 2.f * dot;
+        val = val - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q2v), j));
+        val = val - c2;
+        v += euclid ? val : dot;
+      }
+      ex.insert_unsorted(want ? make_key(v + 0.0f, idx) : pad_key());
+    }
+    write_final<RM>(a, q, ex);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the next query overwrites the queue
+  }
 }
 
 // pool mode, phase 2: the query's n_lists sorted lists of exact candidates (64 RX entries each, pads last) are
@@ -1700,8 +2034,8 @@ static int list_regs_packed(int k) { return pow2_ceil((k + kBandSlack + 63) / 64
 // 244 slots, ONE 256-slot tile at m <= 32) the 2k budget sent 1-2 % of the queries (93 % at n_probe = 1) through
 // the exact redo at k = 100 (profiles/r04_reference_grid.json, "queries_redone_exactly") -- and gets 4k; so does
 // a caller that gives no hint.  (Full-size lists everywhere would cost the long cells 10 % at k = 100, m <= 32.)
-static int list_regs_scan(int k, int m, int max_nprobe, int64_t slots_hint) {
-  const int nw = packed_waves(m);
+static int list_regs_scan(int k, int m, int max_nprobe, int64_t slots_hint, int waves = 0) {
+  const int nw = waves ? waves : packed_waves(m);
   const int rp = list_regs_packed(k);
   if (k < TPQ_SCAN_MIN_RL_K) return rp;
   const int64_t round_slots = (int64_t)nw * 64 * packed_slots(m);
@@ -1738,6 +2072,13 @@ static size_t scan_lds_bytes_packed(int m, int R, int max_nprobe, int fused_floa
              (size_t)fused_floats * 4;
   return (b + 15) & ~(size_t)15;
 }
+// dump modes: no un-permute rows; the 16-bit table is half the size and runs four waves per workgroup
+static size_t scan_lds_bytes_dump(int m, bool sel16, int max_nprobe, int fused_floats) {
+  const int nw = sel16 ? 4 : packed_waves(m);
+  size_t b = (size_t)m * (sel16 ? 512 : 1024) + nw * 512 + (size_t)(3 * max_nprobe + 1) * 4 + 8 + 3 * nw * 4 +
+             (size_t)fused_floats * 4;
+  return (b + 15) & ~(size_t)15;
+}
 static int fused_floats_of(const ScanArgs& a) { return a.lut ? 0 : a.m * a.ds + a.m; }
 // fused finish (scan_packed_kernel RM > 0): instantiated for merged lists of up to kFuseMaxR registers
 // (k <= 248); its merge buffers -- waves x 64 RM keys -- lie over the LUT, the un-permute rows and the queues
@@ -1754,7 +2095,8 @@ static bool fuse_fits(int m, int RM) {
   X(4) X(8) X(12) X(16) X(20) X(24) X(28) X(32) X(40) X(48) X(56) X(64) X(96) X(120) X(128)
 #define TPQ_DECLARE_PACKED(M) \
   int dispatch_packed_##M(const ScanArgs& a, const ResidualArgs* ra, int RL, int R, hipStream_t st); \
-  int dispatch_pool_##M(const ScanArgs& a, int RL, hipStream_t st);
+  int dispatch_pool_##M(const ScanArgs& a, int RL, hipStream_t st);                                  \
+  int dispatch_dump_##M(const ScanArgs& a, int RL, int R, int sel16, hipStream_t st);
 TPQ_PACKED_M_LIST(TPQ_DECLARE_PACKED)
 #undef TPQ_DECLARE_PACKED
 
@@ -1774,7 +2116,7 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // workspace: [flags nq*4][delta nq*4][lists nq*n_lists*64R*8]; n_lists = n_split (reference
 // kernel, only when n_split > 1) or n_split * waves-per-workgroup (packed kernel, always)
 static size_t ws_bytes_for(int nq, int R, int n_lists) {
-  return 2 * align256((size_t)nq * 4) + (size_t)nq * n_lists * R * 64 * 8;
+  return 2 * align256((size_t)nq * 4) + (size_t)nq * n_lists * R * 64 * 8 + align256((size_t)nq * n_lists * 4);
 }
 
 // pool mode workspace: [flags][delta][pool hi nq*n_lists*cap][pool lo ...][counts nq*n_lists]
@@ -1801,6 +2143,7 @@ static void fill_ws(ScanArgs& a, void* workspace, int R, int n_lists) {
   char* lists = p + 2 * align256((size_t)a.nq * 4);
   a.ws_vals = reinterpret_cast<float*>(lists);
   a.ws_idx = reinterpret_cast<int*>(lists + (size_t)a.nq * n_lists * R * 64 * 4);
+  a.list_evict = reinterpret_cast<int*>(lists + (size_t)a.nq * n_lists * R * 64 * 8);  // (dump modes)
 }
 
 static int validate(const ScanArgs& a) {

@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace tpq {
 namespace scan_layout {
 
@@ -51,6 +53,17 @@ __host__ __device__ constexpr int lut_dword(int m, int j, int c) {
   return k.base * 256 + c * k.size + (j - k.base);
 }
 
+// 16-bit selection table (scan_device.h "sel16"): HALFWORD of entry (j, c).  A 64-block keeps the two halves of its
+// sub-quantizers interleaved -- halfword c*64 + 2*(j' & 31) + (j' >> 5), j' = j - base -- so that the dword, hence the
+// bank, is c*32 + (j' & 31): the 32 lanes of a half-wave (32 distinct j' & 31) read 32 distinct banks.  Smaller blocks
+// (tails of an m that is not a multiple of 64) are laid out plainly.
+__host__ __device__ constexpr int lut16_halfword(int m, int j, int c) {
+  const Block k = block_of(m, j);
+  const int r = j - k.base;
+  if (k.size == 64) return k.base * 256 + c * 64 + ((r & 31) << 1) + (r >> 5);
+  return k.base * 256 + c * k.size + r;
+}
+
 // sub-quantizer stored at byte position p of the slot with address s (an involution in p)
 __host__ __device__ constexpr int subq_at(int m, int p, int64_t s) {
   const Block k = block_of(m, p);
@@ -70,6 +83,15 @@ struct BlockAt {
   __host__ __device__ constexpr explicit BlockAt(int p)
       : base(block_of(M, p).base), size(block_of(M, p).size) {}
 };
+
+// f(integral_constant<int, P>) for P = B ... E - 1: a loop whose index is a constant expression in the body
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for_p(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for_p<B + 1, E>(f);
+  }
+}
 
 template <int W>
 struct ChunkT;
@@ -154,6 +176,61 @@ struct Layout {
       acc += tv;
     }
     return acc.x + acc.y;
+  }
+
+  // The same walk over the 16-bit selection table (lut16_halfword): an exact integer sum of m u16 entries.
+  // 64-blocks: byte address = c*128 + (((rel & 31) ^ (s & 31)) << 2) + (((rel >> 5) ^ (s >> 5 & 1)) << 1); per
+  // 16-position quarter h the lane part is a constant, the position's low four bits an inline XOR, the code byte's
+  // << 7 one shift of a sub-dword operand: (lane ^ imm) + (c << 7) -- two VALU per look-up as in accumulate(), and
+  // the adds pair up in v_add3_u32.
+  __device__ static __forceinline__ uint32_t accumulate16(const chunk_t (&w)[kChunks], int s,
+                                                          const uint16_t* __restrict__ lut16) {
+    uint32_t acc[2] = {0u, 0u};
+    uint32_t lane64[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+      lane64[h] = ((((((uint32_t)h & 1u) << 4) ^ ((uint32_t)s & 16u)) | ((uint32_t)s & 15u)) << 2) |
+                  ((((uint32_t)h >> 1) ^ (((uint32_t)s >> 5) & 1u)) << 1);
+    // the table's LDS byte address as an INTEGER folded into the lane constants (a multiple of 128: it commutes with
+    // the XOR of the position bits); the look-up then reads straight from the computed address -- formed as pointer +
+    // offset, every look-up carried one more v_add_u32 of the (zero) base
+    typedef const __attribute__((address_space(3))) uint16_t* lds_u16_ptr;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(lds_u16_ptr)lut16;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) lane64[h] += lbase;
+    const uint32_t seven = 7u;
+    static_for_p<0, M>([&](auto p_c) {
+      constexpr int pp = decltype(p_c)::value;
+      constexpr BlockAt<M> kb(pp);
+      const uint32_t wd = word(w, pp >> 2);
+      uint32_t t;
+      if constexpr (kb.size == 64) {
+        constexpr int rel = pp - kb.base;
+        // address = (lane part ^ position bits) + (code byte << 7): the byte shifted straight out of the code dword
+        // (SDWA), the XOR and the add in one v_xad_u32.  Written as asm: hipcc, seeing that the two parts share no
+        // bits, rewrites the sum into bfe + lshl_or + xor (+ an add3 with 0) -- three to four VALU per look-up
+        uint32_t a;
+        if constexpr ((pp & 3) == 0)
+          asm("v_lshlrev_b32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+              "v_xad_u32 %0, %1, %4, %0" : "=&v"(a) : "v"(lane64[rel >> 4]), "v"(seven), "v"(wd), "n"((rel & 15) << 2));
+        else if constexpr ((pp & 3) == 1)
+          asm("v_lshlrev_b32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+              "v_xad_u32 %0, %1, %4, %0" : "=&v"(a) : "v"(lane64[rel >> 4]), "v"(seven), "v"(wd), "n"((rel & 15) << 2));
+        else if constexpr ((pp & 3) == 2)
+          asm("v_lshlrev_b32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+              "v_xad_u32 %0, %1, %4, %0" : "=&v"(a) : "v"(lane64[rel >> 4]), "v"(seven), "v"(wd), "n"((rel & 15) << 2));
+        else
+          asm("v_lshlrev_b32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+              "v_xad_u32 %0, %1, %4, %0" : "=&v"(a) : "v"(lane64[rel >> 4]), "v"(seven), "v"(wd), "n"((rel & 15) << 2));
+        t = *(lds_u16_ptr)(uintptr_t)(a + (uint32_t)(kb.base * 512));
+      } else {
+        const uint32_t c = (wd >> (8 * (pp & 3))) & 255u;
+        const int lane_part = (pp - kb.base) ^ (s & (kb.size - 1));
+        t = lut16[kb.base * 256 + (int)c * kb.size + lane_part];
+      }
+      acc[(pp >> 1) & 1] += t;
+    });
+    return acc[0] + acc[1];
   }
 };
 

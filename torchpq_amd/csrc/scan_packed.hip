@@ -66,6 +66,64 @@ static int launch_pool(ScanArgs a, hipStream_t st) {
   return TPQ_OK;
 }
 
+// dump modes (scan_device.h): the scan ends with the waves' lists of fast values; scan_finish_exact_kernel, one wave per
+// query, evaluates the band's survivors exactly and writes the result.  Instantiated for m = 64 (the 16-bit table).
+constexpr bool has_dump(int M) { return M == 64; }
+constexpr bool has_sel16(int M) { return M == 64; }
+// the finish kernel: survivors in RM = 2 or 4 registers (k <= 56 rides on 2), sub-vector length 1 / 2, 4 or 8 chunks
+template <int RM, int M>
+static int launch_finish(const ScanArgs& a, int nw_scan, int RL, hipStream_t st) {
+  if constexpr (!has_dump(M)) {
+    return TPQ_ERR_UNSUPPORTED;
+  } else {
+    const size_t flds = finish_lds_bytes(M, a.ds, RM);
+    // one persistent workgroup per CU (its LDS holds the codebook)
+    int dev = 0, n_cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus <= 0)
+      n_cus = 256;
+    const int want = (a.nq + kFinishWaves - 1) / kFinishWaves;
+    const dim3 grid((unsigned)(want < n_cus ? want : n_cus)), block(kFinishWaves * 64);
+    auto go = [&](auto kernel) -> int {
+      int rc = set_lds(kernel, flds, "scan_finish_exact_kernel");
+      if (rc) return rc;
+      hipLaunchKernelGGL(kernel, grid, block, flds, st, a, nw_scan, RL);
+      TPQ_LAUNCH_CHECK("scan_finish_exact_kernel");
+      return TPQ_OK;
+    };
+    const int T = a.n_split * nw_scan * RL;
+    if (a.ds == 1) return T <= 4 ? go(scan_finish_exact_kernel<RM, M, 1, 4>) : go(scan_finish_exact_kernel<RM, M, 1, 8>);
+    return T <= 4 ? go(scan_finish_exact_kernel<RM, M, 2, 4>) : go(scan_finish_exact_kernel<RM, M, 2, 8>);
+  }
+}
+
+template <int RL, int R, int M, int MODE>
+static int launch_dump(ScanArgs a, hipStream_t st) {
+  if constexpr (!has_dump(M) || (MODE == kDumpSel16 && !has_sel16(M))) {
+    set_error("scan_packed (dump mode): not instantiated for n_subvectors=%d", M);
+    return TPQ_ERR_UNSUPPORTED;
+  } else {
+    const size_t lds = scan_lds_bytes_dump(M, MODE == kDumpSel16, a.max_nprobe, fused_floats_of(a));
+    int rc = set_lds(scan_packed_kernel<RL, M, false, MODE>, lds, "scan_packed_kernel (dump mode)");
+    if (rc) return rc;
+    const float delta_rel = 1.05f * 2.0f * 5.9604645e-8f * (float)(M - 1);
+    constexpr int NW = scan_waves(M, MODE);
+    hipLaunchKernelGGL((scan_packed_kernel<RL, M, false, MODE>), dim3((unsigned)a.nq * a.n_split), dim3(NW * 64), lds,
+                       st, a, ResidualArgs{}, delta_rel);
+    TPQ_LAUNCH_CHECK("scan_packed_kernel (dump mode)");
+    return launch_finish<(R < 2 ? 2 : R), M>(a, NW, RL, st);
+    return TPQ_OK;
+  }
+}
+template <int M, int MODE>
+static int dispatch_dump_mode(const ScanArgs& a, int RL, int R, hipStream_t st) {
+#define TPQ_PAIR(A, B) if (RL == A && R == B) return launch_dump<A, B, M, MODE>(a, st);
+  TPQ_PAIR(1, 1) TPQ_PAIR(1, 2) TPQ_PAIR(2, 2) TPQ_PAIR(1, 4) TPQ_PAIR(2, 4)
+#undef TPQ_PAIR
+  set_error("scan_packed (dump mode): no instantiation for list registers (%d, %d)", RL, R);
+  return TPQ_ERR_UNSUPPORTED;
+}
+
 template <int M, bool RES>
 static int dispatch_r(const ScanArgs& a, const ResidualArgs& ra, int RL, int R, hipStream_t st) {
   if (RL == R) {
@@ -106,6 +164,11 @@ int TPQ_CAT(dispatch_pool_, TPQ_PACKED_M)(const ScanArgs& a, int RL, hipStream_t
   }
   set_error("scan_packed (pool mode): no instantiation for %d list registers", RL);
   return TPQ_ERR_UNSUPPORTED;
+}
+
+int TPQ_CAT(dispatch_dump_, TPQ_PACKED_M)(const ScanArgs& a, int RL, int R, int sel16, hipStream_t st) {
+  (void)sel16;  // (the fp32-table dump mode, kDumpF32, is not instantiated: the 16-bit table is the one in use)
+  return dispatch_dump_mode<TPQ_PACKED_M, kDumpSel16>(a, RL, R, st);
 }
 
 int TPQ_CAT(dispatch_packed_, TPQ_PACKED_M)(const ScanArgs& a, const ResidualArgs* ra, int RL, int R,
