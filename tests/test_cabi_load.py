@@ -89,9 +89,10 @@ def test_argument_validation_without_a_gpu():
     assert rc == -1 and "null pointer" in _lib.last_error()
     rc = lib.tpq_ivfpq_pack_codes(None, None, 10, 8, 0, 10, None)
     assert rc == -1
-    # flags + error bounds + per-wave candidate lists (8 waves per workgroup at m <= 64, 16 above)
-    assert lib.tpq_ivfpq_scan_workspace_bytes(100, 100, 1, 64) == 2 * 512 + 100 * 8 * 128 * 8
-    assert lib.tpq_ivfpq_scan_workspace_bytes(100, 100, 4, 120) == 2 * 512 + 100 * 4 * 16 * 128 * 8
+    # flags + error bounds + per-wave candidate lists (8 waves per workgroup at m <= 64, 16 above) + one "may have
+    # evicted a candidate" word per list (the dump route's finish kernel), rounded up to 256 bytes
+    assert lib.tpq_ivfpq_scan_workspace_bytes(100, 100, 1, 64) == 2 * 512 + 100 * 8 * 128 * 8 + 3328
+    assert lib.tpq_ivfpq_scan_workspace_bytes(100, 100, 4, 120) == 2 * 512 + 100 * 4 * 16 * 128 * 8 + 25600
     assert lib.tpq_compute_centroids_workspace_bytes(2, 3, 5) == (2 * 3 * 5 + 2 * 5) * 4
 
 
