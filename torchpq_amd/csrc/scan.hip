@@ -81,7 +81,13 @@ extern "C" size_t tpq_ivfpq_scan_workspace_bytes(int nq, int k, int n_split, int
   if (n_split < 1) n_split = 1;
   int R = list_regs_packed(k) > list_regs(k) ? list_regs_packed(k) : list_regs(k);
   if (R > 16) R = 16;
-  const size_t lists = ws_bytes_for(nq, R, n_split * packed_waves(m));  // covers both kernels
+  // covers both kernels -- and, at m = 64, the dump route's split tail: 4 parts x 4 waves of lists per query
+  size_t lists = ws_bytes_for(nq, R, n_split * packed_waves(m));
+  if (m == 64 && list_regs_packed(k) <= kFuseMaxR) {
+    const int rp = list_regs_packed(k);
+    const size_t tail = ws_bytes_for(nq, rp < 2 ? rp : 2, 16);
+    lists = tail > lists ? tail : lists;
+  }
   const size_t pools = list_regs_packed(k) >= pool_min_list_regs(m) ? pool_ws_bytes(nq, k, m, n_split * packed_waves(m)) : 0;  // pool mode
   return lists > pools ? lists : pools;
 }
@@ -119,7 +125,7 @@ static int fresh_epoch() {
 // large batches of plain PQ at m = 64, k <= 248: dump mode over the 16-bit table (scan_device.h).
 // (variants: TPQ_SCAN_DUMP=0 keeps the one-launch finish)
 static bool dump_route(const ScanArgs& a, bool residual, int R) {
-  if (residual || R > kFuseMaxR || a.n_split != 1) return false;
+  if (residual || R > kFuseMaxR || a.n_split != 1) return false;  // (the route deals the queries itself: dump_tail)
   // the finish kernel recomputes the survivors' table entries from the codebook, held in LDS next to nothing else:
   // fused calls (query + codebook) only, m * ds <= 128
   if (a.lut || a.m != 64 || a.ds > 2) return false;
@@ -128,6 +134,35 @@ static bool dump_route(const ScanArgs& a, bool residual, int R) {
   const char* e = TPQ_AB_ENV("TPQ_SCAN_DUMP");
   if (e && atoi(e) == 0) return false;
   return a.nq >= kDumpMinQueries;
+}
+
+// The batch's last round of workgroups (ScanArgs::unsplit): the chip holds 4 dump-mode workgroups per CU; the
+// nq mod slots queries left after the full rounds are dealt in 4 (or 2) parts each when those parts fit one round and
+// the finish kernel can take their lists (<= 16 chunks of 64 keys per query) -- 1 250 queries: 1 024 whole + 226 x 4.
+static int device_cus() {
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] <= 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+static void dump_tail(int nq, int nw, int RL, int slots, int* unsplit, int* parts) {
+  *unsplit = nq;
+  *parts = 1;
+  if (slots <= 0) return;
+  const int whole = (nq / slots) * slots, rest = nq - whole;
+  if (rest == 0) return;
+  for (int c = 4; c >= 2; c >>= 1) {
+    if ((int64_t)rest * c <= slots && c * nw * RL <= 16) {
+      *unsplit = whole;
+      *parts = c;
+      return;
+    }
+  }
 }
 
 static bool has_packed_kernel(int m) {
@@ -304,9 +339,15 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
       const bool sel16 = true;
       const int nw = 4;
       const int RLd = list_regs_scan(k, m, a.max_nprobe, a.slots_hint, nw);
-      rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, RLd, n_split * nw), "ivfpq_scan_packed");
+      int unsplit = nq, parts = 1;
+      dump_tail(nq, nw, RLd, 4 * device_cus(), &unsplit, &parts);
+      // (a caller's workspace sized by an older rule: the tail stays whole)
+      if (parts > 1 && (!workspace || workspace_bytes < ws_bytes_for(nq, RLd, parts * nw))) unsplit = nq, parts = 1;
+      a.n_split = parts;
+      a.unsplit = parts > 1 ? unsplit : 0;  // (0 with one part per query: "all queries split 1 way")
+      rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, RLd, parts * nw), "ivfpq_scan_packed");
       if (rc) return rc;
-      fill_ws(a, workspace, RLd, n_split * nw);
+      fill_ws(a, workspace, RLd, parts * nw);
       a.epoch = fresh_epoch();
       a.fuse = 0;
       a.tickets = nullptr;

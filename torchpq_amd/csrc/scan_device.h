@@ -62,6 +62,13 @@ struct ScanArgs {
   int pool_cap;
   // dump mode (scan_packed_kernel RM <= kDumpF32): [nq][n_lists] 1 = the wave's list may have evicted a candidate
   int* list_evict;
+  // dump mode, "tail split": queries [0, unsplit) run as ONE workgroup each, queries [unsplit, nq) as n_split
+  // workgroups each (0 = every query is split n_split ways, the meaning of n_split everywhere else).  A batch that is
+  // not a multiple of the chip's workgroup slots ends with a round of few workgroups, each as long as a whole query
+  // (1 250 queries on 1 024 slots: two rounds for 1.22 rounds of work); the queries of that last round are dealt
+  // as short workgroups instead -- they start last (workgroups are dispatched in index order) and fill the slots
+  // the long ones leave.  The lists keep the stride of n_split parts for every query.
+  int unsplit;
 };
 
 // scan_packed_kernel modes beyond the fused finish (RM > 0) and the pools (RM = -1, -2, -3): "dump" -- the scan
@@ -955,8 +962,18 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
   float* xq = reinterpret_cast<float*>(pcell + (RES ? a.max_nprobe : 0));
   const int wave = threadIdx.x >> 6;
   const int lane = lane_id();
-  const int q = blockIdx.x / a.n_split;
-  const int part = blockIdx.x - q * a.n_split;
+  int q, part, parts;  // query, this workgroup's part of it, the parts it is dealt in
+  if (DUMP && (int)blockIdx.x < a.unsplit) {  // (tail split, ScanArgs::unsplit: the leading queries are not split)
+    q = (int)blockIdx.x;
+    part = 0;
+    parts = 1;
+  } else {
+    const int first = DUMP ? a.unsplit : 0;
+    const int b = (int)blockIdx.x - first;
+    q = first + b / a.n_split;
+    part = b - (q - first) * a.n_split;
+    parts = a.n_split;
+  }
   TPQ_PROF(a, blockIdx.x, 0);
   int n_probe = (int)a.n_probe_list[q];
   n_probe = n_probe < 0 ? 0 : (n_probe > a.max_nprobe ? a.max_nprobe : n_probe);
@@ -1071,8 +1088,8 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
   }
 
   const int total_tiles = tab.tile_begin[n_probe];
-  const int t_begin = (int)(((int64_t)total_tiles * part) / a.n_split);
-  const int t_end = (int)(((int64_t)total_tiles * (part + 1)) / a.n_split);
+  const int t_begin = (int)(((int64_t)total_tiles * part) / parts);
+  const int t_end = (int)(((int64_t)total_tiles * (part + 1)) / parts);
 
   // Workgroup-shared admission threshold.  Two valid lower bounds of the final k-th best:
   //  (a) any wave's own k-th best (tau_key, atomic max);
@@ -1839,11 +1856,14 @@ __global__ __launch_bounds__(kFinishWaves * 64) void scan_finish_exact_kernel(Sc
   }
   int* qi = reinterpret_cast<int*>(cb + M * DS * 256) + wave * (RM * 64);  // the wave's survivors (addresses)
   __syncthreads();
-  const int n_lists = a.n_split * nw_scan;
-  const int T = n_lists * RL;  // chunks in use (<= NCH)
+  const int n_lists_all = a.n_split * nw_scan;
+  const int T_all = n_lists_all * RL;  // chunks per query in the workspace (<= NCH)
   const bool euclid = a.euclid != 0;
   for (int q = (int)blockIdx.x * kFinishWaves + wave; q < a.nq; q += (int)gridDim.x * kFinishWaves) {
     if (a.flags[q] == a.epoch) continue;  // the scan left the query to the exact kernel
+    // (tail split: an unsplit query filled the lists of its one part only; the stride is that of n_split parts)
+    const int n_lists = q < a.unsplit ? nw_scan : n_lists_all;
+    const int T = n_lists * RL;  // chunks in use
     // the query: component i in lane i % 64 of register i / 64; |q_j|^2 (ascending-dimension fma chain) in lane j
     float xv[2] = {0.f, 0.f}, q2v = 0.f;
     if (lane < M * DS) xv[0] = a.query[(int64_t)lane * a.nq + q];
@@ -1855,8 +1875,8 @@ __global__ __launch_bounds__(kFinishWaves * 64) void scan_finish_exact_kernel(Sc
         q2v = fmaf(x, x, q2v);
       }
     }
-    const unsigned* __restrict__ bv = reinterpret_cast<const unsigned*>(a.ws_vals) + (int64_t)q * T * 64;
-    const unsigned* __restrict__ bi = reinterpret_cast<const unsigned*>(a.ws_idx) + (int64_t)q * T * 64;
+    const unsigned* __restrict__ bv = reinterpret_cast<const unsigned*>(a.ws_vals) + (int64_t)q * T_all * 64;
+    const unsigned* __restrict__ bi = reinterpret_cast<const unsigned*>(a.ws_idx) + (int64_t)q * T_all * 64;
     unsigned hi[NCH];
     int ix[NCH];
 #pragma unroll
@@ -1866,7 +1886,7 @@ __global__ __launch_bounds__(kFinishWaves * 64) void scan_finish_exact_kernel(Sc
       if (ix[t] == kPadIdx) hi[t] = 0u;
     }
     int evict = 0;
-    if (lane < n_lists) evict = a.list_evict[(int64_t)q * n_lists + lane];
+    if (lane < n_lists) evict = a.list_evict[(int64_t)q * n_lists_all + lane];
     const float band = a.ws_delta[q];
     // F_k: the largest key image t with at least k entries >= t (0 while fewer than k entries exist)
     unsigned fk = 0u;

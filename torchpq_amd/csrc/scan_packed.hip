@@ -91,9 +91,12 @@ static int launch_finish(const ScanArgs& a, int nw_scan, int RL, hipStream_t st)
       TPQ_LAUNCH_CHECK("scan_finish_exact_kernel");
       return TPQ_OK;
     };
-    const int T = a.n_split * nw_scan * RL;
-    if (a.ds == 1) return T <= 4 ? go(scan_finish_exact_kernel<RM, M, 1, 4>) : go(scan_finish_exact_kernel<RM, M, 1, 8>);
-    return T <= 4 ? go(scan_finish_exact_kernel<RM, M, 2, 4>) : go(scan_finish_exact_kernel<RM, M, 2, 8>);
+    const int T = a.n_split * nw_scan * RL;  // (16: the split tail of a batch, ScanArgs::unsplit)
+    if (a.ds == 1)
+      return T <= 4 ? go(scan_finish_exact_kernel<RM, M, 1, 4>)
+                    : (T <= 8 ? go(scan_finish_exact_kernel<RM, M, 1, 8>) : go(scan_finish_exact_kernel<RM, M, 1, 16>));
+    return T <= 4 ? go(scan_finish_exact_kernel<RM, M, 2, 4>)
+                  : (T <= 8 ? go(scan_finish_exact_kernel<RM, M, 2, 8>) : go(scan_finish_exact_kernel<RM, M, 2, 16>));
   }
 }
 
@@ -108,8 +111,9 @@ static int launch_dump(ScanArgs a, hipStream_t st) {
     if (rc) return rc;
     const float delta_rel = 1.05f * 2.0f * 5.9604645e-8f * (float)(M - 1);
     constexpr int NW = scan_waves(M, MODE);
-    hipLaunchKernelGGL((scan_packed_kernel<RL, M, false, MODE>), dim3((unsigned)a.nq * a.n_split), dim3(NW * 64), lds,
-                       st, a, ResidualArgs{}, delta_rel);
+    const unsigned blocks = (unsigned)a.unsplit + (unsigned)(a.nq - a.unsplit) * (unsigned)a.n_split;
+    hipLaunchKernelGGL((scan_packed_kernel<RL, M, false, MODE>), dim3(blocks), dim3(NW * 64), lds, st, a,
+                       ResidualArgs{}, delta_rel);
     TPQ_LAUNCH_CHECK("scan_packed_kernel (dump mode)");
     return launch_finish<(R < 2 ? 2 : R), M>(a, NW, RL, st);
     return TPQ_OK;
