@@ -41,6 +41,18 @@ def test_gist_shape_after_the_100m_scan_in_one_process():
     assert after["frac"] >= 0.6, after
 
 
+def test_traffic_is_measured_in_the_run_that_quotes_it():
+    """bench.py's HBM-bound records carry the FETCH_SIZE of a rocprofv3 --pmc child pass of the same run (corrected per
+    MI355X_MICROARCH.md), not a replay of a committed profile; a box without a working rocprofv3 falls back to the
+    replay and says so"""
+    r = _secondary("c3")["c3"]["roofline"]
+    if not r.get("traffic_measured_in_this_run"):
+        pytest.skip("the counter pass did not run here: " + str(r.get("traffic_source") or r.get("traffic_note")))
+    assert r["traffic"] > 0 and "rocprofv3 --pmc FETCH_SIZE" in r["traffic_source"]
+    # 1 000 queries x 64 of 1 024 cells: lists are shared between queries (L2 / Infinity Cache hits), never re-read
+    assert 0.3 <= r["traffic_over_algorithmic"] <= 1.15, r
+
+
 def test_c1_record_oracle_cpu_leg_and_the_same_index_on_the_gpu():
     c1 = _secondary("c1")["c1"]
     assert "error" not in c1, c1

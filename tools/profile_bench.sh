@@ -18,11 +18,11 @@ for W in $WORKLOADS; do
   OUT="${ROOT}/gpurun_out/${TAG}/${W}"
   mkdir -p "$OUT"
   case "$W" in
-    c2) BENCH="python ${ROOT}/bench.py --steps 20 --warmup 3 --no-secondary"; KERNEL="scan_packed_kernel";;
-    c3) BENCH="python ${ROOT}/bench.py --secondary-only c3"; KERNEL="scan_packed_kernel";;
-    c4) BENCH="python ${ROOT}/bench.py --secondary-only c4"; KERNEL="scan_packed_kernel";;
-    c5) BENCH="python ${ROOT}/bench.py --secondary-only c5"; KERNEL="coarse_kernel";;
-    wide) BENCH="python ${ROOT}/bench.py --secondary-only wide"; KERNEL="gemm_kernel";;
+    c2) BENCH="python ${ROOT}/bench.py --steps 20 --warmup 3 --no-secondary --no-traffic-pass"; KERNEL="scan_packed_kernel";;
+    c3) BENCH="python ${ROOT}/bench.py --secondary-only c3 --no-traffic-pass"; KERNEL="scan_packed_kernel";;
+    c4) BENCH="python ${ROOT}/bench.py --secondary-only c4 --no-traffic-pass"; KERNEL="scan_packed_kernel";;
+    c5) BENCH="python ${ROOT}/bench.py --secondary-only c5 --no-traffic-pass"; KERNEL="coarse_kernel";;
+    wide) BENCH="python ${ROOT}/bench.py --secondary-only wide --no-traffic-pass"; KERNEL="gemm_kernel";;
   esac
   $BENCH > "$OUT/bench.json" 2> "$OUT/bench.err"
   tail -c 600 "$OUT/bench.json"; echo

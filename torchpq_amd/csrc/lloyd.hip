@@ -1213,6 +1213,11 @@ struct UpdArgs {
 // spilled.  The four waves of a block read the same rows: one trip to HBM, the rest from L2 / L1.)
 // NH = cluster halves per dimension tile (1: a wave owns all 256 clusters, 128 accumulator registers, two
 // waves per SIMD; 2: 128 clusters, three waves per SIMD)
+// (Round 5, same box, C5: one extra dword load per wave and tile touching the 32 cache lines of the tile two / four steps
+// on -- to start their trip from HBM early, since a wave has one tile's fragments in flight -- made the update SLOWER:
+// 3.85 -> 4.0 / 5.0 ms.  The kernel is not waiting on HBM latency: matrix pipe 41 % busy, 46 % of the wave cycles issuing,
+// profiles/r04_c5.json; its time is the per-tile chain load -> transposing MFMAs -> pack -> one-hot rows through LDS -> MFMAs
+// of two waves per SIMD, and more requests on the memory path lengthen it.)
 template <int KS, int NH>
 __global__ __launch_bounds__(64 * NH * ((KS + 1) / 2), (NH == 1 ? 2 : 3)) void update_kernel(UpdArgs a) {
   constexpr int DT = (KS + 1) / 2;
