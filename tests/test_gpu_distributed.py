@@ -147,3 +147,61 @@ def test_bench_deadline_prints_one_error_line_instead_of_hanging():
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["value"] is None and "deadline" in rec["error"] and rec["world_size_seen"] == 2
+
+
+_RCCL_ONE = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+import numpy as np
+import torch
+import torch.distributed as dist
+from torchpq_amd import distributed as tpd
+from torchpq_amd.index import IVFPQIndex
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+g = tpd.init_groups(dev, want_rccl=True, timeout_s=120)
+out = {"bulk_backend": g.bulk_backend, "bulk_error": g.bulk_error}
+rng = np.random.default_rng(5)
+xb = torch.from_numpy(np.abs(rng.standard_normal((32, 6000)) * 25).astype(np.float32)).to(dev)
+np.random.seed(5)
+idx = IVFPQIndex(d_vector=32, n_subvectors=8, n_cells=16, initial_size=8, device="cuda:0")
+idx.train(xb)
+idx.add(xb)
+idx.n_probe = 4
+v0, i0 = idx.search(xb[:, :64].contiguous(), k=5)
+torch.cuda.synchronize()
+tpd.host_barrier()
+tpd.replicate_index(idx, src=0, bulk_group=g.bulk, chunk_bytes=1 << 16)   # (many chunks: the chunked path on RCCL)
+torch.cuda.synchronize()
+v1, i1 = idx.search(xb[:, :64].contiguous(), k=5)
+big = torch.arange(1 << 22, device=dev, dtype=torch.int32)                  # 16 MiB through one RCCL broadcast
+if g.bulk is not None:
+    dist.broadcast(big, src=0, group=g.bulk)
+    t = torch.ones(4, device=dev)
+    dist.all_reduce(t, group=g.bulk)
+    out["all_reduce"] = t.tolist()
+torch.cuda.synchronize()
+out["replicated_bytes"] = int(idx.replicated_bytes)
+out["same"] = bool(torch.equal(v0, v1) and torch.equal(i0, i1) and int(big[-1]) == (1 << 22) - 1)
+print(json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_itself_executes_with_one_rank():
+    """The bulk plane of bench.py --gpus N is RCCL; a 1-GPU box cannot hold two RCCL ranks, but it can hold ONE: the
+    group is created on the device, probed, and carries the chunked index broadcast, a 16-MiB broadcast and an
+    all-reduce -- librccl loads, its kernels launch, HSA_ENABLE_IPC_MODE_LEGACY=0 is in effect."""
+    port = 29700 + (os.getpid() % 2000)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", _RCCL_ONE, ROOT, str(port)], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["bulk_backend"] == "nccl", out
+    assert out["bulk_error"] is None and out["same"] and out["replicated_bytes"] > 0
+    assert out["all_reduce"] == [1.0, 1.0, 1.0, 1.0]
