@@ -40,6 +40,14 @@ def test_k_and_sub_vector_lengths_on_a_split_tail(ds, k, n_probe, cell):
     assert out["equal"], out
 
 
+@pytest.mark.parametrize("k,cell,n_probe,nq", [(249, 977, 32, 2048), (300, 977, 32, 1500), (500, 977, 16, 1024),
+                                               (504, 500, 40, 1200), (400, 244, 32, 1100)])
+def test_k_up_to_504_rides_the_route_too(k, cell, n_probe, nq):
+    # (the last case -- short cells, no "spread" -- asks for lists of 8 registers: left to the sorted lists)
+    out = _run(m=64, ds=2, nc=1024, cell=cell, n_probe=n_probe, k=k, nq=nq, fused=True, skew=True, holes=True)
+    assert out["equal"], out
+
+
 def test_tables_the_16_bit_scale_cannot_hold_go_to_the_exact_kernel():
     """queries whose table has an Inf / a huge entry are flagged by the scan and redone by the exact kernel"""
     from torchpq_amd import kernels as K

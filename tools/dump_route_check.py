@@ -74,8 +74,26 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--large-k", action="store_true", help="k in (248, 504] at the C2 shape (and two shapes the route leaves to the lists)")
+    ap.add_argument("--large-k-sweep", action="store_true")
+    ap.add_argument("--one", default=None, help="m,ds,cells,cell,n_probe,k,nq: that shape only (fused, no check)")
     args = ap.parse_args()
     from torchpq_amd import kernels as K
+    if args.one:
+        print(json.dumps(run(K, *[int(x) for x in args.one.split(",")], True, args.iters, False)), flush=True)
+        return
+    if args.large_k_sweep:  # where lists of 4 registers in 4-wave workgroups stop paying: slots per query x k
+        for k in (300, 500):
+            for cell, n_probe in ((244, 16), (244, 32), (244, 64), (977, 8), (977, 16), (977, 24), (977, 32), (977, 64)):
+                print(json.dumps(run(K, 64, 2, 4096 if cell == 244 else 1024, cell, n_probe, k, 10000, True, args.iters,
+                                     False)), flush=True)
+        return
+    if args.large_k:
+        for k in (200, 249, 300, 400, 500, 504):
+            print(json.dumps(run(K, 64, 2, 1024, 977, 32, k, 10000, True, args.iters, not args.no_check)), flush=True)
+        print(json.dumps(run(K, 64, 2, 4096, 244, 32, 300, 10000, True, args.iters, not args.no_check)), flush=True)
+        print(json.dumps(run(K, 64, 1, 1024, 600, 20, 450, 3000, True, 5, not args.no_check, skew=True, holes=True)), flush=True)
+        return
     shapes = [  # m, ds, cells, cell, n_probe, k, nq
         (64, 2, 1024, 977, 32, 100, 10000), (64, 2, 4096, 244, 16, 100, 10000), (64, 2, 4096, 244, 8, 100, 10000),
         (64, 2, 16384, 61, 32, 100, 10000), (64, 2, 4096, 244, 64, 100, 10000), (64, 2, 16384, 61, 128, 100, 10000),

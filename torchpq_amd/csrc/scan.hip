@@ -83,10 +83,11 @@ extern "C" size_t tpq_ivfpq_scan_workspace_bytes(int nq, int k, int n_split, int
   if (R > 16) R = 16;
   // covers both kernels -- and, at m = 64, the dump route's split tail: 4 parts x 4 waves of lists per query
   size_t lists = ws_bytes_for(nq, R, n_split * packed_waves(m));
-  if (m == 64 && list_regs_packed(k) <= kFuseMaxR) {
+  if (m == 64 && dump_finish_regs(k, 1) <= kDumpMaxR) {
     const int rp = list_regs_packed(k);
-    const size_t tail = ws_bytes_for(nq, rp < 2 ? rp : 2, 16);
+    const size_t tail = ws_bytes_for(nq, rp < 2 ? rp : 2, 16), whole = ws_bytes_for(nq, rp < 4 ? rp : 4, 4);
     lists = tail > lists ? tail : lists;
+    lists = whole > lists ? whole : lists;
   }
   const size_t pools = list_regs_packed(k) >= pool_min_list_regs(m) ? pool_ws_bytes(nq, k, m, n_split * packed_waves(m)) : 0;  // pool mode
   return lists > pools ? lists : pools;
@@ -122,18 +123,30 @@ static int fresh_epoch() {
   return (int)(((uint32_t)(ns ^ (ns >> 29)) * 0x9e3779b1u) | 1u);
 }
 
-// large batches of plain PQ at m = 64, k <= 248: dump mode over the 16-bit table (scan_device.h).
-// (variants: TPQ_SCAN_DUMP=0 keeps the one-launch finish)
-static bool dump_route(const ScanArgs& a, bool residual, int R) {
-  if (residual || R > kFuseMaxR || a.n_split != 1) return false;  // (the route deals the queries itself: dump_tail)
+// large batches of plain PQ at m = 64, k <= 504: dump mode over the 16-bit table (scan_device.h).
+// (variants: TPQ_SCAN_DUMP=0 keeps the one-launch finish / the lists)
+// returns 0 (not this route), kDumpSel16 (four-wave workgroups) or kDumpSel16W8 (eight-wave workgroups: k in (248, 504]
+// where four waves would need longer lists than eight -- long cells; lists of <= 2 registers, 16 chunks per query)
+static int dump_route(const ScanArgs& a, bool residual, int R) {
+  if (residual || R > kDumpMaxR || a.n_split != 1) return 0;  // (the route deals the queries itself: dump_tail)
   // the finish kernel recomputes the survivors' table entries from the codebook, held in LDS next to nothing else:
   // fused calls (query + codebook) only, m * ds <= 128
-  if (a.lut || a.m != 64 || a.ds > 2) return false;
-  // (it takes a query's lists as at most 8 chunks of 64 keys: four waves x RL <= 2)
-  if (list_regs_scan(a.k, a.m, a.max_nprobe, a.slots_hint, 4) > 2) return false;
+  if (a.lut || a.m != 64 || a.ds > 2 || a.nq < kDumpMinQueries) return 0;
   const char* e = TPQ_AB_ENV("TPQ_SCAN_DUMP");
-  if (e && atoi(e) == 0) return false;
-  return a.nq >= kDumpMinQueries;
+  if (e && atoi(e) == 0) return 0;
+  // (the finish kernel takes a query's lists as at most 16 chunks of 64 keys: four waves x RL <= 4, eight x RL <= 2)
+  const int rl4 = list_regs_scan(a.k, a.m, a.max_nprobe, a.slots_hint, 4);
+  const int rl8 = list_regs_scan(a.k, a.m, a.max_nprobe, a.slots_hint);
+  // Lists of 4 registers in four-wave workgroups only where eight waves would need them as well (short cells, k > 256):
+  // folding into a 256-entry list is what a large k costs, and four waves see twice the candidates each.
+  // Same box, 10 000 queries, ms, four waves / the sorted lists of the three-launch path: k = 300, 244-slot cells x
+  // 16 / 32 / 64 probes: 1.48 / 1.98 / 2.92 against 2.23 / 2.83 / 3.91 (k = 500: 1.74 / 2.51 / 3.61 against 2.63 / 3.33
+  // / 4.47) -- both at 4 registers; 977-slot cells x 8 / 32 probes, k = 300: 1.91 / 4.37 against 1.69 / 3.45 -- 4
+  // registers against 2: those take the eight-wave form.
+  if (rl4 <= 2 || (rl4 <= 4 && rl4 <= rl8)) return kDumpSel16;
+  if (e && atoi(e) == 1) return 0;  // (variants: TPQ_SCAN_DUMP=1 = four waves or the lists)
+  if (a.k > 248 && rl8 <= 2) return kDumpSel16W8;
+  return 0;
 }
 
 // The batch's last round of workgroups (ScanArgs::unsplit): the chip holds 4 dump-mode workgroups per CU; the
@@ -335,12 +348,12 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
   // large batches of plain PQ at m = 64, k <= 248: dump mode (scan_device.h) -- the scan workgroups stream over the
   // 16-bit table (32 KiB: four workgroups per CU) and end with their lists of fast values, one wave per query finishes
   {
-    if (dump_route(a, ra != nullptr, R)) {
-      const bool sel16 = true;
-      const int nw = 4;
+    const int Rf = dump_finish_regs(k, a.slots_hint);
+    if (const int mode = dump_route(a, ra != nullptr, Rf)) {
+      const int nw = mode == kDumpSel16 ? 4 : packed_waves(m);
       const int RLd = list_regs_scan(k, m, a.max_nprobe, a.slots_hint, nw);
       int unsplit = nq, parts = 1;
-      dump_tail(nq, nw, RLd, 4 * device_cus(), &unsplit, &parts);
+      if (mode == kDumpSel16) dump_tail(nq, nw, RLd, 4 * device_cus(), &unsplit, &parts);
       // (a caller's workspace sized by an older rule: the tail stays whole)
       if (parts > 1 && (!workspace || workspace_bytes < ws_bytes_for(nq, RLd, parts * nw))) unsplit = nq, parts = 1;
       a.n_split = parts;
@@ -353,7 +366,7 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
       a.tickets = nullptr;
       a.small_lists = 0;
       switch (m) {
-#define TPQ_CASE_M(M) case M: rc = dispatch_dump_##M(a, RLd, R, sel16 ? 1 : 0, st); break;
+#define TPQ_CASE_M(M) case M: rc = dispatch_dump_##M(a, RLd, Rf, mode, st); break;
         TPQ_PACKED_M_LIST(TPQ_CASE_M)
 #undef TPQ_CASE_M
         default: rc = TPQ_ERR_UNSUPPORTED; break;

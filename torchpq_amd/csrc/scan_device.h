@@ -76,6 +76,8 @@ struct ScanArgs {
 // merges them, evaluates the band's survivors exactly from global memory and writes the result.
 constexpr int kDumpF32 = -8;     // fp32 table in LDS (m KiB), the permuted-order fp32 sum as the selection key
 constexpr int kDumpSel16 = -16;  // 16-bit fixed-point table (m / 2 KiB), an exact integer sum as the selection key
+constexpr int kDumpSel16W8 = -17;  // the same with the eight waves of the other paths (k in (248, 504]: lists of <= 2 registers)
+constexpr bool is_sel16(int RM) { return RM == kDumpSel16 || RM == kDumpSel16W8; }
 constexpr int kDumpMinQueries = 1024;  // batches that fill the chip's 4 x 256 workgroup slots at least once
 
 #ifdef TPQ_SCAN_PROFILE
@@ -941,7 +943,7 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
                                                                                       ResidualArgs ra,
                                                                                       float delta_rel) {
   using L = scan_layout::Layout<M>;
-  constexpr bool DUMP = RM <= kDumpF32, SEL16 = RM == kDumpSel16, POOL = RM < 0 && !DUMP;
+  constexpr bool DUMP = RM <= kDumpF32, SEL16 = is_sel16(RM), POOL = RM < 0 && !DUMP;
   static_assert(!(DUMP && RES), "dump mode serves plain PQ");
   constexpr int NW = scan_waves(M, RM);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1837,12 +1839,16 @@ __global__ __launch_bounds__(512) void scan_merge_refine_kernel(ScanArgs a) {
 // butterfly: 160 us, instruction-bound at ~6 000 VALU per query; this form: ~2 500.)  Nothing of a scan workgroup's
 // table slot is held while this runs, which is the point of the split: the end of a query idled that slot for 17 of
 // its 43 us.
-constexpr int kFinishWaves = 16;
+// (waves per workgroup: 16 while the survivor queues -- 64 RM addresses per wave -- fit beside the codebook's 128 KiB;
+// RM = 8, k in (248, 504]: 8)
+constexpr int finish_waves(int RM) { return RM <= 8 ? 16 : 8; }  // (RM = 8, ds = 2: 128 + 32 KiB, all of the CU's LDS)
+constexpr int kDumpMaxR = 8;  // registers of the finish kernel's exact list: k <= 504
 static size_t finish_lds_bytes(int m, int ds, int RM) {
-  return (size_t)m * ds * 1024 + (size_t)kFinishWaves * RM * 64 * 4;
+  return (size_t)m * ds * 1024 + (size_t)finish_waves(RM) * RM * 64 * 4;
 }
 template <int RM, int M, int DS, int NCH>
-__global__ __launch_bounds__(kFinishWaves * 64) void scan_finish_exact_kernel(ScanArgs a, int nw_scan, int RL) {
+__global__ __launch_bounds__(finish_waves(RM) * 64) void scan_finish_exact_kernel(ScanArgs a, int nw_scan, int RL) {
+  constexpr int kFinishWaves = finish_waves(RM);
   using L = scan_layout::Layout<M>;
   static_assert(M == 64, "one 64-block: the in-register un-permute below");
   static_assert(M * DS <= 128, "the query rides in two registers per lane");
@@ -2040,6 +2046,15 @@ static int pow2_ceil(int r) {
 static int list_regs(int k) { return pow2_ceil((k + 63) / 64); }  // 1, 2, 4, 8, 16
 constexpr int kBandSlack = 8;  // spare list entries the packed path wants beyond k
 static int list_regs_packed(int k) { return pow2_ceil((k + kBandSlack + 63) / 64); }
+// ... and of the finish kernel's exact list on the dump routes: the band of the 16-bit table is ~70 table units wide
+// whatever the values, and what lies within it below the k-th best grows with the slots scanned (k = 500 over 31 000
+// slots: 504-520 survivors -- beyond 512 the query is redone by the exact kernel, 0.47 ms per 10 000 queries)
+static int dump_finish_regs(int k, int64_t slots_hint) {
+  // (up to 16 384 slots per query the extras stay within the 8 entries every packed path allows: k = 504 over 7 800
+  // slots ran 2.58 ms against the lists' 3.36)
+  const int slack = (slots_hint > 0 && slots_hint <= 16384) ? kBandSlack : 16 + k / 8;
+  return pow2_ceil((k + slack + 63) / 64);
+}
 // Registers of the per-wave lists of the packed scan.  Tiles are dealt round-robin, so a wave's share
 // of the top-k is ~k/NW: the lists are sized for at least 2k entries over the workgroup (64 RL per
 // wave) instead of k + 8 per wave.  Folding 64 candidates into a 512- or 1024-entry sorted list used
@@ -2093,8 +2108,7 @@ static size_t scan_lds_bytes_packed(int m, int R, int max_nprobe, int fused_floa
   return (b + 15) & ~(size_t)15;
 }
 // dump modes: no un-permute rows; the 16-bit table is half the size and runs four waves per workgroup
-static size_t scan_lds_bytes_dump(int m, bool sel16, int max_nprobe, int fused_floats) {
-  const int nw = sel16 ? 4 : packed_waves(m);
+static size_t scan_lds_bytes_dump(int m, bool sel16, int nw, int max_nprobe, int fused_floats) {
   size_t b = (size_t)m * (sel16 ? 512 : 1024) + nw * 512 + (size_t)(3 * max_nprobe + 1) * 4 + 8 + 3 * nw * 4 +
              (size_t)fused_floats * 4;
   return (b + 15) & ~(size_t)15;
@@ -2116,7 +2130,7 @@ static bool fuse_fits(int m, int RM) {
 #define TPQ_DECLARE_PACKED(M) \
   int dispatch_packed_##M(const ScanArgs& a, const ResidualArgs* ra, int RL, int R, hipStream_t st); \
   int dispatch_pool_##M(const ScanArgs& a, int RL, hipStream_t st);                                  \
-  int dispatch_dump_##M(const ScanArgs& a, int RL, int R, int sel16, hipStream_t st);
+  int dispatch_dump_##M(const ScanArgs& a, int RL, int R, int mode, hipStream_t st);
 TPQ_PACKED_M_LIST(TPQ_DECLARE_PACKED)
 #undef TPQ_DECLARE_PACKED
 

@@ -82,8 +82,9 @@ static int launch_finish(const ScanArgs& a, int nw_scan, int RL, hipStream_t st)
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus <= 0)
       n_cus = 256;
-    const int want = (a.nq + kFinishWaves - 1) / kFinishWaves;
-    const dim3 grid((unsigned)(want < n_cus ? want : n_cus)), block(kFinishWaves * 64);
+    constexpr int FW = finish_waves(RM);
+    const int want = (a.nq + FW - 1) / FW;
+    const dim3 grid((unsigned)(want < n_cus ? want : n_cus)), block(FW * 64);
     auto go = [&](auto kernel) -> int {
       int rc = set_lds(kernel, flds, "scan_finish_exact_kernel");
       if (rc) return rc;
@@ -102,11 +103,11 @@ static int launch_finish(const ScanArgs& a, int nw_scan, int RL, hipStream_t st)
 
 template <int RL, int R, int M, int MODE>
 static int launch_dump(ScanArgs a, hipStream_t st) {
-  if constexpr (!has_dump(M) || (MODE == kDumpSel16 && !has_sel16(M))) {
+  if constexpr (!has_dump(M) || (is_sel16(MODE) && !has_sel16(M)) || (MODE == kDumpSel16W8 && RL > 2)) {
     set_error("scan_packed (dump mode): not instantiated for n_subvectors=%d", M);
     return TPQ_ERR_UNSUPPORTED;
   } else {
-    const size_t lds = scan_lds_bytes_dump(M, MODE == kDumpSel16, a.max_nprobe, fused_floats_of(a));
+    const size_t lds = scan_lds_bytes_dump(M, is_sel16(MODE), scan_waves(M, MODE), a.max_nprobe, fused_floats_of(a));
     int rc = set_lds(scan_packed_kernel<RL, M, false, MODE>, lds, "scan_packed_kernel (dump mode)");
     if (rc) return rc;
     const float delta_rel = 1.05f * 2.0f * 5.9604645e-8f * (float)(M - 1);
@@ -122,7 +123,11 @@ static int launch_dump(ScanArgs a, hipStream_t st) {
 template <int M, int MODE>
 static int dispatch_dump_mode(const ScanArgs& a, int RL, int R, hipStream_t st) {
 #define TPQ_PAIR(A, B) if (RL == A && R == B) return launch_dump<A, B, M, MODE>(a, st);
-  TPQ_PAIR(1, 1) TPQ_PAIR(1, 2) TPQ_PAIR(2, 2) TPQ_PAIR(1, 4) TPQ_PAIR(2, 4)
+  if constexpr (MODE == kDumpSel16W8) {
+    TPQ_PAIR(1, 8) TPQ_PAIR(2, 8)
+  } else {
+    TPQ_PAIR(1, 1) TPQ_PAIR(1, 2) TPQ_PAIR(2, 2) TPQ_PAIR(1, 4) TPQ_PAIR(2, 4) TPQ_PAIR(2, 8) TPQ_PAIR(4, 8)
+  }
 #undef TPQ_PAIR
   set_error("scan_packed (dump mode): no instantiation for list registers (%d, %d)", RL, R);
   return TPQ_ERR_UNSUPPORTED;
@@ -170,8 +175,9 @@ int TPQ_CAT(dispatch_pool_, TPQ_PACKED_M)(const ScanArgs& a, int RL, hipStream_t
   return TPQ_ERR_UNSUPPORTED;
 }
 
-int TPQ_CAT(dispatch_dump_, TPQ_PACKED_M)(const ScanArgs& a, int RL, int R, int sel16, hipStream_t st) {
-  (void)sel16;  // (the fp32-table dump mode, kDumpF32, is not instantiated: the 16-bit table is the one in use)
+int TPQ_CAT(dispatch_dump_, TPQ_PACKED_M)(const ScanArgs& a, int RL, int R, int mode, hipStream_t st) {
+  // (the fp32-table dump mode, kDumpF32, is not instantiated: the 16-bit table is the one in use)
+  if (mode == kDumpSel16W8) return dispatch_dump_mode<TPQ_PACKED_M, kDumpSel16W8>(a, RL, R, st);
   return dispatch_dump_mode<TPQ_PACKED_M, kDumpSel16>(a, RL, R, st);
 }
 
