@@ -118,6 +118,12 @@ static bool fuse_enabled() {
 // the value that marks a raised flag in this call: non-zero, different from call to call (the flags live in
 // the caller's uninitialised workspace, which may be the memory an earlier call used) -- from the clock, so
 // that the library keeps no counter
+// INVARIANT (captured graphs replay with the SAME epoch and the same workspace): every path that raises flags also
+// consumes them before the call's last kernel ends -- the fused finisher and scan_ref_kernel / scan_residual_kernel
+// reset a flag they act on; scan_pool_merge_kernel and scan_finish_exact_kernel only skip (or raise) and rely on the
+// dispatch_ref launch that follows them IN THE SAME CALL.  A call that returns an error between those two launches
+// leaves flags raised: harmless for the next call (another epoch), and a capture that saw a failed launch is dead
+// anyway.  A stale word that happens to equal the epoch costs one needless exact redo, never a wrong result.
 static int fresh_epoch() {
   const uint64_t ns = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
   return (int)(((uint32_t)(ns ^ (ns >> 29)) * 0x9e3779b1u) | 1u);
