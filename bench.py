@@ -798,9 +798,10 @@ def secondary_pass(device, budget_s, only=None):
                 continue
             out[name] = fn(device, sp)
             prefix = {"c3": "scan_packed_kernel<1, 120", "c4": "scan_packed_kernel<1, 64"}.get(name)
-            # the HBM-bound records carry the traffic of THIS run (a counter pass in a child process); the
-            # committed profile is the fallback, and what the matrix-bound records (c5, wide) quote
-            if not (prefix and measured_traffic(out[name]["roofline"], ["--secondary-only", name], prefix)):
+            # every record carries the traffic of THIS run (a counter pass in a child process over the same
+            # workload: the dominant kernel's HBM-side reads per launch); the committed profile is the fallback
+            counted = prefix or {"c5": "coarse_kernel", "wide": "gemm_kernel<false"}.get(name)
+            if not (counted and measured_traffic(out[name]["roofline"], ["--secondary-only", name], counted)):
                 attach_traffic(out[name]["roofline"], name)
             if prefix:
                 cross_check_profile(out[name]["roofline"], name, prefix)
