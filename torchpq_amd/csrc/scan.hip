@@ -371,6 +371,9 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
       a.fuse = 0;
       a.tickets = nullptr;
       a.small_lists = 0;
+#ifdef TPQ_SCAN_PROFILE
+      a.prof = g_scan_prof;
+#endif
       switch (m) {
 #define TPQ_CASE_M(M) case M: rc = dispatch_dump_##M(a, RLd, Rf, mode, st); break;
         TPQ_PACKED_M_LIST(TPQ_CASE_M)
