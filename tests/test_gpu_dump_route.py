@@ -75,3 +75,62 @@ def test_tables_the_16_bit_scale_cannot_hold_go_to_the_exact_kernel():
     ok = ~torch.isnan(ref[0]).any(1)   # (NaN values compare unequal to themselves: checked through the addresses)
     assert torch.equal(got[0][ok], ref[0][ok])
     assert torch.equal(got[1], ref[1])
+
+
+@pytest.mark.parametrize("k,n_probe,nq", [(100, 200, 1300), (10, 70, 2100), (300, 96, 1024), (40, 5, 4000)])
+def test_ragged_probe_lists_empty_and_repeated_cells(k, n_probe, nq):
+    """per-query n_probe (smart probing), more than 64 probes (the probe table's second round), empty cells, a cell
+    listed twice in a row (skipped: ivfpq_topk.cu:864-866), tombstones -- against the reference-layout kernel"""
+    from torchpq_amd import kernels as K
+    dev = "cuda:0"
+    g = torch.Generator(device=dev)
+    g.manual_seed(k * 7 + n_probe)
+    m, ds, nc = 64, 2, 700
+    sizes = (torch.rand(nc, generator=g, device=dev) ** 3 * 900).long()
+    sizes[torch.rand(nc, generator=g, device=dev) < 0.15] = 0                      # empty cells
+    cap = sizes + 9
+    start = torch.cumsum(cap, 0) - cap
+    n_slots = int(cap.sum().item())
+    storage = torch.randint(0, 256, (m // 4, n_slots, 4), generator=g, device=dev, dtype=torch.uint8)
+    is_empty = (torch.rand(n_slots, generator=g, device=dev) < 0.05).to(torch.uint8)
+    codebook = torch.randn(m, ds, 256, generator=g, device=dev) * 3
+    query = torch.randn(m * ds, nq, generator=g, device=dev) * 3
+    cells = torch.rand(nq, nc, generator=g, device=dev).argsort(1)[:, :n_probe].contiguous()
+    rep = torch.rand(nq, generator=g, device=dev) < 0.3                            # probe 1 repeats probe 0
+    if n_probe > 1:
+        cells[rep, 1] = cells[rep, 0]
+    cs, sz = start[cells].contiguous(), sizes[cells].contiguous()
+    npl = torch.randint(1, n_probe + 1, (nq,), generator=g, device=dev)
+    npl[::17] = 0                                                                  # queries that probe nothing
+    scan = K.IVFPQTopkHip(m=m)
+    packed = K.PackCodesHip()(storage)
+    hint = int(sizes.float().mean().item() * n_probe)
+    got = scan.topk_fused(storage, query, codebook, is_empty, cs, sz, npl, k, packed=packed, slots_hint=hint)
+    ref = scan.topk_fused(storage, query, codebook, is_empty, cs, sz, npl, k, packed=None, slots_hint=hint)
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    assert bool(torch.isinf(ref[0][::17]).all())                                   # (-inf, -1) padding rows
+
+
+def test_index_search_large_batch_equals_small_batches():
+    """IVFPQIndex.search(): one batch of 3 000 queries (the large-batch route with its split tail) == the same queries
+    in batches of 500 (the one-launch finish), values and ids bit for bit; smart probing on; some items removed"""
+    import numpy as np
+    from torchpq_amd.index import IVFPQIndex
+    dev = "cuda:0"
+    rng = np.random.default_rng(11)
+    d, n, nq = 128, 120_000, 3000
+    base = torch.from_numpy(np.abs(rng.standard_normal((d, n)) * 30).astype(np.float32)).to(dev)
+    xq = torch.from_numpy(np.abs(rng.standard_normal((d, nq)) * 30).astype(np.float32)).to(dev)
+    np.random.seed(11)
+    idx = IVFPQIndex(d_vector=d, n_subvectors=64, n_cells=256, initial_size=64, device=dev)
+    idx.train(base[:, :40000].contiguous())
+    idx.add(base)
+    idx.remove(ids=torch.arange(0, 3000, 3, device=dev))
+    idx.n_probe = 24
+    for smart in (False, True):
+        idx.use_smart_probing = smart
+        v, i = idx.search(xq, k=150)
+        parts = [idx.search(xq[:, b:b + 500].contiguous(), k=150) for b in range(0, nq, 500)]
+        torch.cuda.synchronize()
+        assert torch.equal(v, torch.cat([p[0] for p in parts])) and torch.equal(i, torch.cat([p[1] for p in parts]))
