@@ -133,11 +133,17 @@ static int fresh_epoch() {
 // (variants: TPQ_SCAN_DUMP=0 keeps the one-launch finish / the lists)
 // returns 0 (not this route), kDumpSel16 (four-wave workgroups) or kDumpSel16W8 (eight-wave workgroups: k in (248, 504]
 // where four waves would need longer lists than eight -- long cells; lists of <= 2 registers, 16 chunks per query)
+static int dump_min_queries() {  // (variants: TPQ_SCAN_DUMP_MINQ=n takes batches from n queries on, whatever n_split says)
+  const char* e = TPQ_AB_ENV("TPQ_SCAN_DUMP_MINQ");
+  return e ? atoi(e) : kDumpMinQueries;
+}
 static int dump_route(const ScanArgs& a, bool residual, int R) {
-  if (residual || R > kDumpMaxR || a.n_split != 1) return 0;  // (the route deals the queries itself: dump_tail)
+  if (residual || R > kDumpMaxR) return 0;
+  // (the route deals the queries itself -- dump_tail --: a caller's n_split > 1 belongs to batches below its threshold)
+  if (a.n_split != 1 && dump_min_queries() == kDumpMinQueries) return 0;
   // the finish kernel recomputes the survivors' table entries from the codebook, held in LDS next to nothing else:
   // fused calls (query + codebook) only, m * ds <= 128
-  if (a.lut || a.m != 64 || a.ds > 2 || a.nq < kDumpMinQueries) return 0;
+  if (a.lut || a.m != 64 || a.ds > 2 || a.nq < dump_min_queries()) return 0;
   const char* e = TPQ_AB_ENV("TPQ_SCAN_DUMP");
   if (e && atoi(e) == 0) return 0;
   // (the finish kernel takes a query's lists as at most 16 chunks of 64 keys: four waves x RL <= 4, eight x RL <= 2)
