@@ -127,7 +127,15 @@ int tpq_ivfpq_scan_topk_packed_tickets(const uint8_t* packed, const uint8_t* cod
  * never written to or read from HBM.  This is what IVFPQIndex.search_cells
  * (torchpq/index/IVFPQIndex.py:452-461: precompute_adc + IVFPQTopk.topk) collapses to.
  * query f32 [m*ds][nq], codebook f32 [m][ds][256]; `packed` may be NULL (reference-layout
- * kernel); everything else as tpq_ivfpq_scan_topk[_packed]. */
+ * kernel); everything else as tpq_ivfpq_scan_topk[_packed].
+ * Large batches (nq >= 1024 with n_split == 1, m == 64, ds <= 2, k <= 504, `packed` given): three launches --
+ * the scan workgroups (four per CU) stream over a 16-bit fixed-point SELECTION table built from query and
+ * codebook and end with their lists of fast values; a finish kernel, one wave per query, evaluates every
+ * candidate within the table's rigorous error band exactly (the reference's arithmetic and order, from the
+ * codebook) and writes the result; the exact kernel redoes flagged queries (normally none).  Same results,
+ * bit for bit.  The library deals the batch's last round of workgroups in parts of a query;
+ * nothing of this shows at the boundary beyond the workspace size, which
+ * tpq_ivfpq_scan_workspace_bytes(nq, k, n_split, 64) already covers. */
 int tpq_ivfpq_search_fused(const uint8_t* packed, const uint8_t* codes, const float* query,
                            const float* codebook, int ds, int metric, const uint8_t* is_empty,
                            const int64_t* cell_start, const int64_t* cell_size,
