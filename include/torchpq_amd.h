@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TPQ_VERSION 400 /* 0.4.0 */
+#define TPQ_VERSION 500 /* 0.5.0 */
 
 #define TPQ_OK 0
 #define TPQ_ERR_INVALID_ARGUMENT (-1)
