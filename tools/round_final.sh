@@ -1,4 +1,5 @@
 #!/bin/bash
+# round end, one gpurun call: the GPU suite, then everything DESIGN section 4 quotes (tools/round_profiles.sh)
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r05_pytest_gpu_final.log 2>&1
