@@ -601,7 +601,13 @@ def secondary_c1(device, stream_peak):
     idx.load_state_dict(new)
     idx.n_probe, idx.use_smart_probing = n_probe, False
     xq = dev(q)
-    dt, scan_ms, _, gv, gi, stats = time_search(idx, xq, k, 20, 3)
+    # (20 searches of 1 000 queries are 2 ms of wall time right after 80 s of 256 host threads: the host side of one
+    # such run was seen at 4.5 ms per call with the kernels at their usual 42 us -- so: a pause, more warm-up, and the
+    # faster of two runs, both on the record)
+    time.sleep(0.3)
+    runs = [time_search(idx, xq, k, 20, 10) for _ in range(2)]
+    c1_ms_runs = [round(r[0] / 20 * 1e3, 4) for r in runs]
+    dt, scan_ms, _, gv, gi, stats = min(runs, key=lambda r: r[0])
     gv, gi = gv.cpu().numpy(), gi.cpu().numpy()
     ids_equal = float((gi == ci).mean())
     finite = np.isfinite(cv)
@@ -628,6 +634,7 @@ def secondary_c1(device, stream_peak):
                     "what": "oracle/: kmeans_fit_redo (VQ 15 / PQ 25 iterations, direct -(a-b)^2 assign in C/OpenMP, "
                             "numpy update), max_sim encode, ContainerState.add, search (numpy coarse + C/OpenMP scan)"},
             "gpu": {"search_queries_per_s": round(nq * 20 / dt, 1), "ms_per_step": round(dt / 20 * 1e3, 4),
+                    "ms_per_step_of_both_runs": c1_ms_runs,
                     "train_s": round(g1 - g0, 3), "add_s": round(g2 - g1, 3),
                     "what": "IVFPQIndex.search() on the oracle-built index (load_state_dict); train/add of the same "
                             "data by the GPU path"},
@@ -773,19 +780,23 @@ def secondary_wide(device, stream_peak, iters=3):
                                       "exact pairs) is in the time"}}
 
 
-def secondary_pass(device, budget_s, only=None):
+def secondary_pass(device, budget_s, only=None, skip=(), stream_peak=None):
+    """`skip`: records left for a later call (the driver's run does c1 -- 80 s of all host cores -- AFTER the
+    headline's timed region); `stream_peak`: a value measured by an earlier call (not measured again)"""
     out = {}
     t_start = time.time()
-    try:
-        sp = stream_peak_gbps(device)
-        out["stream_peak"] = {"value": round(sp, 1), "unit": "GB/s", "frac_of_spec": round(sp / HBM_PEAK_GBPS, 4),
-                              "what": "tpq_ubench_stream_read, 8 GiB buffer, dwordx4 loads, best of 5"}
-    except Exception as e:
-        sp = None
-        out["stream_peak"] = {"error": repr(e)[:300]}
+    sp = stream_peak
+    if sp is None:
+        try:
+            sp = stream_peak_gbps(device)
+            out["stream_peak"] = {"value": round(sp, 1), "unit": "GB/s", "frac_of_spec": round(sp / HBM_PEAK_GBPS, 4),
+                                  "what": "tpq_ubench_stream_read, 8 GiB buffer, dwordx4 loads, best of 5"}
+        except Exception as e:
+            sp = None
+            out["stream_peak"] = {"error": repr(e)[:300]}
     for name, fn in (("c4", secondary_c4), ("c3", secondary_c3), ("c5", secondary_c5), ("wide", secondary_wide),
                      ("c1", secondary_c1)):
-        if only and name not in only:
+        if (only and name not in only) or name in skip:
             continue
         if time.time() - t_start > budget_s:
             out[name] = {"skipped": f"secondary budget of {budget_s:.0f} s spent"}
@@ -959,7 +970,8 @@ def run(args, world, rank, done):
         print(json.dumps({"secondary": secondary}))
         return
     if world == 1 and not args.no_secondary and args.workload == "c2":
-        secondary, stream_peak = secondary_pass(device, args.secondary_budget)
+        # (c1's CPU leg keeps every host core busy for 80 s: it runs after the headline's timed region, below)
+        secondary, stream_peak = secondary_pass(device, args.secondary_budget, skip=("c1",))
 
     # ---- the index: built on rank 0, replicated with one broadcast per buffer ------------------
     t_train = t_add = 0.0
@@ -1119,6 +1131,9 @@ def run(args, world, rank, done):
             inter = [len(np.intersect1d(gpu_ids[q], cpu_ids[q])) for q in range(cpu_ids.shape[0])]
             out["recall_vs_ref@%d" % args.k] = round(float(np.mean(inter)) / args.k, 4)
         if secondary is not None:
+            if world == 1 and not args.no_secondary and args.workload == "c2":
+                late, _ = secondary_pass(device, args.secondary_budget, only={"c1"}, stream_peak=stream_peak or 0.0)
+                secondary.update(late)
             out["secondary"] = secondary
         print(json.dumps(out))
     if world > 1:
