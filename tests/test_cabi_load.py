@@ -11,7 +11,7 @@ from conftest import ROOT
 def test_library_loads_and_exports_header_symbols():
     from torchpq_amd import _lib
     lib = _lib.load()
-    assert lib.tpq_version() == 400
+    assert lib.tpq_version() == 500
     header = open(os.path.join(ROOT, "include", "torchpq_amd.h")).read()
     declared = set(re.findall(r"\b(tpq_[a-z0-9_]+)\s*\(", header))
     assert declared, "no declarations parsed"
