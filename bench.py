@@ -372,7 +372,10 @@ def pmc_traffic(child_args, kernel_filter, timeout_s=240):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
-    td = tempfile.mkdtemp(prefix="tpq_pmc_", dir="/tmp")
+    try:
+        td = tempfile.mkdtemp(prefix="tpq_pmc_", dir="/tmp")
+    except OSError:
+        return None
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = [exe, "--pmc", "FETCH_SIZE", "TCC_EA0_RDREQ_sum", "--output-format", "csv", "-d", td, "-o", "run", "--",
            sys.executable, os.path.abspath(__file__)] + list(child_args) + ["--no-traffic-pass"]
