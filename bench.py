@@ -237,10 +237,10 @@ def time_search(idx, queries, k, steps, warmup, barrier=None):
         stats.update({"kernel_ms_median": round(med, 4), "kernel_ms_min": round(min(per_step), 4),
                       "kernel_ms_max": round(max(per_step), 4),
                       "steps_slower_than_1p3x_median": int(sum(t > 1.3 * med for t in per_step))})
-    # queries that took the in-kernel exact redo (the candidate band overflowed): one more,
-    # untimed, search with the workspace kept.  Defined for the one-launch finish only
-    # (k <= 248, one workgroup per query); "slow and normally never taken" -- here it is counted.
-    if k <= 248 and scan.last_n_split == 1 and nb == 1 and not idx.pq_use_residual:
+    # queries that took the exact redo (the candidate band overflowed, a table could not be scaled): one more,
+    # untimed, search with the workspace kept; counted on every packed route (the one-launch finisher's own
+    # redo branch, or the flag-gated exact kernel that ends the other routes) -- "slow and normally never taken"
+    if nb == 1:  # (every packed route leaves its mark: IVFPQTopkHip.last_redone)
         scan.keep_workspace = True
         try:
             idx.search(queries, k=k)
@@ -264,12 +264,26 @@ def hbm_roofline(algo_bytes, kernel_ms, kernel, stream_peak=None, resident_bytes
     r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": kernel,
          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(algo_bytes)}
-    if resident_bytes is not None:
-        r["code_bytes_resident"] = int(resident_bytes)
-        r["fed_by"] = "infinity_cache" if resident_bytes <= INFINITY_CACHE_BYTES else "hbm"
     if stream_peak:
         r["stream_peak"] = round(stream_peak, 1)
         r["frac_of_stream_peak"] = round(achieved / stream_peak, 4)
+    if resident_bytes is not None:
+        # `fed_by` is decided by what was MEASURED where a measurement can decide it: a rate above the
+        # box's DRAM stream peak cannot have come from DRAM alone; below it, an array that fits the 256 MiB MALL and is
+        # re-read many times per launch is served from there after its first touch; an array beyond the MALL read at or
+        # below the stream peak is DRAM-fed (the 100 M-slot record adds the "cold" variant: every byte once per launch)
+        r["code_bytes_resident"] = int(resident_bytes)
+        r["reads_of_each_code_byte_per_launch"] = round(algo_bytes / max(resident_bytes, 1), 1)
+        if stream_peak and achieved > stream_peak:
+            r["fed_by"] = "infinity_cache" if resident_bytes <= 2 * INFINITY_CACHE_BYTES else "hbm+infinity_cache"
+            r["fed_by_basis"] = (f"measured: {achieved:.0f} GB/s is above this box's DRAM stream peak "
+                                 f"({stream_peak:.0f} GB/s), so part of it is re-reads served by the Infinity Cache")
+        elif resident_bytes <= INFINITY_CACHE_BYTES:
+            r["fed_by"] = "infinity_cache"
+            r["fed_by_basis"] = "the code array fits the 256 MiB Infinity Cache and every byte is re-read within a launch"
+        else:
+            r["fed_by"] = "hbm"
+            r["fed_by_basis"] = "code array beyond the Infinity Cache, rate at or below the DRAM stream peak"
     if stats:
         r.update(stats)
     r.update(extra)
@@ -428,27 +442,64 @@ def measured_traffic(roofline, child_args, kernel_filter):
     return True
 
 
-def stream_peak_gbps(device, gib=8, iters=5):
-    """sustained HBM read rate: tpq_ubench_stream_read over a buffer far beyond the 256 MiB
-    Infinity Cache, best of `iters` (HIP events on the launch stream)"""
+STREAM_SETTINGS = (
+    # (label, n_blocks per CU, threads, unroll, chunk_bytes, nontemporal); chunk 0 = the buffer cut evenly
+    ("grid-stride, 8 x 256 threads per CU, 8 in flight, nt (round 1-5's figure)", None, 256, 8, 0, 1),
+    ("even cut, 8 x 256 per CU, 8 in flight, nt", 8, 256, 8, 0, 1),
+    ("even cut, 8 x 256 per CU, 16 in flight, nt", 8, 256, 16, 0, 1),
+    ("even cut, 4 x 512 per CU, 8 in flight, plain loads", 4, 512, 8, 0, 0),
+    ("cells of 390 592 B (a C4 cell) dealt to 4 x 256 per CU, 4 in flight, plain loads (the scan's pattern)",
+     4, 256, 4, 390592, 0),
+    ("cells of 390 592 B dealt to 4 x 256 per CU, 8 in flight, nt", 4, 256, 8, 390592, 1),
+    ("cells of 62 528 B (a C2 cell) dealt to 8 x 256 per CU, 8 in flight, nt", 8, 256, 8, 62528, 1),
+    ("2 MiB pieces dealt to 2 x 1024 per CU, 8 in flight, nt", 2, 1024, 8, 2 << 20, 1),
+)
+
+
+def stream_peak_sweep(device, gib=8, iters=3):
+    """sustained HBM read rate of the box: the streaming-read microkernel over a buffer far beyond the 256 MiB
+    Infinity Cache (every byte read once per launch: DRAM, not cache), in a handful of settings -- the scan's own
+    access pattern among them --, best of `iters` each (HIP events on the launch stream).  Returns (best GB/s,
+    [(label, GB/s)])."""
     from torchpq_amd import _lib
     lib = _lib.load()
     buf = torch.empty(gib << 30, device=device, dtype=torch.uint8)
     buf.view(torch.int64).fill_(0x0123456789abcdef)
     sink = torch.zeros(1, device=device, dtype=torch.int32)
     st = _lib.stream_ptr(device)
-    best = 0.0
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    rows = []
     with torch.cuda.device(device):
-        for it in range(iters + 1):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            _lib.check(lib.tpq_ubench_stream_read(_lib.ptr(buf), buf.numel(), _lib.ptr(sink), 0, st),
-                       "tpq_ubench_stream_read")
-            e1.record()
-            torch.cuda.synchronize()
-            if it:  # first launch = warm-up
-                best = max(best, buf.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9)
-    return best
+        for label, per_cu, threads, unroll, chunk, nt in STREAM_SETTINGS:
+            best = 0.0
+            for it in range(iters + 1):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                if per_cu is None:
+                    _lib.check(lib.tpq_ubench_stream_read(_lib.ptr(buf), buf.numel(), _lib.ptr(sink), 0, st),
+                               "tpq_ubench_stream_read")
+                else:
+                    _lib.check(lib.tpq_ubench_stream_read_ex(_lib.ptr(buf), buf.numel(), _lib.ptr(sink), per_cu * cus,
+                                                             threads, unroll, chunk, nt, st),
+                               "tpq_ubench_stream_read_ex")
+                e1.record()
+                torch.cuda.synchronize()
+                if it:  # first launch = warm-up
+                    best = max(best, buf.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+            rows.append((label, round(best, 1)))
+    return max(r[1] for r in rows), rows
+
+
+def stream_peak_gbps(device, gib=8, iters=3):
+    return stream_peak_sweep(device, gib, iters)[0]
+
+
+def stream_peak_record(device):
+    sp, rows = stream_peak_sweep(device)
+    return sp, {"value": round(sp, 1), "unit": "GB/s", "frac_of_spec": round(sp / HBM_PEAK_GBPS, 4),
+                "what": "tpq_ubench_stream_read[_ex], 8 GiB buffer read once per launch (DRAM: 32 x the Infinity Cache), "
+                        "16-byte loads, best setting, best of 3",
+                "settings_GBps": {label: v for label, v in rows}}
 
 
 def cpu_baseline(idx, queries, k, n_sample):
@@ -487,6 +538,59 @@ def cpu_baseline(idx, queries, k, n_sample):
             "split_s": {"coarse": round(t1 - t0, 3), "lut": round(t2 - t1, 3), "scan": round(t3 - t2, 3)},
             "sample": f"{n_sample} of the {queries.shape[1]} queries, full pipeline (coarse: numpy BLAS GEMM + "
                       f"epilogue + top-n_probe; LUT and list scan: C/OpenMP on {cores} threads), {dt:.1f} s"}, ids
+
+
+def oracle_sample_check(idx, queries, vals, ids, k, n_sample=32, host=None, cells=None, npl=None):
+    """The TIMED route checked where it was timed: `n_sample` queries spread over the batch
+    that was just searched (first and last included), the C oracle (adc_lut + scan_topk: the reference's
+    arithmetic, ivfpq_topk.cu:822-971) run on the GPU's own probed cells of exactly those queries, and the
+    rows the timed call returned compared with it -- values bit for bit, ids entry by entry.  `host`: a dict
+    that caches the index's host copies between calls on the same index."""
+    from oracle import c_oracle
+    from oracle import ivfpq_oracle as orc
+    t0 = time.time()
+    nq = queries.shape[1]
+    n_sample = max(1, min(n_sample, nq))
+    sel = torch.unique(torch.linspace(0, nq - 1, n_sample, device=queries.device).round().long())
+    qs = queries[:, sel].contiguous()
+    if idx.distance == "cosine":
+        from torchpq_amd import util
+        qs = util.normalize(qs, dim=0)
+    if cells is None:
+        _, cells, npl = idx.probe(qs)
+    else:  # (search_cells with the caller's cells: no coarse step to repeat)
+        cells, npl = cells[sel], npl[sel]
+    cells_h, npl_h = cells.cpu().numpy(), npl.cpu().numpy()
+    host = host if host is not None else {}
+    if host.get("version") != (idx._storage.data_ptr(), idx.n_items):
+        host.clear()
+        host.update(version=(idx._storage.data_ptr(), idx.n_items), storage=idx._storage.cpu().numpy(),
+                    is_empty=idx._is_empty.cpu().numpy(), a2i=idx._address2id.cpu().numpy(),
+                    cs=idx._cell_start.cpu().numpy(), sz=idx._cell_size.cpu().numpy(),
+                    pq=idx.pq_codec.codebook.cpu().numpy())
+    lut = c_oracle.adc_lut(qs.cpu().numpy(), host["pq"], idx.distance)
+    ev, ea = c_oracle.scan_topk(host["storage"], lut, host["is_empty"], host["cs"][cells_h], host["sz"][cells_h],
+                                npl_h, k)
+    ei = orc.get_id_by_address(host["a2i"], ea)
+    gv, gi = vals[sel].cpu().numpy(), ids[sel].cpu().numpy()
+    return {"queries_checked": int(sel.numel()), "of_the_timed_batch_of": int(nq),
+            "ids_equal_to_oracle": round(float((gi == ei).mean()), 6),
+            "values_bit_equal": bool(np.array_equal(gv.view(np.int32), ev.view(np.int32))),
+            "rows_fully_equal": int(((gi == ei).all(1) & (gv.view(np.int32) == ev.view(np.int32)).all(1)).sum()),
+            "recall_vs_ref": round(float(np.mean([len(np.intersect1d(gi[r], ei[r])) for r in range(gi.shape[0])]))
+                                   / k, 4),
+            "max_address_checked": int(ea.max()), "addresses_beyond_2p24": int((ea >= (1 << 24)).sum()),
+            "check_s": round(time.time() - t0, 2),
+            "what": "rows of the TIMED search() call vs oracle/ (C adc_lut + scan_topk on the GPU's probed cells of "
+                    "the same queries, address -> id)"}
+
+
+def ids_digest(vals, ids):
+    """sha1 over the raw bytes of a result (values, then ids): equal digests <=> bit-equal results"""
+    h = hashlib.sha1()
+    h.update(vals.contiguous().cpu().numpy().tobytes())
+    h.update(ids.contiguous().cpu().numpy().tobytes())
+    return h.hexdigest()[:16]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -528,6 +632,7 @@ def secondary_c3(device, stream_peak, steps=20):
                         f"{nq} queries, search() end to end",
             "value": round(nq * steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / steps * 1e3, 4),
             "train_s": round(t_train, 2), "add_s": round(t_add, 2),
+            "oracle_check": oracle_sample_check(idx, queries, vals, ids, k),
             "roofline": hbm_roofline(algo, scan_ms, "scan_packed_kernel<1,120,false,2> (one launch: scan + merge + "
                                      "write)", stream_peak, resident_bytes=idx._storage.numel(), stats=stats,
                                      launches_per_step=nb, bytes_per_query=round(algo / nq, 1))}
@@ -543,13 +648,169 @@ def secondary_c4(device, stream_peak, steps=5):
     queries = torch.randn(d, nq, generator=g, device=device)
     dt, scan_ms, nb, vals, ids, stats = time_search(idx, queries, k, steps, 1)
     algo = scanned_bytes(idx, queries, m)
-    return {"workload": f"synthetic codes d={d} n={n} IVFPQ n_cells={n_cells} m={m} nprobe={n_probe} k={k}, "
-                        f"{nq} queries per GPU, search() end to end (coarse probe + fused LUT + scan)",
+    host = {}
+    rec = {"workload": f"synthetic codes d={d} n={n} IVFPQ n_cells={n_cells} m={m} nprobe={n_probe} k={k}, "
+                       f"{nq} queries per GPU, search() end to end (coarse probe + fused LUT + scan)",
+           "value": round(nq * steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / steps * 1e3, 4),
+           "oracle_check": oracle_sample_check(idx, queries, vals, ids, k, host=host),
+           "roofline": hbm_roofline(algo, scan_ms, "scan_packed_kernel<1,64,false,-16> (four-wave workgroups over the "
+                                    "16-bit selection table) + scan_finish_exact_kernel; kernel_ms brackets both",
+                                    stream_peak, resident_bytes=idx._storage.numel(), stats=stats,
+                                    launches_per_step=nb, bytes_per_query=round(algo / nq, 1))}
+    try:
+        rec["cold"] = c4_cold_variant(idx, device, stream_peak, k, steps, host)
+        rec["roofline"]["dram_frac"] = rec["cold"]["roofline"]["frac"]
+        rec["roofline"]["dram_frac_what"] = ("the same kernels on the COLD variant of this index (`cold`): every cell "
+                                             "probed by exactly one query, each code byte read once per launch")
+        warm, cold = rec["roofline"]["achieved"], rec["cold"]["roofline"]["achieved"]
+        rec["roofline"]["rate_over_cold_rate"] = round(warm / cold, 4)
+    except Exception as e:  # noqa: BLE001 -- the variant must not cost the record
+        rec["cold"] = {"error": repr(e)[:300]}
+    return rec
+
+
+def c4_cold_variant(idx, device, stream_peak, k, steps, host):
+    """how much of the 100 M-slot scan's rate is DRAM?  In the timed batch each cell is probed by ~39 of
+    the 10 000 queries, and re-reads that land within the Infinity Cache's reach are counted by FETCH_SIZE like DRAM
+    reads.  Here the SAME index is searched with the 16 384 cells dealt to 1 024 queries, 16 each, every cell exactly once
+    (a random permutation): each of the 6.4 GB of code bytes is read ONCE per launch, 25 x the Infinity Cache apart -- what
+    this runs at is DRAM.  1 024 queries take the large-batch route the headline takes (four-wave workgroups, 16-bit
+    selection table, finish kernel)."""
+    n_cells, m = idx.n_cells, idx.n_subvectors
+    nq, n_probe = 1024, n_cells // 1024
+    g = torch.Generator(device=device)
+    g.manual_seed(977)
+    cells = torch.randperm(n_cells, generator=g, device=device).view(nq, n_probe).contiguous()
+    queries = torch.randn(idx.d_vector, nq, generator=g, device=device)
+    npl = torch.full((nq,), n_probe, device=device, dtype=torch.long)
+    scan = idx._ivfpq_topk._scan
+    run = lambda: idx.search_cells(queries, cells, n_probe_list=npl, k=k)  # noqa: E731
+    run()
+    torch.cuda.synchronize()
+    scan.record_events = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        vals, ids = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per = [a.elapsed_time(b) for a, b in scan.record_events]
+    scan.record_events = None
+    algo = int(idx._cell_size.sum().item()) * m
+    stats = {"kernel_ms_min": round(min(per), 4), "kernel_ms_median": round(float(np.median(per)), 4),
+             "kernel_ms_max": round(max(per), 4), "n_split": scan.last_n_split}
+    roof = hbm_roofline(algo, float(np.mean(per)), "scan_packed_kernel<1,64,false,-16> + scan_finish_exact_kernel",
+                        stream_peak, resident_bytes=idx._storage.numel(), stats=stats)
+    roof["fed_by"], roof["fed_by_basis"] = "hbm", "by construction: every code byte is read once per launch"
+    return {"workload": f"the same index, {nq} queries x {n_probe} cells, every cell probed exactly once per launch "
+                        f"(search_cells: fused LUT + scan + finish; no coarse step)",
             "value": round(nq * steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / steps * 1e3, 4),
-            "roofline": hbm_roofline(algo, scan_ms, "scan_packed_kernel<1,64,false,-16> (four-wave workgroups over the "
-                                     "16-bit selection table) + scan_finish_exact_kernel; kernel_ms brackets both",
-                                     stream_peak, resident_bytes=idx._storage.numel(), stats=stats,
-                                     launches_per_step=nb, bytes_per_query=round(algo / nq, 1))}
+            "oracle_check": oracle_sample_check(idx, queries, vals, ids, k, host=host, cells=cells, npl=npl),
+            "roofline": roof}
+
+
+def secondary_residual(device, stream_peak, steps=10):
+    """residual PQ (`pq_use_residual=True`, ivfpq_topk.cu:1039-1208 /
+    index/IVFPQIndex.py:366-450) at the configs[1] shape, search() end to end; algorithmic bytes per slot = m code
+    bytes + the 4-byte per-slot term the packed residual scan reads beside them."""
+    from oracle import c_oracle
+    from oracle import ivfpq_oracle as orc
+    from torchpq_amd.index import IVFPQIndex
+    d, m, n_cells, n, nq, n_probe, k = 128, 64, 1024, 1_000_000, 10000, 32, 100
+    synth = SiftLike(d, device)
+    base = synth.sample(n, seed=1)
+    g = torch.Generator(device=device)
+    g.manual_seed(2)
+    train = base[:, torch.randperm(n, generator=g, device=device)[:100_000]].contiguous()
+    np.random.seed(1234)
+    idx = IVFPQIndex(d_vector=d, n_subvectors=m, n_cells=n_cells, initial_size=2 * n // n_cells, device=str(device),
+                     pq_use_residual=True)
+    t0 = time.time()
+    idx.train(train)
+    torch.cuda.synchronize()
+    t_train = time.time() - t0
+    t0 = time.time()
+    for b in range(0, n, 1 << 18):
+        idx.add(base[:, b:b + (1 << 18)].contiguous())
+    idx.release_spare()
+    torch.cuda.synchronize()
+    t_add = time.time() - t0
+    del base, train
+    idx.n_probe, idx.use_smart_probing = n_probe, False
+    queries = synth.sample(nq, seed=4321)
+    dt, scan_ms, nb, vals, ids, stats = time_search(idx, queries, k, steps, 2)
+    slots = scanned_bytes(idx, queries, m) // m
+    algo = slots * (m + 4)
+    # oracle sample: the GPU's probed cells and base sims, the index's own part1 / part2 tables (the kernel's
+    # arithmetic; part2 is a library GEMM), the C restatement of ivfpq_topk_residual_precomputed over them
+    sel = torch.unique(torch.linspace(0, nq - 1, 32, device=device).round().long())
+    qs = queries[:, sel].contiguous()
+    topk_sims, cells, npl = idx.probe(qs)
+    p1, p2 = idx.precomputed_adc_residual_precomputed(qs)
+    N = lambda t: t.cpu().numpy()  # noqa: E731
+    cells_h = N(cells)
+    ev, ea = c_oracle.scan_topk_residual(N(idx._storage), N(p1), N(p2.contiguous()), cells_h, N(topk_sims),
+                                         N(idx._is_empty), N(idx._cell_start)[cells_h], N(idx._cell_size)[cells_h],
+                                         N(npl), k)
+    ei = orc.get_id_by_address(N(idx._address2id), ea)
+    gv, gi = N(vals[sel]), N(ids[sel])
+    return {"workload": f"residual PQ (pq_use_residual=True), SIFT1M-like d={d} n={n} n_cells={n_cells} m={m} "
+                        f"nprobe={n_probe} k={k}, {nq} queries, search() end to end",
+            "value": round(nq * steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / steps * 1e3, 4),
+            "train_s": round(t_train, 2), "add_s": round(t_add, 2),
+            "oracle_check": {"queries_checked": int(sel.numel()), "ids_equal_to_oracle": round(float((gi == ei).mean()), 6),
+                             "values_bit_equal": bool(np.array_equal(gv.view(np.int32), ev.view(np.int32))),
+                             "what": "rows of the TIMED search() call vs oracle/ scan_topk_residual (C) on the GPU's "
+                                     "probed cells, base sims and part1 / part2 tables"},
+            "roofline": hbm_roofline(algo, scan_ms, "scan_packed_kernel<.,64,RES=true> + scan_merge_refine_kernel + "
+                                     "the flag-gated scan_residual_kernel; kernel_ms brackets the scan call",
+                                     stream_peak, resident_bytes=idx._storage.numel() + 4 * idx._storage.shape[1],
+                                     stats=stats, launches_per_step=nb, bytes_per_slot=m + 4,
+                                     bytes_per_query=round(algo / nq, 1))}
+
+
+def secondary_flat(device, stream_peak, steps=5):
+    """FlatIndex (exact search, index/FlatIndex.py:44-101) -- one library GEMM + the HIP row top-k --, the
+    recall ground-truth generator, at the configs[1] base size.  Bound: HBM -- the [nq, n] similarity matrix is written
+    once and read once (8 B per (query, vector) pair); the GEMM's 2 nq n d flop ride beneath it."""
+    from torchpq_amd.index import FlatIndex
+    d, n, nq, k = 128, 1_000_000, 1000, 100
+    synth = SiftLike(d, device)
+    base = synth.sample(n, seed=1)
+    idx = FlatIndex(d_vector=d, initial_size=n, device=str(device))
+    idx.add(base)
+    queries = synth.sample(nq, seed=4321)
+    idx.search(queries, k=k)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        vals, ids = idx.search(queries, k=k)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = e0.elapsed_time(e1) / steps
+    # oracle sample: exact brute force in float64 on the host for 16 queries
+    sel = np.unique(np.linspace(0, nq - 1, 16).round().astype(np.int64))
+    xb = base.cpu().numpy().astype(np.float64)
+    xq = queries[:, torch.from_numpy(sel).to(device)].cpu().numpy().astype(np.float64)
+    sims = 2.0 * (xq.T @ xb) - (xq * xq).sum(0)[:, None] - (xb * xb).sum(0)[None, :]
+    order = np.argsort(-sims, axis=1, kind="stable")[:, :k]
+    ev = np.take_along_axis(sims, order, 1)
+    gv, gi = vals.cpu().numpy()[sel], ids.cpu().numpy()[sel]
+    overlap = float(np.mean([len(np.intersect1d(gi[r], order[r])) for r in range(len(sel))])) / k
+    rel = float(np.max(np.abs(gv - ev) / np.maximum(np.abs(ev), 1.0)))
+    algo = 8 * nq * n
+    roof = hbm_roofline(algo, ms, "rocBLAS SGEMM (library) + topk_select_kernel (HIP) + id_by_address; kernel_ms = the "
+                                  "whole search() on the stream", stream_peak)
+    roof["gemm_flops_per_launch"] = 2.0 * nq * n * d
+    return {"workload": f"FlatIndex exact search d={d} n={n}, {nq} queries, k={k} (SIFT1M-like)",
+            "value": round(nq * steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / steps * 1e3, 4),
+            "oracle_check": {"queries_checked": int(len(sel)), "top_k_overlap_with_float64_brute_force": round(overlap, 4),
+                             "values_max_rel_diff": rel,
+                             "what": "float64 brute force on the host; fp32 GEMM summation order differs from the exact "
+                                     "order, so ids are compared as sets and values at 1e-4 (BASELINE.json tolerance)"},
+            "roofline": roof}
 
 
 def secondary_c1(device, stream_peak):
@@ -792,14 +1053,12 @@ def secondary_pass(device, budget_s, only=None, skip=(), stream_peak=None):
     sp = stream_peak
     if sp is None:
         try:
-            sp = stream_peak_gbps(device)
-            out["stream_peak"] = {"value": round(sp, 1), "unit": "GB/s", "frac_of_spec": round(sp / HBM_PEAK_GBPS, 4),
-                                  "what": "tpq_ubench_stream_read, 8 GiB buffer, dwordx4 loads, best of 5"}
+            sp, out["stream_peak"] = stream_peak_record(device)
         except Exception as e:
             sp = None
             out["stream_peak"] = {"error": repr(e)[:300]}
     for name, fn in (("c4", secondary_c4), ("c3", secondary_c3), ("c5", secondary_c5), ("wide", secondary_wide),
-                     ("c1", secondary_c1)):
+                     ("residual", secondary_residual), ("flat", secondary_flat), ("c1", secondary_c1)):
         if (only and name not in only) or name in skip:
             continue
         if time.time() - t_start > budget_s:
@@ -816,7 +1075,9 @@ def secondary_pass(device, budget_s, only=None, skip=(), stream_peak=None):
             # every record carries the traffic of THIS run (a counter pass in a child process over the same
             # workload: the dominant kernel's HBM-side reads per launch); the committed profile is the fallback
             counted = prefix or {"c5": "coarse_kernel", "wide": "gemm_kernel<false"}.get(name)
-            if not (counted and measured_traffic(out[name]["roofline"], ["--secondary-only", name], counted)):
+            if name in ("residual", "flat"):
+                pass  # (time-boxed records without a counter pass: `traffic` stays null)
+            elif not (counted and measured_traffic(out[name]["roofline"], ["--secondary-only", name], counted)):
                 attach_traffic(out[name]["roofline"], name)
             if prefix:
                 cross_check_profile(out[name]["roofline"], name, prefix)
@@ -880,8 +1141,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-traffic-pass", action="store_true",
                     help="do not run the rocprofv3 --pmc child pass that measures `traffic` in this run")
-    ap.add_argument("--secondary-only", default=None, help="comma list of c1,c3,c4,c5,wide (profiling)")
-    ap.add_argument("--secondary-budget", type=float, default=60.0)
+    ap.add_argument("--secondary-only", default=None, help="comma list of c1,c3,c4,c5,wide,residual,flat (profiling)")
+    ap.add_argument("--secondary-budget", type=float, default=150.0)
     ap.add_argument("--dist-timeout", type=float, default=300.0,
                     help="N > 1: timeout of the process groups (rendezvous, RCCL probe, broadcast)")
     ap.add_argument("--deadline", type=float, default=900.0,
@@ -981,10 +1242,7 @@ def run(args, world, rank, done):
         # 3.15-3.24 -- and 3.15-3.24 again when 80 s of CPU work lay between them.)  The other records follow it;
         # configs[0], whose CPU leg keeps every host core busy for 80 s, comes last.
         try:
-            stream_peak = stream_peak_gbps(device)
-            stream_record = {"value": round(stream_peak, 1), "unit": "GB/s",
-                             "frac_of_spec": round(stream_peak / HBM_PEAK_GBPS, 4),
-                             "what": "tpq_ubench_stream_read, 8 GiB buffer, dwordx4 loads, best of 5"}
+            stream_peak, stream_record = stream_peak_record(device)
         except Exception as e:  # noqa: BLE001
             stream_peak, stream_record = None, {"error": repr(e)[:300]}
         torch.cuda.empty_cache()
@@ -1033,16 +1291,18 @@ def run(args, world, rank, done):
 
     # weak scaling: every rank searches its own --nq queries (same distribution, rank-specific
     # seed); strong scaling: ONE batch of --nq queries (rank 0's), split over the ranks
-    def make_queries(mode):
+    def full_queries(mode):
         seed_rank = rank if mode == "weak" else 0
         if args.workload == "c4":
             qg = torch.Generator(device=device)
             qg.manual_seed(4321 + seed_rank)
-            q = torch.randn(args.d, args.nq, generator=qg, device=device)
-        elif real is not None:
-            q = real[2]
-        else:
-            q = synth.sample(args.nq, seed=4321 + seed_rank)
+            return torch.randn(args.d, args.nq, generator=qg, device=device)
+        if real is not None:
+            return real[2]
+        return synth.sample(args.nq, seed=4321 + seed_rank)
+
+    def make_queries(mode):
+        q = full_queries(mode)
         return q if mode == "weak" or world == 1 else tpd.shard_queries(q, rank, world)
 
     def timed(mode):
@@ -1073,6 +1333,31 @@ def run(args, world, rank, done):
         other = mode_summary(om, odt, oper)
     dt, per_rank_dt, scan_ms, vals, ids, queries, scan_stats = timed(args.scaling)
     headline = mode_summary(args.scaling, dt, per_rank_dt)
+
+    # ---- N > 1: are the replicas equal?  Every rank searches ITS shard of the one shared batch (the strong-scaling
+    # batch, rank 0's queries) and contributes a digest of the raw result bytes over the control plane; rank 0 searches
+    # the whole batch alone and digests the same row ranges: equal digests <=> every replica returns, for its shard,
+    # bit for bit what one GPU returns for the unsharded batch (no data-path collective: 16 bytes per rank)
+    replica_check = None
+    if world > 1:
+        done["stage"] = "replica check (digests of the shared batch)"
+        qfull = full_queries("strong")
+        b0, e0 = tpd.shard_bounds(qfull.shape[1], rank, world)
+        v_s, i_s = idx.search(qfull[:, b0:e0].contiguous(), k=args.k)
+        digests = [None] * world
+        dist.all_gather_object(digests, ids_digest(v_s, i_s))
+        if rank == 0:
+            v_f, i_f = idx.search(qfull, k=args.k)
+            expect = []
+            for r in range(world):
+                b, e = tpd.shard_bounds(qfull.shape[1], r, world)
+                expect.append(ids_digest(v_f[b:e], i_f[b:e]))
+            replica_check = {"shard_digests": digests, "rank0_unsharded_digests": expect,
+                             "all_ranks_bit_equal_to_rank0_unsharded": digests == expect,
+                             "what": f"sha1[:16] of (values, ids) of each rank's shard of ONE batch of "
+                                     f"{qfull.shape[1]} queries vs rank 0's search of the whole batch"}
+            del v_f, i_f
+        del qfull, v_s, i_s
 
     # ---- roofline of the dominant kernel (the list scan) --------------------------------------
     algo_bytes = scanned_bytes(idx, queries, args.m)  # uint8 codes only: the irreducible read
@@ -1117,6 +1402,8 @@ def run(args, world, rank, done):
     }
     if other is not None:
         out["other_scaling"] = other
+    if replica_check is not None:
+        out["replica_check"] = replica_check
     if do_secondary:
         # strong scaling on N GPUs searches nq / N queries per GPU: the rate a 1/N batch reaches on ONE GPU,
         # relative to the full batch, is the efficiency strong scaling can reach at N (no collective in the path)
@@ -1149,6 +1436,17 @@ def run(args, world, rank, done):
             gpu_ids = ids[:cpu_ids.shape[0]].cpu().numpy()
             inter = [len(np.intersect1d(gpu_ids[q], cpu_ids[q])) for q in range(cpu_ids.shape[0])]
             out["recall_vs_ref@%d" % args.k] = round(float(np.mean(inter)) / args.k, 4)
+            out["ids_equal_to_oracle"] = round(float((gpu_ids == cpu_ids).mean()), 6)
+        # the timed route checked at the size it was timed at: a sample of the batch vs the C oracle, bit for bit
+        # (N > 1: the oracle on a 256-query sample of rank 0's batch -- the parity figure of the N-GPU line; the
+        # CPU baseline itself stays an N = 1 record)
+        if not args.no_cpu_baseline:
+            oc = oracle_sample_check(idx, queries, vals, ids, args.k, n_sample=256 if world > 1 else 32)
+            out["oracle_check"] = oc
+            if world > 1:
+                out["recall_vs_ref@%d" % args.k] = oc.pop("recall_vs_ref")
+            else:
+                oc.pop("recall_vs_ref", None)
         if do_secondary:
             late, _ = secondary_pass(device, args.secondary_budget, only={"c1"}, stream_peak=stream_peak or 0.0)
             secondary.update(late)

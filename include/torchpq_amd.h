@@ -113,6 +113,21 @@ int tpq_ivfpq_scan_topk_packed(const uint8_t* packed, const uint8_t* codes, cons
                                int k, int n_split, void* workspace, size_t workspace_bytes,
                                tpq_stream_t stream);
 size_t tpq_ivfpq_scan_tickets_bytes(int nq);
+
+/* Diagnostics: which kernels a scan call with these arguments runs -- a host-side function that launches nothing and
+ * applies exactly the rules of the entry points above (tests assert the route a shape takes; bench.py names the timed
+ * kernel from it).  `has_lut`: a materialised table is passed (tpq_ivfpq_scan_topk[_packed]) rather than query +
+ * codebook (tpq_ivfpq_search_fused); `has_packed`: the scan-layout copy is passed; `residual`: the residual entry point.
+ * Returns one of TPQ_SCAN_ROUTE_*, or -1 for arguments the entry points reject. */
+#define TPQ_SCAN_ROUTE_REF 0            /* scan_ref_kernel / scan_residual_kernel: the reference layout, exact */
+#define TPQ_SCAN_ROUTE_ONE_LAUNCH 1     /* scan_packed_kernel<.., RM > 0>: the scan workgroups finish their queries */
+#define TPQ_SCAN_ROUTE_LISTS 2          /* scan_packed_kernel + scan_merge_refine_kernel + the flag-gated exact redo */
+#define TPQ_SCAN_ROUTE_POOLS 3          /* large k: scan_packed_kernel<.., RM < 0> + scan_pool_merge_kernel + redo */
+#define TPQ_SCAN_ROUTE_DUMP_F32 8       /* large batches, m = 8 / 16 / 32: fp32 table, scan_finish_exact_kernel + redo */
+#define TPQ_SCAN_ROUTE_DUMP_SEL16 16    /* large batches, m = 64: 16-bit table, four-wave workgroups + finish + redo */
+#define TPQ_SCAN_ROUTE_DUMP_SEL16_W8 17 /* ... eight-wave workgroups (k in (248, 504] on long cells) */
+int tpq_ivfpq_scan_route(int nq, int k, int n_split, int m, int ds, int max_nprobe, int64_t slots_hint, int has_lut,
+                         int has_packed, int has_tickets, int residual);
 int tpq_ivfpq_scan_topk_packed_tickets(const uint8_t* packed, const uint8_t* codes, const float* lut,
                                        const uint8_t* is_empty, const int64_t* cell_start,
                                        const int64_t* cell_size, const int64_t* n_probe_list,
@@ -135,7 +150,11 @@ int tpq_ivfpq_scan_topk_packed_tickets(const uint8_t* packed, const uint8_t* cod
  * codebook) and writes the result; the exact kernel redoes flagged queries (normally none).  Same results,
  * bit for bit.  The library deals the batch's last round of workgroups in parts of a query;
  * nothing of this shows at the boundary beyond the workspace size, which
- * tpq_ivfpq_scan_workspace_bytes(nq, k, n_split, 64) already covers. */
+ * tpq_ivfpq_scan_workspace_bytes(nq, k, n_split, 64) already covers.
+ * Short codes (m == 8, 16, 32; k <= 248; m * ds <= 128 here, any table through tpq_ivfpq_scan_topk_packed) take the
+ * same three launches over the fp32 table their workgroups stream over anyway: the scan workgroup ends after its
+ * last tile, the finish kernel takes the exact entries from the codebook (this entry point) or from the caller's
+ * table (tpq_ivfpq_scan_topk_packed).  tpq_ivfpq_scan_route tells which route a shape takes. */
 int tpq_ivfpq_search_fused(const uint8_t* packed, const uint8_t* codes, const float* query,
                            const float* codebook, int ds, int metric, const uint8_t* is_empty,
                            const int64_t* cell_start, const int64_t* cell_size,
@@ -468,6 +487,13 @@ int tpq_scatter_codes(const uint8_t* codes, const int64_t* address, uint8_t* sto
  * against next to the 8 TB/s spec figure.  `sink_or_null`: optional u32 the kernel may bump. */
 int tpq_ubench_stream_read(const void* src, size_t bytes, void* sink_or_null, int n_blocks,
                            tpq_stream_t stream);
+/* Measurement utility: the same streaming read with its knobs exposed -- `threads` per workgroup (a multiple of 64,
+ * <= 1024), `unroll` 16-byte loads in flight per lane (4, 8, 16), `chunk_bytes` = the size of a contiguous piece dealt to
+ * ONE workgroup (a probed cell of the list scan; 0 = the buffer cut evenly over the workgroups), `nontemporal` loads or
+ * plain ones.  bench.py sweeps a few settings, the scan's own pattern among them, and quotes the best as the stream peak:
+ * a record labelled "hbm" must not exceed it. */
+int tpq_ubench_stream_read_ex(const void* src, size_t bytes, void* sink_or_null, int n_blocks, int threads,
+                              int unroll, size_t chunk_bytes, int nontemporal, tpq_stream_t stream);
 /* Measurement utility: the k-means update's read pattern without its compute -- data f32
  * [l][d][n] read by one-wave blocks, 32 rows x 256 bytes per 64-point tile, `chunks` blocks per
  * (sub-problem, 32-row group) taking tiles round-robin.  Tells a pattern-bound kernel from a

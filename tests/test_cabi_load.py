@@ -93,7 +93,9 @@ def test_argument_validation_without_a_gpu():
     # evicted a candidate" word per list (the dump route's finish kernel), rounded up to 256 bytes
     # (m = 64: room for the dump route's split tail -- 4 parts x 4 waves of lists of 128 entries per query)
     assert lib.tpq_ivfpq_scan_workspace_bytes(100, 100, 1, 64) == 2 * 512 + 100 * 16 * 128 * 8 + 6400
-    assert lib.tpq_ivfpq_scan_workspace_bytes(100, 100, 1, 32) == 2 * 512 + 100 * 4 * 128 * 8 + 1792
+    # (m = 8, 16, 32 since round 6 likewise; the other short codes keep their four lists per query)
+    assert lib.tpq_ivfpq_scan_workspace_bytes(100, 100, 1, 32) == 2 * 512 + 100 * 16 * 128 * 8 + 6400
+    assert lib.tpq_ivfpq_scan_workspace_bytes(100, 100, 1, 24) == 2 * 512 + 100 * 4 * 128 * 8 + 1792
     assert lib.tpq_ivfpq_scan_workspace_bytes(100, 100, 4, 120) == 2 * 512 + 100 * 4 * 16 * 128 * 8 + 25600
     assert lib.tpq_compute_centroids_workspace_bytes(2, 3, 5) == (2 * 3 * 5 + 2 * 5) * 4
 

@@ -116,3 +116,49 @@ def test_rccl_probe_failure_on_one_rank_falls_back_on_all_and_chunked_broadcast(
         assert ret["err0"] and ret["err1"]
         if mode == "probe":
             assert "rank 1" in ret["err1"] and "another rank" in ret["err0"]
+
+
+def test_object_collectives_follow_the_groups_backend(monkeypatch):
+    """the metadata broadcasts were forced onto device=cpu, which an NCCL-only default group
+    (`init_process_group("nccl")`, the recipe INTEGRATION.md showed) cannot serve.  The device now follows the
+    group: CPU where a CPU backend exists, torch's own choice (None) elsewhere."""
+    from torchpq_amd import distributed as tpd
+    for cfg, cpu in (("cuda:nccl", False), ("nccl", False), ("cpu:gloo,cuda:nccl", True), ("gloo", True)):
+        monkeypatch.setattr(dist, "get_backend_config", lambda group=None, c=cfg: c)
+        assert tpd.has_cpu_backend(None) is cpu
+        assert tpd.object_device(None) == (torch.device("cpu") if cpu else None)
+    # the branch torch < 2.1 takes (no get_backend_config): the plain backend name
+    monkeypatch.setattr(dist, "get_backend_config", lambda group=None: (_ for _ in ()).throw(AttributeError("x")))
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
+    assert tpd.object_device(None) is None
+
+
+def _gloo_worker_control_group(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torchpq_amd import distributed as tpd
+    # pretend the default group is NCCL-only: init_groups must then create its own gloo control group and run the
+    # MIN over IT; broadcast_state over that group still announces its metadata on the CPU
+    real = tpd.has_cpu_backend
+    tpd.has_cpu_backend = lambda group=None: False if group is None else real(group)
+    try:
+        g = tpd.init_groups(device="cpu", want_rccl=True, timeout_s=60, create=lambda: None,
+                            probe=lambda grp: None)
+    finally:
+        tpd.has_cpu_backend = real
+    assert g.control is not None and "gloo" in str(dist.get_backend(g.control))
+    tpd.host_barrier(g.control)
+    st = tpd.broadcast_state({"a": torch.arange(5)} if rank == 0 else {}, src=0, device="cpu", group=g.control)
+    if rank == 1:
+        ret["ok"] = bool(torch.equal(st["a"], torch.arange(5))) and g.bulk_backend == "nccl"
+    dist.destroy_process_group()
+
+
+def test_init_groups_brings_its_own_control_group_when_the_default_has_no_cpu_backend():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_worker_control_group, args=(2, port, ret), nprocs=2, join=True)
+    assert ret.get("ok") is True

@@ -98,6 +98,14 @@ def test_bench_gpus2_self_launches_under_the_one_device_hook():
     assert 0 < cfg["ms_per_step_rank_min"] <= cfg["ms_per_step_rank_max"] == rec["ms_per_step"]
     other = rec["other_scaling"]
     assert other["scaling"] == "strong" and other["queries_per_step_all_ranks"] == 512 and other["value"] > 0
+    # VERDICT r5 #1c: the N-GPU line carries its own parity figures -- rank 0's timed results against the C oracle on
+    # a 256-query sample, and a digest per rank of its shard of the shared batch against rank 0's unsharded search
+    oc = rec["oracle_check"]
+    assert oc["queries_checked"] == 256 and oc["ids_equal_to_oracle"] == 1.0 and oc["values_bit_equal"] is True
+    assert rec["recall_vs_ref@100"] == 1.0
+    rc = rec["replica_check"]
+    assert len(rc["shard_digests"]) == 2 and rc["all_ranks_bit_equal_to_rank0_unsharded"] is True
+    assert rc["shard_digests"][0] != rc["shard_digests"][1]          # (different shards: different rows)
 
 
 def test_bench_gpus2_strong_scaling_is_the_headline_when_asked():
@@ -187,6 +195,55 @@ out["same"] = bool(torch.equal(v0, v1) and torch.equal(i0, i1) and int(big[-1]) 
 print(json.dumps(out))
 dist.destroy_process_group()
 '''
+
+
+_NCCL_ONLY = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+import numpy as np
+import torch
+import torch.distributed as dist
+from torchpq_amd import distributed as tpd
+from torchpq_amd.index import IVFPQIndex
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)          # what INTEGRATION.md's shortest recipe does: NO CPU backend
+out = {"object_device": str(tpd.object_device(None))}
+rng = np.random.default_rng(6)
+xb = torch.from_numpy(np.abs(rng.standard_normal((32, 6000)) * 25).astype(np.float32)).to(dev)
+np.random.seed(6)
+idx = IVFPQIndex(d_vector=32, n_subvectors=8, n_cells=16, initial_size=8, device="cuda:0")
+idx.train(xb)
+idx.add(xb)
+idx.n_probe = 4
+v0, i0 = idx.search(xb[:, :64].contiguous(), k=5)
+tpd.replicate_index(idx)                                 # ADVICE r5: raised "No backend type associated with device type cpu"
+v1, i1 = idx.search(xb[:, :64].contiguous(), k=5)
+g = tpd.init_groups(dev, want_rccl=True, timeout_s=120)  # on an NCCL-only default group: its own gloo control group
+tpd.host_barrier(g.control)
+out.update(same=bool(torch.equal(v0, v1) and torch.equal(i0, i1)), bulk_backend=g.bulk_backend,
+           bulk_error=g.bulk_error, control=str(dist.get_backend(g.control)))
+print(json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
+def test_replicate_index_on_an_nccl_only_default_group():
+    """ADVICE r5 (medium): `init_process_group("nccl")` + `replicate_index(index)` -- the recipe INTEGRATION.md shows --
+    has no CPU backend; the metadata broadcasts must not force device=cpu there, and init_groups must bring its own
+    gloo control group"""
+    port = 29800 + (os.getpid() % 2000)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", _NCCL_ONLY, ROOT, str(port)], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["object_device"] == "None" and out["same"], out
+    assert out["bulk_backend"] == "nccl" and out["bulk_error"] is None and "gloo" in out["control"], out
 
 
 def test_rccl_itself_executes_with_one_rank():

@@ -40,7 +40,7 @@ def test_scan_layout_policy_and_instantiated_m():
     assert tuple(int(x) for x in re.findall(r"X\((\d+)\)", m_list)) == PACKED_M
     build = open(os.path.join(ROOT, "torchpq_amd", "csrc", "build.sh")).read()
     loop = re.search(r"for m in ([\d ]+);", build).group(1)
-    assert tuple(int(x) for x in loop.split()) == PACKED_M
+    assert tuple(sorted(int(x) for x in loop.split())) == PACKED_M   # (build.sh compiles the longest units first)
 
 
 def test_alias_table_points_at_existing_wrappers():
@@ -189,3 +189,35 @@ def test_assign_path_policy_and_host_side_shape_functions():
     frag_bytes = (16384 // 128) * 4 * 17 * 1024                                # 128 chunks x 4 units x 17 KiB
     assert off == frag_bytes + 256 and ws >= frag_bytes + (1 << 20) * 4
     assert lib.tpq_max_sim_split_supported(64, 1_000_000, 256) == 1 and lib.tpq_max_sim_split_supported(65, 10, 4) == 0
+
+
+def test_scan_route_rules():
+    """tpq_ivfpq_scan_route: the library's own routing rule, host only (nothing is launched) -- which kernels a scan call
+    runs (reference dispatch by k and m: fn/IVFPQTopk.py:39-104, kernels/IVFPQTopkCuda.py:81-142)"""
+    from torchpq_amd import kernels as K
+
+    def r(m, nq, k, ds=2, n_split=1, n_probe=32, hint=None, has_lut=False, packed=True, residual=False, tickets=None):
+        return K.IVFPQTopkHip(m=m).route(nq, k, n_split, ds, n_probe, hint, has_lut, packed, tickets, residual)
+
+    # the headline and the 100 M-slot workload: four-wave workgroups over the 16-bit table
+    assert r(64, 10000, 100, hint=32 * 977) == "dump_sel16"
+    assert r(64, 10000, 100, n_probe=64, hint=64 * 6103) == "dump_sel16"
+    assert r(64, 10000, 300, hint=32 * 977) == "dump_sel16_w8"      # k in (248, 504] on long cells: eight waves
+    assert r(64, 10000, 600) == "pools"
+    assert r(64, 1023, 100) == "one_launch_finish"                  # below the route's batch size
+    assert r(64, 10000, 100, has_lut=True) == "one_launch_finish"   # m = 64 needs query + codebook for the finish
+    assert r(64, 10000, 100, ds=4) == "one_launch_finish"           # m * ds > 128
+    assert r(64, 16, 100, n_split=8, tickets=False) == "sorted_lists" and r(64, 16, 100, n_split=8) == "one_launch_finish"
+    # round 6: the short codes
+    for m, ds in ((32, 4), (16, 8), (8, 16), (32, 1)):
+        assert r(m, 10000, 100, ds=ds, hint=32 * 244) == "dump_f32"
+        assert r(m, 10000, 100, has_lut=True) == "dump_f32"         # the caller's table: entries gathered per survivor
+        assert r(m, 1000, 100, ds=ds) == "one_launch_finish"
+    assert r(32, 10000, 100, ds=8) == "one_launch_finish"           # fused, m * ds > 128: the codebook would not fit
+    assert r(32, 10000, 300, ds=4) == "pools"                       # k > 248 at m <= 32
+    assert r(24, 10000, 100, ds=4) == "one_launch_finish"           # block structure 16 + 8: not built for the route
+    assert r(120, 1000, 100, has_lut=True, n_probe=64) == "one_launch_finish"
+    assert r(64, 10000, 100, residual=True) == "sorted_lists"
+    assert r(64, 10000, 100, packed=False) == "reference_layout"
+    assert r(64, 10000, 1020, has_lut=True) == "reference_layout"   # no room for the candidate band next to k
+    assert r(64, 0, 100) == "rejected"

@@ -37,6 +37,7 @@ SIGNATURES = {
     "tpq_ivfpq_search_fused": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _i64, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "tpq_ivfpq_scan_tickets_bytes": (_sz, [_i]),
+    "tpq_ivfpq_scan_route": (_i, [_i, _i, _i, _i, _i, _i, _i64, _i, _i, _i, _i]),
     "tpq_ivfpq_scan_topk_packed_tickets": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64,
                                                 _i, _i, _i, _i, _i, _vp, _sz, _vp, _i64, _vp]),
     "tpq_ivfpq_search_fused_tickets": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -90,6 +91,7 @@ SIGNATURES = {
     "tpq_pq_decode": (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp]),
     "tpq_scatter_codes": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _vp]),
     "tpq_ubench_stream_read": (_i, [_vp, _sz, _vp, _i, _vp]),
+    "tpq_ubench_stream_read_ex": (_i, [_vp, _sz, _vp, _i, _i, _i, _sz, _i, _vp]),
     "tpq_ubench_rows_read": (_i, [_vp, _i, _i, _i64, _i, _vp, _vp]),
 }
 

@@ -27,6 +27,7 @@
 //                        candidates exactly (ascending j) at the end of the query and dumps its
 //                        list; scan_merge_refine_kernel (one wave per query) merges the lists.
 //                        Results are bit-identical to scan_ref_kernel.
+#include <atomic>
 #include <chrono>
 
 #include "scan_device.h"
@@ -83,7 +84,7 @@ extern "C" size_t tpq_ivfpq_scan_workspace_bytes(int nq, int k, int n_split, int
   if (R > 16) R = 16;
   // covers both kernels -- and, at m = 64, the dump route's split tail: 4 parts x 4 waves of lists per query
   size_t lists = ws_bytes_for(nq, R, n_split * packed_waves(m));
-  if (m == 64 && dump_finish_regs(k, 1) <= kDumpMaxR) {
+  if ((m == 64 || m == 32 || m == 16 || m == 8) && dump_finish_regs(k, 1) <= kDumpMaxR) {
     const int rp = list_regs_packed(k);
     const size_t tail = ws_bytes_for(nq, rp < 2 ? rp : 2, 16), whole = ws_bytes_for(nq, rp < 4 ? rp : 4, 4);
     lists = tail > lists ? tail : lists;
@@ -141,13 +142,24 @@ static int dump_route(const ScanArgs& a, bool residual, int R) {
   if (residual || R > kDumpMaxR) return 0;
   // (the route deals the queries itself -- dump_tail --: a caller's n_split > 1 belongs to batches below its threshold)
   if (a.n_split != 1 && dump_min_queries() == kDumpMinQueries) return 0;
-  // the finish kernel recomputes the survivors' table entries from the codebook, held in LDS next to nothing else:
-  // fused calls (query + codebook) only, m * ds <= 128
-  if (a.lut || a.m != 64 || a.ds > 2 || a.nq < dump_min_queries()) return 0;
+  if (a.nq < dump_min_queries()) return 0;
   const char* e = TPQ_AB_ENV("TPQ_SCAN_DUMP");
   if (e && atoi(e) == 0) return 0;
   // (the finish kernel takes a query's lists as at most 16 chunks of 64 keys: four waves x RL <= 4, eight x RL <= 2)
   const int rl4 = list_regs_scan(a.k, a.m, a.max_nprobe, a.slots_hint, 4);
+  if (a.m == 8 || a.m == 16 || a.m == 32) {
+    // Short codes (round 6): the fp32 table their four-wave workgroups stream over anyway; the finish kernel takes the
+    // exact entries from the codebook in LDS (fused calls, m * ds <= 128) or from the caller's table.  k <= 248: the
+    // pools keep the larger k (TPQ_SCAN_DUMP_SHORT_K=n in variant builds moves the limit for A/B).
+    const char* ek = TPQ_AB_ENV("TPQ_SCAN_DUMP_SHORT_K");
+    const int kmax = ek ? atoi(ek) : kDumpShortMaxK;
+    if (a.k > kmax || rl4 > 4) return 0;
+    if (!a.lut && a.m * a.ds > 128) return 0;
+    return kDumpF32;
+  }
+  // m = 64: the 16-bit table.  The finish kernel recomputes the survivors' table entries from the codebook, held in
+  // LDS next to nothing else: fused calls (query + codebook) only, m * ds <= 128
+  if (a.lut || a.m != 64 || a.ds > 2) return 0;
   const int rl8 = list_regs_scan(a.k, a.m, a.max_nprobe, a.slots_hint);
   // Lists of 4 registers in four-wave workgroups only where eight waves would need them as well (short cells, k > 256):
   // folding into a 256-entry list is what a large k costs, and four waves see twice the candidates each.
@@ -165,15 +177,36 @@ static int dump_route(const ScanArgs& a, bool residual, int R) {
 // nq mod slots queries left after the full rounds are dealt in 4 (or 2) parts each when those parts fit one round and
 // the finish kernel can take their lists (<= 16 chunks of 64 keys per query) -- 1 250 queries: 1 024 whole + 226 x 4.
 static int device_cus() {
-  static int cached[64] = {};
+  // (per-device cache; relaxed atomics: concurrent first calls from several host threads write the same value)
+  static std::atomic<int> cached[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (cached[dev] <= 0) {
-    int n = 0;
+  int n = cached[dev].load(std::memory_order_relaxed);
+  if (n <= 0) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cached[dev] = n;
+    cached[dev].store(n, std::memory_order_relaxed);
   }
-  return cached[dev];
+  return n;
+}
+// workgroup slots of the dump-mode scan kernel on this device: CUs x the workgroups of it a CU holds -- from the occupancy
+// query of the kernel's smallest instantiation (the "4 per CU" used to be an assumption)
+static int dump_slots(int m, int mode) {
+  static std::atomic<int> per_cu[3][4] = {};  // [mode][m class]
+  const int mi = mode == kDumpSel16 ? 0 : (mode == kDumpF32 ? 1 : 2), ci = m == 64 ? 0 : (m == 32 ? 1 : (m == 16 ? 2 : 3));
+  int n = per_cu[mi][ci].load(std::memory_order_relaxed);
+  if (n <= 0) {
+    n = 4;
+    int q = 0;
+    switch (m) {
+#define TPQ_CASE_M(M) case M: q = dump_occupancy_##M(mode); break;
+      TPQ_PACKED_M_LIST(TPQ_CASE_M)
+#undef TPQ_CASE_M
+      default: break;
+    }
+    if (q > 0) n = q;
+    per_cu[mi][ci].store(n, std::memory_order_relaxed);
+  }
+  return n * device_cus();
 }
 static void dump_tail(int nq, int nw, int RL, int slots, int* unsplit, int* parts) {
   *unsplit = nq;
@@ -293,6 +326,52 @@ extern "C" int tpq_ivfpq_scan_topk_packed(const uint8_t* packed, const uint8_t* 
                                             k, n_split, workspace, workspace_bytes, nullptr, 0, stream);
 }
 
+// Which kernels a packed call runs (the order of the tests is run_packed's): TPQ_SCAN_ROUTE_* of torchpq_amd.h.
+// `dump_regs`: registers of the finish kernel's exact list on the dump routes.
+static int packed_route(const ScanArgs& a, bool residual, int* dump_regs = nullptr) {
+  const int m = a.m, k = a.k;
+  const int R = list_regs_packed(k);
+  if (!has_packed_kernel(m)) return TPQ_SCAN_ROUTE_REF;
+  const bool lds_fits =
+      scan_lds_bytes_packed(m, R > 16 ? 16 : R, a.max_nprobe, fused_floats_of(a), residual) <= 160 * 1024;
+  // k within kBandSlack of 1024 (no room for the candidate band), or a probe table that no longer
+  // fits next to the LUT: scan exactly with the reference-layout kernel
+  if (R > 16 || !lds_fits) return TPQ_SCAN_ROUTE_REF;
+  // (measured against the sorted lists of the three-launch path, C2 shape, 10 000 queries: m = 64, k = 600 / 1000:
+  // 6.1 / 6.9 ms against 7.1 / 8.3; m = 120 (1 000 queries), k = 1000: 2.0 against 3.4 -- and k = 600: 1.9 against 1.6;
+  // m = 16, 32: within 2 %; k = 300, 500 at m = 64: 4.1 / 4.5 against 3.6 / 4.0)
+  const bool pools = !residual && R >= pool_min_list_regs(m) && (packed_waves(m) < 16 || k > 768) && fuse_enabled();
+  if (!pools) {  // (large batches: dump_route)
+    const int Rf = dump_finish_regs(k, a.slots_hint);
+    if (dump_regs) *dump_regs = Rf;
+    const int mode = dump_route(a, residual, Rf);
+    if (mode == kDumpSel16) return TPQ_SCAN_ROUTE_DUMP_SEL16;
+    if (mode == kDumpSel16W8) return TPQ_SCAN_ROUTE_DUMP_SEL16_W8;
+    if (mode == kDumpF32) return TPQ_SCAN_ROUTE_DUMP_F32;
+  } else {
+    return TPQ_SCAN_ROUTE_POOLS;
+  }
+  const int RL = list_regs_scan(k, m, a.max_nprobe, a.slots_hint);
+  if (!residual && fuse_enabled() && fuse_fits(m, R) && packed_waves(m) * RL >= R && (a.n_split == 1 || a.tickets))
+    return TPQ_SCAN_ROUTE_ONE_LAUNCH;
+  return TPQ_SCAN_ROUTE_LISTS;
+}
+
+extern "C" int tpq_ivfpq_scan_route(int nq, int k, int n_split, int m, int ds, int max_nprobe, int64_t slots_hint,
+                                    int has_lut, int has_packed, int has_tickets, int residual) {
+  if (nq <= 0 || k < 1 || k > 1024 || m < 4 || m % 4 != 0 || n_split < 1 || max_nprobe < 1) return -1;
+  if (!has_packed) return TPQ_SCAN_ROUTE_REF;
+  ScanArgs a{};
+  static const float dummy_lut = 0.f;
+  static int32_t dummy_tickets = 0;
+  a.lut = has_lut ? &dummy_lut : nullptr;   // (only tested against nullptr)
+  a.ds = has_lut ? 0 : ds;
+  a.nq = nq; a.k = k; a.n_split = n_split; a.m = m; a.max_nprobe = max_nprobe;
+  a.slots_hint = slots_hint;
+  a.tickets = has_tickets ? &dummy_tickets : nullptr;
+  return packed_route(a, residual != 0);
+}
+
 static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_t workspace_bytes,
                       tpq_stream_t stream) {
   int rc = validate(a);
@@ -300,6 +379,7 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
   TPQ_REQUIRE(a.packed != nullptr, "ivfpq_scan_packed: null packed pointer");
   if (a.nq == 0) return TPQ_OK;
   const int nq = a.nq, k = a.k, n_split = a.n_split, m = a.m;
+  int32_t* const caller_tickets = a.tickets;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int R = list_regs_packed(k);
   if (!has_packed_kernel(m)) {
@@ -307,12 +387,11 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
               "tpq_ivfpq_scan_topk", m);
     return TPQ_ERR_UNSUPPORTED;
   }
-  // k within kBandSlack of 1024 (no room for the candidate band), or a probe table that no longer
-  // fits next to the LUT: scan exactly with the reference-layout kernel
-  const bool lds_fits =
-      scan_lds_bytes_packed(m, R > 16 ? 16 : R, a.max_nprobe, fused_floats_of(a), ra != nullptr) <=
-      160 * 1024;
-  if (R > 16 || !lds_fits) {
+  int Rf = 0;
+  int route = packed_route(a, ra != nullptr, &Rf);
+  if (route == TPQ_SCAN_ROUTE_REF) {
+    // k within kBandSlack of 1024 (no room for the candidate band), or a probe table that no longer
+    // fits next to the LUT: scan exactly with the reference-layout kernel
     if (ra) {
       a.n_split = 1;
       return run_residual_ref(a, *ra, st);
@@ -326,10 +405,7 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
     return dispatch_ref(a, Rr, st);
   }
   const int n_lists = n_split * packed_waves(m);
-  // (measured against the sorted lists of the three-launch path, C2 shape, 10 000 queries: m = 64, k = 600 / 1000:
-  // 6.1 / 6.9 ms against 7.1 / 8.3; m = 120 (1 000 queries), k = 1000: 2.0 against 3.4 -- and k = 600: 1.9 against 1.6;
-  // m = 16, 32: within 2 %; k = 300, 500 at m = 64: 4.1 / 4.5 against 3.6 / 4.0)
-  if (!ra && R >= pool_min_list_regs(m) && (packed_waves(m) < 16 || k > 768) && fuse_enabled()) {
+  if (route == TPQ_SCAN_ROUTE_POOLS) {
     // the largest k, plain PQ: pool mode (scan_device.h) -- threshold lists of ceil(k / waves) entries, unsorted pools,
     // one ranking kernel per query; flagged queries (a pool or the ranking buffer overflowed) redone exactly
     // (the ranking kernel takes a query's lists into LDS: fewer workgroups per query when they would not fit)
@@ -357,41 +433,51 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
     b.only_flagged = a.flags;
     return dispatch_ref(b, list_regs(k), st);
   }
-  // large batches of plain PQ at m = 64, k <= 248: dump mode (scan_device.h) -- the scan workgroups stream over the
-  // 16-bit table (32 KiB: four workgroups per CU) and end with their lists of fast values, one wave per query finishes
-  {
-    const int Rf = dump_finish_regs(k, a.slots_hint);
-    if (const int mode = dump_route(a, ra != nullptr, Rf)) {
-      const int nw = mode == kDumpSel16 ? 4 : packed_waves(m);
-      const int RLd = list_regs_scan(k, m, a.max_nprobe, a.slots_hint, nw);
-      int unsplit = nq, parts = 1;
-      if (mode == kDumpSel16) dump_tail(nq, nw, RLd, 4 * device_cus(), &unsplit, &parts);
-      // (a caller's workspace sized by an older rule: the tail stays whole)
-      if (parts > 1 && (!workspace || workspace_bytes < ws_bytes_for(nq, RLd, parts * nw))) unsplit = nq, parts = 1;
-      a.n_split = parts;
-      a.unsplit = parts > 1 ? unsplit : 0;  // (0 with one part per query: "all queries split 1 way")
-      rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, RLd, parts * nw), "ivfpq_scan_packed");
-      if (rc) return rc;
-      fill_ws(a, workspace, RLd, parts * nw);
-      a.epoch = fresh_epoch();
-      a.fuse = 0;
-      a.tickets = nullptr;
-      a.small_lists = 0;
+  // large batches of plain PQ, k <= 504: dump mode (scan_device.h) -- the scan workgroups stream over the selection table
+  // (m = 64: 16-bit, 32 KiB, four workgroups per CU; m = 8, 16, 32: the fp32 table) and end with their lists of fast
+  // values, one wave per query finishes
+  if (route == TPQ_SCAN_ROUTE_DUMP_SEL16 || route == TPQ_SCAN_ROUTE_DUMP_SEL16_W8 || route == TPQ_SCAN_ROUTE_DUMP_F32) {
+    const int mode = route == TPQ_SCAN_ROUTE_DUMP_SEL16 ? kDumpSel16
+                                                        : (route == TPQ_SCAN_ROUTE_DUMP_F32 ? kDumpF32 : kDumpSel16W8);
+    const int nw = mode == kDumpSel16W8 ? packed_waves(m) : 4;
+    const int RLd = list_regs_scan(k, m, a.max_nprobe, a.slots_hint, nw);
+    int unsplit = nq, parts = 1;
+    if (mode != kDumpSel16W8) dump_tail(nq, nw, RLd, dump_slots(m, mode), &unsplit, &parts);
+    // (a caller's workspace sized by an older rule: the tail stays whole)
+    if (parts > 1 && (!workspace || workspace_bytes < ws_bytes_for(nq, RLd, parts * nw))) unsplit = nq, parts = 1;
+    a.n_split = parts;
+    a.unsplit = parts > 1 ? unsplit : 0;  // (0 with one part per query: "all queries split 1 way")
+    rc = need_ws(workspace, workspace_bytes, ws_bytes_for(nq, RLd, parts * nw), "ivfpq_scan_packed");
+    if (rc) return rc;
+    fill_ws(a, workspace, RLd, parts * nw);
+    a.epoch = fresh_epoch();
+    a.fuse = 0;
+    a.tickets = nullptr;
+    a.small_lists = 0;
 #ifdef TPQ_SCAN_PROFILE
-      a.prof = g_scan_prof;
+    a.prof = g_scan_prof;
 #endif
-      switch (m) {
+    switch (m) {
 #define TPQ_CASE_M(M) case M: rc = dispatch_dump_##M(a, RLd, Rf, mode, st); break;
-        TPQ_PACKED_M_LIST(TPQ_CASE_M)
+      TPQ_PACKED_M_LIST(TPQ_CASE_M)
 #undef TPQ_CASE_M
-        default: rc = TPQ_ERR_UNSUPPORTED; break;
-      }
-      if (rc) return rc;
+      default: rc = TPQ_ERR_UNSUPPORTED; break;
+    }
+    if (rc == TPQ_OK) {
       ScanArgs b = a;  // exact redo of the (normally zero) flagged queries
       b.n_split = 1;
       b.only_flagged = a.flags;
       return dispatch_ref(b, list_regs(k), st);
     }
+    // TPQ_ERR_UNSUPPORTED = no instantiation for (mode, RLd, Rf) at this m, reported before any launch: the sorted
+    // lists below take the call (a change of the list-size heuristics must not fail a search)
+    if (rc != TPQ_ERR_UNSUPPORTED) return rc;
+    a.n_split = n_split;
+    a.unsplit = 0;
+    a.tickets = caller_tickets;
+    const int RLs = list_regs_scan(k, m, a.max_nprobe, a.slots_hint);
+    route = (fuse_enabled() && fuse_fits(m, R) && packed_waves(m) * RLs >= R && (n_split == 1 || a.tickets))
+                ? TPQ_SCAN_ROUTE_ONE_LAUNCH : TPQ_SCAN_ROUTE_LISTS;
   }
   // registers of the per-wave lists (<= R)
   const int RL = list_regs_scan(k, m, a.max_nprobe, a.slots_hint);
@@ -406,9 +492,7 @@ static int run_packed(ScanArgs a, const ResidualArgs* ra, void* workspace, size_
   a.epoch = fresh_epoch();
   // the scan workgroups finish the query themselves (merge, write, exact redo): one launch instead of three.
   // (k <= 248, plain PQ; a query split over several workgroups needs the caller's tickets)
-  a.fuse = 0;
-  if (!ra && fuse_enabled() && fuse_fits(m, R) && packed_waves(m) * RL >= R)
-    a.fuse = (n_split == 1 || a.tickets) ? 1 : 0;
+  a.fuse = route == TPQ_SCAN_ROUTE_ONE_LAUNCH ? 1 : 0;
   if (!a.fuse) a.tickets = nullptr;
   switch (m) {
 #define TPQ_CASE_M(M) case M: rc = dispatch_packed_##M(a, ra, RL, R, st); break;

@@ -24,6 +24,10 @@ static int pool_min_list_regs(int m) { return m <= 32 ? 8 : kPoolMinListRegs; }
 constexpr int kScanWaves = 8;
 constexpr int kScanThreads = kScanWaves * 64;
 
+// ws_delta[q] after a call: the value scan_ref_kernel / scan_residual_kernel leave when they redo a FLAGGED query (a
+// selection band is >= 0 and the one-launch finisher writes 1.f / 0.f: -1 is neither) -- IVFPQTopkHip.last_redone
+constexpr float kRedoneMark = -1.f;
+
 struct ScanArgs {
   const uint8_t* codes;    // reference layout [m/4][n_slots][4]
   const uint8_t* packed;   // scan layout (packed kernel only)
@@ -79,6 +83,7 @@ constexpr int kDumpSel16 = -16;  // 16-bit fixed-point table (m / 2 KiB), an exa
 constexpr int kDumpSel16W8 = -17;  // the same with the eight waves of the other paths (k in (248, 504]: lists of <= 2 registers)
 constexpr bool is_sel16(int RM) { return RM == kDumpSel16 || RM == kDumpSel16W8; }
 constexpr int kDumpMinQueries = 1024;  // batches that fill the chip's 4 x 256 workgroup slots at least once
+constexpr int kDumpShortMaxK = 248;    // m = 8, 16, 32 (kDumpF32): the pools take the larger k
 
 #ifdef TPQ_SCAN_PROFILE
 #define TPQ_PROF(a, q, i)                                                        \
@@ -334,7 +339,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_ref_kernel(ScanArgs a) {
                   reinterpret_cast<int*>(smem + kScanWaves * R * 64 * 4));
   // exact redo (one workgroup per query): the flag is consumed -- every thread read it before the first barrier.
   // (a captured graph replays with the same epoch: a flag left raised would redo the query on every replay)
-  if (a.only_flagged && threadIdx.x == 0) const_cast<int*>(a.only_flagged)[q] = 0;
+  // Diagnostics: ws_delta[q] = kRedoneMark says "this query was redone exactly" -- on the routes whose
+  // ws_delta holds a selection band the finisher's 1.f / 0.f never appears, so IVFPQTopkHip.last_redone reads this mark
+  // (a band is >= 0; nobody reads ws_delta after this kernel, the call's last).
+  if (a.only_flagged && threadIdx.x == 0) {
+    const_cast<int*>(a.only_flagged)[q] = 0;
+    if (a.ws_delta) a.ws_delta[q] = kRedoneMark;
+  }
 }
 
 // ---- residual PQ (reference layout, exact) --------------------------------------------------
@@ -439,7 +450,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_residual_kernel(ScanArgs a,
   sel.flush();
   finish_query<R>(a, q, 0, sel.top, reinterpret_cast<float*>(smem),
                   reinterpret_cast<int*>(smem + kScanWaves * R * 64 * 4));
-  if (a.only_flagged && threadIdx.x == 0) const_cast<int*>(a.only_flagged)[q] = 0;  // consumed (see scan_ref_kernel)
+  if (a.only_flagged && threadIdx.x == 0) {  // consumed, and marked as redone (see scan_ref_kernel)
+    const_cast<int*>(a.only_flagged)[q] = 0;
+    if (a.ws_delta) a.ws_delta[q] = kRedoneMark;
+  }
 }
 
 // ---- packed-layout kernel ------------------------------------------------------------------
@@ -1839,28 +1853,35 @@ __global__ __launch_bounds__(512) void scan_merge_refine_kernel(ScanArgs a) {
 // butterfly: 160 us, instruction-bound at ~6 000 VALU per query; this form: ~2 500.)  Nothing of a scan workgroup's
 // table slot is held while this runs, which is the point of the split: the end of a query idled that slot for 17 of
 // its 43 us.
-// (waves per workgroup: 16 while the survivor queues -- 64 RM addresses per wave -- fit beside the codebook's 128 KiB;
-// RM = 8, k in (248, 504]: 8)
-constexpr int finish_waves(int RM) { return RM <= 8 ? 16 : 8; }  // (RM = 8, ds = 2: 128 + 32 KiB, all of the CU's LDS)
+// (waves per workgroup: 16 at every RM the kernel is built for -- RM = 8, k in (248, 504], ds = 2: 128 KiB of codebook + 32
+// KiB of survivor queues, all of the CU's LDS; a longer exact list would halve them)
+//
+// Round 6: every packed block structure (the 64-block of m = 64 and the 32 / 16 / 8 / 4-blocks of the shorter codes:
+// the un-permute below walks scan_layout's blocks), any sub-vector length with m * ds <= 128 (DS = 0: read from the
+// arguments), and a second SOURCE of the exact entries -- FROM_LUT: the caller's materialised table [m][nq][256]
+// (tpq_adc_lut's output, the reference boundary: IVFPQTopkCuda.topk(precomputed=...), kernels/IVFPQTopkCuda.py:81-142),
+// gathered per survivor (m independent loads per lane, ascending-j adds); nothing is staged in LDS then.
+constexpr int finish_waves(int RM) { return RM <= 8 ? 16 : 8; }
 constexpr int kDumpMaxR = 8;  // registers of the finish kernel's exact list: k <= 504
-static size_t finish_lds_bytes(int m, int ds, int RM) {
-  return (size_t)m * ds * 1024 + (size_t)finish_waves(RM) * RM * 64 * 4;
+static size_t finish_lds_bytes(int m, int ds, int RM, bool from_lut) {
+  return (from_lut ? 0 : (size_t)m * ds * 1024) + (size_t)finish_waves(RM) * RM * 64 * 4;
 }
-template <int RM, int M, int DS, int NCH>
+template <int RM, int M, int DS, int NCH, bool FROM_LUT = false>
 __global__ __launch_bounds__(finish_waves(RM) * 64) void scan_finish_exact_kernel(ScanArgs a, int nw_scan, int RL) {
   constexpr int kFinishWaves = finish_waves(RM);
   using L = scan_layout::Layout<M>;
-  static_assert(M == 64, "one 64-block: the in-register un-permute below");
-  static_assert(M * DS <= 128, "the query rides in two registers per lane");
+  constexpr int G = M / 4;  // code dwords per slot
+  static_assert(DS == 0 || M * DS <= 128, "the query rides in two registers per lane");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int ds = DS ? DS : a.ds;  // (the host admits m * ds <= 128 only)
   float* cb = reinterpret_cast<float*>(smem);  // [m][ds][256]
-  {
+  if constexpr (!FROM_LUT) {
     const float4* __restrict__ src = reinterpret_cast<const float4*>(a.codebook);
     float4* dst = reinterpret_cast<float4*>(cb);
-    for (int i = threadIdx.x; i < M * DS * 64; i += kFinishWaves * 64) dst[i] = src[i];
+    for (int i = threadIdx.x; i < M * ds * 64; i += kFinishWaves * 64) dst[i] = src[i];
   }
-  int* qi = reinterpret_cast<int*>(cb + M * DS * 256) + wave * (RM * 64);  // the wave's survivors (addresses)
+  int* qi = reinterpret_cast<int*>(cb + (FROM_LUT ? 0 : M * ds * 256)) + wave * (RM * 64);  // the wave's survivors (addresses)
   __syncthreads();
   const int n_lists_all = a.n_split * nw_scan;
   const int T_all = n_lists_all * RL;  // chunks per query in the workspace (<= NCH)
@@ -1872,13 +1893,14 @@ __global__ __launch_bounds__(finish_waves(RM) * 64) void scan_finish_exact_kerne
     const int T = n_lists * RL;  // chunks in use
     // the query: component i in lane i % 64 of register i / 64; |q_j|^2 (ascending-dimension fma chain) in lane j
     float xv[2] = {0.f, 0.f}, q2v = 0.f;
-    if (lane < M * DS) xv[0] = a.query[(int64_t)lane * a.nq + q];
-    if (64 + lane < M * DS) xv[1] = a.query[(int64_t)(64 + lane) * a.nq + q];
-    if (lane < M) {
-#pragma unroll
-      for (int e = 0; e < DS; ++e) {
-        const float x = a.query[(int64_t)(lane * DS + e) * a.nq + q];
-        q2v = fmaf(x, x, q2v);
+    if constexpr (!FROM_LUT) {
+      if (lane < M * ds) xv[0] = a.query[(int64_t)lane * a.nq + q];
+      if (64 + lane < M * ds) xv[1] = a.query[(int64_t)(64 + lane) * a.nq + q];
+      if (lane < M) {
+        for (int e = 0; e < ds; ++e) {
+          const float x = a.query[(int64_t)(lane * ds + e) * a.nq + q];
+          q2v = fmaf(x, x, q2v);
+        }
       }
     }
     const unsigned* __restrict__ bv = reinterpret_cast<const unsigned*>(a.ws_vals) + (int64_t)q * T_all * 64;
@@ -1938,47 +1960,76 @@ __global__ __launch_bounds__(finish_waves(RM) * 64) void scan_finish_exact_kerne
       const int idx = want ? qi[r * 64 + lane] : 0;  // (idle lanes walk slot 0's bytes: in range)
       typename L::chunk_t cw[L::kChunks];
       L::load(a.packed, a.n_slots, idx, cw);
-      // sub-quantizer order: out dword D byte B = in dword D ^ (x >> 2), byte B ^ (x & 3), x = idx mod 64
-      const unsigned x = (unsigned)idx & 63u;
-      const unsigned sel = 0x03020100u ^ ((x & 3u) * 0x01010101u);
-      unsigned cd[16];
+      // sub-quantizer order, block by block (scan_layout::subq_at): inside a block of B positions from base b,
+      // out dword D byte Y = in dword D ^ (x >> 2), byte Y ^ (x & 3), x = idx mod B -- a byte permute per dword for
+      // the low two bits of x, log2(B / 4) rounds of conditional dword swaps for the others
+      unsigned cd[G];
 #pragma unroll
-      for (int d = 0; d < 16; ++d) {
+      for (int d = 0; d < G; ++d) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const scan_layout::BlockAt<M> kb(4 * d);
+        const unsigned x = (unsigned)idx & (unsigned)(kb.size - 1);
+        const unsigned sel = 0x03020100u ^ ((x & 3u) * 0x01010101u);
         const unsigned wd = L::word(cw, d);
         cd[d] = __builtin_amdgcn_perm(wd, wd, sel);
       }
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const bool sw = ((x >> (2 + b)) & 1u) != 0u;
 #pragma unroll
-        for (int d = 0; d < 16; ++d) {
-          if ((d & (1 << b)) == 0) {
-            const unsigned lo = cd[d], up = cd[d | (1 << b)];
+        for (int d = 0; d < G; ++d) {
+          const scan_layout::BlockAt<M> kb(4 * d);
+          const int dr = d - (kb.base >> 2);            // dword inside the block
+          if ((4 << b) < kb.size && (dr & (1 << b)) == 0) {  // the block has this XOR bit; d is the pair's lower dword
+            const bool sw = (((unsigned)idx >> (2 + b)) & 1u) != 0u;  // (bit 2 + b of idx mod B: 4 << b < B)
+            const unsigned lo = cd[d], up = cd[d | (1 << b)];         // (blocks are aligned to their size: | == +)
             cd[d] = sw ? up : lo;
             cd[d | (1 << b)] = sw ? lo : up;
           }
         }
       }
       float v = 0.f;
+      if constexpr (FROM_LUT) {
+        // the caller's table: entry (j, c) of query q at lut[(j * nq + q) * 256 + c]; all loads first, adds ascending j
+        float ent[M];
 #pragma unroll
-      for (int j = 0; j < M; ++j) {
-        const unsigned c = (cd[j >> 2] >> (8 * (j & 3))) & 255u;
-        float dot = 0.f, c2 = 0.f;
-#pragma unroll
-        for (int e = 0; e < DS; ++e) {
-          constexpr int dummy = 0;
-          (void)dummy;
-          const int i = j * DS + e;
-          const float y = cb[i * 256 + (int)c];
-          const float xx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[i >> 6]), i & 63));
-          dot = fmaf(xx, y, dot);
-          c2 = fmaf(y, y, c2);
+        for (int j = 0; j < M; ++j) {
+          const unsigned c = (cd[j >> 2] >> (8 * (j & 3))) & 255u;
+          ent[j] = a.lut[((int64_t)j * a.nq + q) * 256 + (int)c];
         }
-        // (fused_lut4's arithmetic, operation for operation)
-        float val = 2.f * dot;
-        val = val - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q2v), j));
-        val = val - c2;
-        v += euclid ? val : dot;
+#pragma unroll
+        for (int j = 0; j < M; ++j) v += ent[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          const unsigned c = (cd[j >> 2] >> (8 * (j & 3))) & 255u;
+          float dot = 0.f, c2 = 0.f;
+          if constexpr (DS != 0) {
+#pragma unroll
+            for (int e = 0; e < DS; ++e) {
+              const int i = j * DS + e;
+              const float y = cb[i * 256 + (int)c];
+              const float xx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[i >> 6]), i & 63));
+              dot = fmaf(xx, y, dot);
+              c2 = fmaf(y, y, c2);
+            }
+          } else {
+            for (int e = 0; e < ds; ++e) {  // (wave-uniform trip count and lane index)
+              const int i = j * ds + e;
+              const float y = cb[i * 256 + (int)c];
+              const int x0 = __builtin_amdgcn_readlane(__float_as_int(xv[0]), i & 63);
+              const int x1 = __builtin_amdgcn_readlane(__float_as_int(xv[1]), i & 63);
+              const float xx = __int_as_float(i < 64 ? x0 : x1);
+              dot = fmaf(xx, y, dot);
+              c2 = fmaf(y, y, c2);
+            }
+          }
+          // (fused_lut4's arithmetic, operation for operation)
+          float val = 2.f * dot;
+          val = val - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q2v), j));
+          val = val - c2;
+          v += euclid ? val : dot;
+        }
       }
       ex.insert_unsorted(want ? make_key(v + 0.0f, idx) : pad_key());
     }
@@ -2130,7 +2181,8 @@ static bool fuse_fits(int m, int RM) {
 #define TPQ_DECLARE_PACKED(M) \
   int dispatch_packed_##M(const ScanArgs& a, const ResidualArgs* ra, int RL, int R, hipStream_t st); \
   int dispatch_pool_##M(const ScanArgs& a, int RL, hipStream_t st);                                  \
-  int dispatch_dump_##M(const ScanArgs& a, int RL, int R, int mode, hipStream_t st);
+  int dispatch_dump_##M(const ScanArgs& a, int RL, int R, int mode, hipStream_t st);                 \
+  int dump_occupancy_##M(int mode);
 TPQ_PACKED_M_LIST(TPQ_DECLARE_PACKED)
 #undef TPQ_DECLARE_PACKED
 

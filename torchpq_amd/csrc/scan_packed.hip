@@ -67,16 +67,22 @@ static int launch_pool(ScanArgs a, hipStream_t st) {
 }
 
 // dump modes (scan_device.h): the scan ends with the waves' lists of fast values; scan_finish_exact_kernel, one wave per
-// query, evaluates the band's survivors exactly and writes the result.  Instantiated for m = 64 (the 16-bit table).
-constexpr bool has_dump(int M) { return M == 64; }
+// query, evaluates the band's survivors exactly and writes the result.  m = 64: the 16-bit table (kDumpSel16 / W8);
+// m = 8, 16, 32 (round 6): the fp32 table the four-wave workgroups of the short codes stream over anyway (kDumpF32) --
+// what they gain is the early end of the scan workgroup.
 constexpr bool has_sel16(int M) { return M == 64; }
-// the finish kernel: survivors in RM = 2 or 4 registers (k <= 56 rides on 2), sub-vector length 1 / 2, 4 or 8 chunks
+constexpr bool has_dump_f32(int M) { return M == 8 || M == 16 || M == 32; }
+constexpr bool has_dump(int M) { return has_sel16(M) || has_dump_f32(M); }
+// the finish kernel: survivors in RM = 2, 4 or 8 registers (k <= 56 rides on 2); the exact entries from the codebook
+// in LDS (fused calls; sub-vector length 1 / 2 compiled in at m = 64, read from the arguments otherwise) or gathered from
+// the caller's table (m <= 32); 4, 8 or 16 chunks of 64 keys per query
 template <int RM, int M>
 static int launch_finish(const ScanArgs& a, int nw_scan, int RL, hipStream_t st) {
   if constexpr (!has_dump(M)) {
     return TPQ_ERR_UNSUPPORTED;
   } else {
-    const size_t flds = finish_lds_bytes(M, a.ds, RM);
+    const bool from_lut = a.lut != nullptr;
+    const size_t flds = finish_lds_bytes(M, a.ds, RM, from_lut);
     // one persistent workgroup per CU (its LDS holds the codebook)
     int dev = 0, n_cus = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -84,7 +90,9 @@ static int launch_finish(const ScanArgs& a, int nw_scan, int RL, hipStream_t st)
       n_cus = 256;
     constexpr int FW = finish_waves(RM);
     const int want = (a.nq + FW - 1) / FW;
-    const dim3 grid((unsigned)(want < n_cus ? want : n_cus)), block(FW * 64);
+    // (the table-gathering form holds no codebook: workgroups are cheap, two per CU hide the gathers' latency)
+    const int cap = from_lut ? 2 * n_cus : n_cus;
+    const dim3 grid((unsigned)(want < cap ? want : cap)), block(FW * 64);
     auto go = [&](auto kernel) -> int {
       int rc = set_lds(kernel, flds, "scan_finish_exact_kernel");
       if (rc) return rc;
@@ -93,19 +101,28 @@ static int launch_finish(const ScanArgs& a, int nw_scan, int RL, hipStream_t st)
       return TPQ_OK;
     };
     const int T = a.n_split * nw_scan * RL;  // (16: the split tail of a batch, ScanArgs::unsplit)
-    if (a.ds == 1)
-      return T <= 4 ? go(scan_finish_exact_kernel<RM, M, 1, 4>)
-                    : (T <= 8 ? go(scan_finish_exact_kernel<RM, M, 1, 8>) : go(scan_finish_exact_kernel<RM, M, 1, 16>));
-    return T <= 4 ? go(scan_finish_exact_kernel<RM, M, 2, 4>)
-                  : (T <= 8 ? go(scan_finish_exact_kernel<RM, M, 2, 8>) : go(scan_finish_exact_kernel<RM, M, 2, 16>));
+    if constexpr (has_sel16(M)) {
+      if (a.ds == 1)
+        return T <= 4 ? go(scan_finish_exact_kernel<RM, M, 1, 4>)
+                      : (T <= 8 ? go(scan_finish_exact_kernel<RM, M, 1, 8>) : go(scan_finish_exact_kernel<RM, M, 1, 16>));
+      return T <= 4 ? go(scan_finish_exact_kernel<RM, M, 2, 4>)
+                    : (T <= 8 ? go(scan_finish_exact_kernel<RM, M, 2, 8>) : go(scan_finish_exact_kernel<RM, M, 2, 16>));
+    } else {
+      if (from_lut)
+        return T <= 4 ? go(scan_finish_exact_kernel<RM, M, 0, 4, true>)
+                      : (T <= 8 ? go(scan_finish_exact_kernel<RM, M, 0, 8, true>)
+                                : go(scan_finish_exact_kernel<RM, M, 0, 16, true>));
+      return T <= 4 ? go(scan_finish_exact_kernel<RM, M, 0, 4>)
+                    : (T <= 8 ? go(scan_finish_exact_kernel<RM, M, 0, 8>) : go(scan_finish_exact_kernel<RM, M, 0, 16>));
+    }
   }
 }
 
 template <int RL, int R, int M, int MODE>
 static int launch_dump(ScanArgs a, hipStream_t st) {
-  if constexpr (!has_dump(M) || (is_sel16(MODE) && !has_sel16(M)) || (MODE == kDumpSel16W8 && RL > 2)) {
-    set_error("scan_packed (dump mode): not instantiated for n_subvectors=%d", M);
-    return TPQ_ERR_UNSUPPORTED;
+  if constexpr ((is_sel16(MODE) && !has_sel16(M)) || (MODE == kDumpF32 && !has_dump_f32(M)) ||
+                (MODE == kDumpSel16W8 && RL > 2)) {
+    return TPQ_ERR_UNSUPPORTED;  // (no message: scan.hip falls back to the sorted-list paths)
   } else {
     const size_t lds = scan_lds_bytes_dump(M, is_sel16(MODE), scan_waves(M, MODE), a.max_nprobe, fused_floats_of(a));
     int rc = set_lds(scan_packed_kernel<RL, M, false, MODE>, lds, "scan_packed_kernel (dump mode)");
@@ -117,19 +134,22 @@ static int launch_dump(ScanArgs a, hipStream_t st) {
                        ResidualArgs{}, delta_rel);
     TPQ_LAUNCH_CHECK("scan_packed_kernel (dump mode)");
     return launch_finish<(R < 2 ? 2 : R), M>(a, NW, RL, st);
-    return TPQ_OK;
   }
 }
+// TPQ_ERR_UNSUPPORTED without a launch = "no instantiation for these list registers": the caller (scan.hip) falls
+// through to the sorted-list paths instead of failing the search (the pairs below cover what
+// list_regs_scan / dump_finish_regs produce today; a change of either heuristic must not turn into an error)
 template <int M, int MODE>
 static int dispatch_dump_mode(const ScanArgs& a, int RL, int R, hipStream_t st) {
 #define TPQ_PAIR(A, B) if (RL == A && R == B) return launch_dump<A, B, M, MODE>(a, st);
   if constexpr (MODE == kDumpSel16W8) {
     TPQ_PAIR(1, 8) TPQ_PAIR(2, 8)
+  } else if constexpr (MODE == kDumpF32) {
+    TPQ_PAIR(1, 1) TPQ_PAIR(1, 2) TPQ_PAIR(2, 2) TPQ_PAIR(1, 4) TPQ_PAIR(2, 4) TPQ_PAIR(4, 4) TPQ_PAIR(2, 8) TPQ_PAIR(4, 8)
   } else {
     TPQ_PAIR(1, 1) TPQ_PAIR(1, 2) TPQ_PAIR(2, 2) TPQ_PAIR(1, 4) TPQ_PAIR(2, 4) TPQ_PAIR(2, 8) TPQ_PAIR(4, 8)
   }
 #undef TPQ_PAIR
-  set_error("scan_packed (dump mode): no instantiation for list registers (%d, %d)", RL, R);
   return TPQ_ERR_UNSUPPORTED;
 }
 
@@ -175,10 +195,32 @@ int TPQ_CAT(dispatch_pool_, TPQ_PACKED_M)(const ScanArgs& a, int RL, hipStream_t
   return TPQ_ERR_UNSUPPORTED;
 }
 
+// returns TPQ_ERR_UNSUPPORTED -- before anything was launched -- when (mode, RL, R) has no instantiation at this m
 int TPQ_CAT(dispatch_dump_, TPQ_PACKED_M)(const ScanArgs& a, int RL, int R, int mode, hipStream_t st) {
-  // (the fp32-table dump mode, kDumpF32, is not instantiated: the 16-bit table is the one in use)
   if (mode == kDumpSel16W8) return dispatch_dump_mode<TPQ_PACKED_M, kDumpSel16W8>(a, RL, R, st);
+  if (mode == kDumpF32) return dispatch_dump_mode<TPQ_PACKED_M, kDumpF32>(a, RL, R, st);
   return dispatch_dump_mode<TPQ_PACKED_M, kDumpSel16>(a, RL, R, st);
+}
+
+// workgroups of the dump-mode scan kernel (RL = 1, a 64-probe table, fused LUT at ds = 2) one CU holds; 0 = not built
+template <int M, int MODE>
+static int dump_occupancy_of() {
+  if constexpr ((is_sel16(MODE) && !has_sel16(M)) || (MODE == kDumpF32 && !has_dump_f32(M))) {
+    return 0;
+  } else {
+    constexpr int NW = scan_waves(M, MODE);
+    const size_t lds = scan_lds_bytes_dump(M, is_sel16(MODE), NW, 64, M * 2 + M);
+    int n = 0;
+    if (set_lds(scan_packed_kernel<1, M, false, MODE>, lds, "scan_packed_kernel (dump mode)") != TPQ_OK) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, scan_packed_kernel<1, M, false, MODE>, NW * 64, lds) != hipSuccess)
+      return 0;
+    return n;
+  }
+}
+int TPQ_CAT(dump_occupancy_, TPQ_PACKED_M)(int mode) {
+  if (mode == kDumpSel16W8) return dump_occupancy_of<TPQ_PACKED_M, kDumpSel16W8>();
+  if (mode == kDumpF32) return dump_occupancy_of<TPQ_PACKED_M, kDumpF32>();
+  return dump_occupancy_of<TPQ_PACKED_M, kDumpSel16>();
 }
 
 int TPQ_CAT(dispatch_packed_, TPQ_PACKED_M)(const ScanArgs& a, const ResidualArgs* ra, int RL, int R,

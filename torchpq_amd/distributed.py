@@ -37,10 +37,31 @@ class Groups:
         self.control, self.bulk, self.bulk_backend, self.bulk_error = control, bulk, bulk_backend, bulk_error
 
 
+def has_cpu_backend(group=None):
+    """does `group` (None = the default group) carry a CPU backend (gloo / mpi)?  A group made by
+    `init_process_group("nccl")` does not: CPU tensors -- and object collectives forced onto the CPU -- fail on it
+    with "No backend type associated with device type cpu"."""
+    try:
+        cfg = str(dist.get_backend_config(group)).lower()
+    except Exception:  # noqa: BLE001 -- older torch: the plain backend name
+        cfg = str(dist.get_backend(group)).lower()
+    return any(b in cfg for b in ("gloo", "mpi", "ucc"))
+
+
+def object_device(group=None):
+    """the `device=` of the metadata (object) collectives: the CPU wherever the group has a CPU backend -- the control
+    plane must not depend on a GPU transport --, None (torch picks the group's own device) on an NCCL-only group"""
+    return torch.device("cpu") if has_cpu_backend(group) else None
+
+
 def host_barrier(group=None):
-    """barrier on the control plane (a 1-element CPU all-reduce): callers synchronize their device first"""
-    t = torch.zeros(1, dtype=torch.int32)
-    dist.all_reduce(t, group=group)
+    """barrier on the control plane (a 1-element CPU all-reduce): callers synchronize their device first.
+    (`group`: Groups.control when init_groups had to bring its own gloo group; None = the default group)"""
+    if has_cpu_backend(group):
+        t = torch.zeros(1, dtype=torch.int32)
+        dist.all_reduce(t, group=group)
+    else:  # an NCCL-only group handed in by the caller: a device barrier is all there is
+        dist.barrier(group=group)
 
 
 def init_groups(device=None, want_rccl=True, timeout_s=300.0, probe=None, create=None):
@@ -48,12 +69,18 @@ def init_groups(device=None, want_rccl=True, timeout_s=300.0, probe=None, create
     and verified by `probe(group)` (default: an all-reduce of one int32 on the device).  Every rank learns
     whether ALL probes succeeded (a MIN over the control plane) -- a transport that fails on one rank only
     must not leave the others waiting inside a collective.  `create` / `probe` replace the group's
-    creation / its check (validation hooks of bench.py and the CPU tests)."""
+    creation / its check (validation hooks of bench.py and the CPU tests).  Called on an NCCL-only default
+    group (`init_process_group("nccl")`), it creates a gloo control group of its own: `Groups.control`."""
+    import time
     from datetime import timedelta
     to = timedelta(seconds=timeout_s)
     if not dist.is_initialized():
         dist.init_process_group("gloo", timeout=to)
     g = Groups(control=None)
+    if not has_cpu_backend(None):
+        # the caller initialised an NCCL-only default group (ADVICE r5): the control plane gets a gloo group of its
+        # own -- the MIN below and every host_barrier(g.control) are CPU collectives
+        g.control = dist.new_group(backend="gloo", timeout=to)
     if not want_rccl:
         return g
     err = None
@@ -64,9 +91,25 @@ def init_groups(device=None, want_rccl=True, timeout_s=300.0, probe=None, create
         else:
             bulk = dist.new_group(backend="nccl", timeout=to, device_id=torch.device(device))
         if probe is None:
+            # The probe runs on a SIDE stream and is awaited by polling an event against the deadline: a transport
+            # that never completes on this rank must not park the host inside synchronize() -- the rank would then
+            # miss the MIN below and its peers would wait there.  (A hung collective stays queued on the side
+            # stream, which nobody else uses; the group is not used again.  What remains: with the default
+            # TORCH_NCCL_ASYNC_ERROR_HANDLING the NCCL watchdog may still abort the process after `timeout_s` --
+            # the peers then see the control plane's own timeout, not a hang.)
+            side = torch.cuda.Stream(device=device)
+            done = torch.cuda.Event()
             t = torch.ones(1, dtype=torch.int32, device=device)
-            dist.all_reduce(t, group=bulk)
-            torch.cuda.synchronize(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                dist.all_reduce(t, group=bulk)
+                done.record(side)
+            deadline = time.monotonic() + timeout_s
+            while not done.query():
+                if time.monotonic() > deadline:
+                    raise RuntimeError(f"RCCL probe all-reduce did not complete within {timeout_s:.0f} s")
+                time.sleep(0.002)
+            torch.cuda.current_stream(device).wait_stream(side)
             if int(t.item()) != dist.get_world_size():
                 raise RuntimeError(f"RCCL probe all-reduce returned {int(t.item())}")
         else:
@@ -74,7 +117,7 @@ def init_groups(device=None, want_rccl=True, timeout_s=300.0, probe=None, create
     except Exception as e:  # noqa: BLE001 -- any transport error: fall back, keep the message
         err = f"{type(e).__name__}: {e}"[:300]
     ok = torch.tensor([0 if err else 1], dtype=torch.int32)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=g.control)
     if int(ok.item()) == 1:
         g.bulk, g.bulk_backend = bulk, "nccl"
     else:
@@ -101,7 +144,7 @@ def broadcast_state(state, src=0, device=None, group=None, bulk_group=None, chun
     if rank == src:
         meta[0] = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in state.items()
                    if v is not None]
-    dist.broadcast_object_list(meta, src=src, group=group, device=torch.device("cpu"))
+    dist.broadcast_object_list(meta, src=src, group=group, device=object_device(group))
     data_group = bulk_group if bulk_group is not None else group
     out = {}
     for name, shape, dtype in meta[0]:
@@ -134,7 +177,7 @@ def replicate_index(index, src=0, group=None, bulk_group=None, chunk_bytes=1 << 
     if dist.get_rank(group) == src:
         extra[0] = {"n_probe": index.n_probe, "use_smart_probing": index.use_smart_probing,
                     "smart_probing_temperature": index._smart_probing_temperature}
-    dist.broadcast_object_list(extra, src=src, group=group, device=torch.device("cpu"))
+    dist.broadcast_object_list(extra, src=src, group=group, device=object_device(group))
     if dist.get_rank(group) != src:
         index.load_state_dict(sd)
     index.n_probe = extra[0]["n_probe"]

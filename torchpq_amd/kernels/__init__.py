@@ -52,6 +52,7 @@ class IVFPQTopkHip:
         self._ticket_cache = {}
         self.keep_workspace = False   # diagnostics: keep the last call's workspace in `last_workspace`
         self.last_workspace = None
+        self.last_call = None         # diagnostics: the arguments of the last topk / topk_fused call (`last_route()`)
 
     def _tickets(self, n_query, n_split, device):
         """zeroed int32 [>= n_query] for this (device, current stream), or None (unsplit queries need none;
@@ -81,13 +82,36 @@ class IVFPQTopkHip:
         self._ticket_cache.pop((dev.index, torch.cuda.current_stream(dev).cuda_stream), None)
 
     def last_redone(self, n_query):
-        """diagnostics (synchronises; needs keep_workspace): queries of the last one-launch scan that took the
-        in-kernel exact redo (ws_delta[q] == 1, csrc/scan_device.h)"""
+        """diagnostics (synchronises; needs keep_workspace): queries of the last packed scan that were redone exactly --
+        by the one-launch finisher's own redo branch (ws_delta[q] == 1) or, on the routes that end with the flag-gated
+        exact kernel (the large-batch route over the 16-bit table, the pools, the three-launch path: ws_delta holds a
+        selection band there), by that kernel, which leaves kRedoneMark = -1 (csrc/scan_device.h)"""
         ws = self.last_workspace
         if ws is None:
             return None
         off = (n_query * 4 + 255) // 256 * 256
-        return int((ws[off:off + 4 * n_query].view(torch.float32) == 1.0).sum().item())
+        d = ws[off:off + 4 * n_query].view(torch.float32)
+        return int(((d == 1.0) | (d == -1.0)).sum().item())
+
+    ROUTES = {0: "reference_layout", 1: "one_launch_finish", 2: "sorted_lists", 3: "pools", 8: "dump_f32",
+              16: "dump_sel16", 17: "dump_sel16_w8", -1: "rejected"}
+
+    def route(self, n_query, k, n_split=1, ds=0, n_probe=1, slots_hint=None, has_lut=True, packed=True,
+              tickets=None, residual=False):
+        """diagnostics: the kernels a call with these arguments runs (tpq_ivfpq_scan_route: the library's own rule,
+        nothing is launched) -- one of ROUTES' names.  `tickets` defaults to what topk / topk_fused pass: the cached
+        buffer of a split query outside a stream capture."""
+        if tickets is None:
+            tickets = n_split > 1
+        code = load().tpq_ivfpq_scan_route(int(n_query), int(k), int(n_split), self.m, int(ds), int(n_probe),
+                                            int(slots_hint or 0), int(bool(has_lut)),
+                                            int(bool(packed) and self.m in PACKED_M), int(bool(tickets)),
+                                            int(bool(residual)))
+        return self.ROUTES.get(code, str(code))
+
+    def last_route(self):
+        """diagnostics: route(...) of the last topk / topk_fused call"""
+        return None if self.last_call is None else self.route(**self.last_call)
 
     def _n_split(self, n_query, device, slots_hint=None):
         """Workgroups per query so that small batches still fill the chip (256 CUs x 2).
@@ -149,6 +173,8 @@ class IVFPQTopkHip:
         if n_split is None:
             n_split = self._n_split(n_query, device, slots_hint)
         self.last_n_split = n_split  # diagnostics / tests: workgroups per query of the last call
+        self.last_call = dict(n_query=n_query, k=k, n_split=n_split, ds=0, n_probe=n_probe, slots_hint=slots_hint,
+                              has_lut=True, packed=packed is not None)
         ws_bytes = lib.tpq_ivfpq_scan_workspace_bytes(n_query, k, n_split, self.m)
         ws = torch.empty(max(ws_bytes, 1), device=device, dtype=torch.uint8) if ws_bytes else None
         ev = None
@@ -211,6 +237,8 @@ class IVFPQTopkHip:
         if n_split is None:
             n_split = self._n_split(n_query, device, slots_hint)
         self.last_n_split = n_split  # diagnostics / tests: workgroups per query of the last call
+        self.last_call = dict(n_query=n_query, k=k, n_split=n_split, ds=ds, n_probe=n_probe, slots_hint=slots_hint,
+                              has_lut=False, packed=packed is not None)
         ws_bytes = lib.tpq_ivfpq_scan_workspace_bytes(n_query, k, n_split, self.m)
         ws = torch.empty(max(ws_bytes, 1), device=device, dtype=torch.uint8)
         metric = _lib.METRIC_NEG_SQ_L2 if distance == "euclidean" else _lib.METRIC_INNER
@@ -335,6 +363,10 @@ class IVFPQTopkHip:
                 ptr(cell_start), ptr(cell_size), ptr(n_probe_list), ptr(values), ptr(address),
                 ptr(address2id), ptr(ids), n_data, n_query, n_probe, self.m, k, n_split, ptr(ws),
                 ws_bytes, stream_ptr(device)), "tpq_ivfpq_scan_topk_residual_packed")
+        if self.keep_workspace:
+            self.last_workspace = ws
+        self.last_call = dict(n_query=n_query, k=k, n_split=n_split, ds=ds, n_probe=n_probe, slots_hint=slots_hint,
+                              has_lut=part1 is not None, packed=True, residual=True)
         if ev is not None:
             ev[1].record(torch.cuda.current_stream(device))
             self.record_events.append(ev)
