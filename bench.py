@@ -367,7 +367,7 @@ def attach_traffic(roofline, name):
 TRAFFIC_PASS = {"enabled": True}
 
 
-def pmc_traffic(child_args, kernel_filter, timeout_s=240):
+def pmc_traffic(child_args, kernel_filter, timeout_s=240, grid_threads=None):
     """HBM-side read bytes per launch of `kernel_filter`, measured IN THIS RUN: the same workload once more in a
     child process under `rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum` (a counter pass of its own: PMC
     collection serialises the kernels and cannot share a process with the timed region), corrected as
@@ -407,6 +407,10 @@ def pmc_traffic(child_args, kernel_filter, timeout_s=240):
         for f in glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 if kernel_filter in r["Kernel_Name"]:
+                    # (`grid_threads`: only the launches of that many threads -- the child of the 100 M-slot record
+                    # also runs the cold variant through the same kernel, 2 048 workgroups instead of 10 000)
+                    if grid_threads is not None and int(r.get("Grid_Size", -1)) != grid_threads:
+                        continue
                     if r["Counter_Name"] == "FETCH_SIZE":
                         fetch.append(float(r["Counter_Value"]))
                     elif r["Counter_Name"] == "TCC_EA0_RDREQ_sum":
@@ -424,9 +428,9 @@ def pmc_traffic(child_args, kernel_filter, timeout_s=240):
         shutil.rmtree(td, ignore_errors=True)
 
 
-def measured_traffic(roofline, child_args, kernel_filter):
+def measured_traffic(roofline, child_args, kernel_filter, grid_threads=None):
     """roofline["traffic"] from this run's own counter pass; True when it was attached"""
-    t = pmc_traffic(child_args, kernel_filter)
+    t = pmc_traffic(child_args, kernel_filter, grid_threads=grid_threads)
     if not t:
         return False
     algo = roofline.get("algorithmic_bytes_per_launch")
@@ -669,15 +673,19 @@ def secondary_c4(device, stream_peak, steps=5):
     return rec
 
 
+C4_COLD_QUERIES = 2048  # (two rounds of the chip's 1 024 workgroup slots: 1 024 x 16 / 2 048 x 8 / 4 096 x 4 / 8 192 x 2
+#                          measured 5.19 / 5.49 / 5.40 / 5.05 TB/s on one box, tools/ab_stream.py)
+
+
 def c4_cold_variant(idx, device, stream_peak, k, steps, host):
     """how much of the 100 M-slot scan's rate is DRAM?  In the timed batch each cell is probed by ~39 of
     the 10 000 queries, and re-reads that land within the Infinity Cache's reach are counted by FETCH_SIZE like DRAM
-    reads.  Here the SAME index is searched with the 16 384 cells dealt to 1 024 queries, 16 each, every cell exactly once
+    reads.  Here the SAME index is searched with the 16 384 cells dealt to 2 048 queries, 8 each, every cell exactly once
     (a random permutation): each of the 6.4 GB of code bytes is read ONCE per launch, 25 x the Infinity Cache apart -- what
-    this runs at is DRAM.  1 024 queries take the large-batch route the headline takes (four-wave workgroups, 16-bit
+    this runs at is DRAM.  2 048 queries take the large-batch route the headline takes (four-wave workgroups, 16-bit
     selection table, finish kernel)."""
     n_cells, m = idx.n_cells, idx.n_subvectors
-    nq, n_probe = 1024, n_cells // 1024
+    nq, n_probe = C4_COLD_QUERIES, n_cells // C4_COLD_QUERIES
     g = torch.Generator(device=device)
     g.manual_seed(977)
     cells = torch.randperm(n_cells, generator=g, device=device).view(nq, n_probe).contiguous()
@@ -1077,6 +1085,15 @@ def secondary_pass(device, budget_s, only=None, skip=(), stream_peak=None):
             counted = prefix or {"c5": "coarse_kernel", "wide": "gemm_kernel<false"}.get(name)
             if name in ("residual", "flat"):
                 pass  # (time-boxed records without a counter pass: `traffic` stays null)
+            elif name == "c4":
+                # the timed batch (10 000 four-wave workgroups) and the cold variant (2 048) run the same kernel: one
+                # counter pass each, told apart by the launch's thread count
+                if not measured_traffic(out[name]["roofline"], ["--secondary-only", name], counted,
+                                        grid_threads=10000 * 256):
+                    attach_traffic(out[name]["roofline"], name)
+                cold = out[name].get("cold", {}).get("roofline")
+                if cold is not None:
+                    measured_traffic(cold, ["--secondary-only", name], counted, grid_threads=C4_COLD_QUERIES * 256)
             elif not (counted and measured_traffic(out[name]["roofline"], ["--secondary-only", name], counted)):
                 attach_traffic(out[name]["roofline"], name)
             if prefix:

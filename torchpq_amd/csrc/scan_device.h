@@ -505,22 +505,25 @@ __device__ __forceinline__ void stage_lut_blocked(const ScanArgs& a, int q, floa
     const float mx = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
     atomicMax(&jmax[j], __float_as_uint(mx));
   };
-  if (!part1 && !a.lut && a.ds <= 2) {
-    // fused table, short sub-vectors: a thread's entries come from 2 ds codebook loads each, and a plain loop
-    // pays one L2 round trip per entry (8 entries per thread at m = 64: 4.6 of the 23 us a single-query
-    // workgroup lives; 8.5 us when 512 workgroups stage at once).  All loads of U entries are issued first.
+  constexpr int DSM = M <= 32 ? 4 : 2;  // (m = 64 keeps 2 x 4 loads in flight: its eight-wave kernels sit at the VGPR cap)
+  if (!part1 && !a.lut && a.ds <= DSM) {
+    // fused table, short sub-vectors: a thread's entries come from ds codebook loads each, and a plain loop
+    // pays one L2 round trip per entry group (8 groups per thread at m = 64: 4.6 of the 23 us a single-query
+    // workgroup lives; 8.5 us when 512 workgroups stage at once).  All loads of U entry groups are issued first.
+    // (round 6: ds = 3, 4 too -- SIFT's m = 32 walked its 8 groups per thread one round trip at a time: 14.2 of the
+    // 15.5 us a workgroup of the reference grid's IVF4096 x 32 probes spent before its first tile)
     constexpr int U = TPQ_LUT_U;
     const int ds = a.ds;
     for (int i0 = threadIdx.x; i0 < m * 64; i0 += U * n_threads) {
-      float4 y[U][2];
+      float4 y[U][DSM];
       int j[U], c4[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int i = i0 + u * n_threads;
         place(i < m * 64 ? i : i0, j[u], c4[u]);
         const float4* __restrict__ cb = reinterpret_cast<const float4*>(a.codebook) + (int64_t)j[u] * ds * 64 + c4[u];
-        y[u][0] = cb[0];
-        y[u][1] = ds > 1 ? cb[64] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int e = 0; e < DSM; ++e) y[u][e] = e < ds ? cb[e * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -528,7 +531,7 @@ __device__ __forceinline__ void stage_lut_blocked(const ScanArgs& a, int q, floa
         float4 dot = make_float4(0.f, 0.f, 0.f, 0.f), c2 = dot;
         float q2 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < DSM; ++e) {
           if (e >= ds) break;
           const float4 yy = y[u][e];
           const float x = xq[j[u] * ds + e];
@@ -695,7 +698,7 @@ __device__ __forceinline__ float exact_lane(const typename scan_layout::Layout<M
 // ---- the 16-bit selection table ("sel16") -------------------------------------------------------------
 // T[j][c] = round((LUT[j][c] + A_j) * inv), A_j = max_c |LUT[j][c]|, inv = 65535 / (2 max_j A_j): u16, laid out by
 // scan_layout::lut16_halfword.  F(slot) = sum_j T[j][code_j] is an EXACT integer (< 2^24: carried as a float), and
-// |F - (e_real + sum_j A_j) * inv| <= 0.51 m + 1 (per entry: the two fp32 roundings of (x + A_j) * inv, 0.008, and the
+// |F - (e_real + sum_j A_j) * inv| <= 0.51 m + 1 (per entry: the fp32 roundings of x * inv + (A_j * inv + 0.5), 0.008, and the
 // rounding to an integer, 0.5; + 1 for the rounding of inv itself), so the selection band of the fp32 fast value
 // carries over with delta = (0.51 m + 1) + (m - 1) u sum_j A_j * inv units.  Half the LDS of the fp32 table: four
 // workgroups per CU at m = 64 instead of two.
@@ -789,8 +792,12 @@ __device__ __forceinline__ void lut16_store(const float4 (&ent)[M * 64 / NT], co
     const int g = i >> 6, r = i & 63;
     const int j = (g % jblocks) * JB + (r & (JB - 1));
     const int c = ((g / jblocks) * CB + (r >> JS)) * 4;
-    const float off = __uint_as_float(jmax[j]);
-    auto qz = [&](float x) -> uint16_t { return (uint16_t)(unsigned)fminf((x + off) * inv + 0.5f, 65535.f); };
+    // T = trunc(x * inv + (A_j * inv + 0.5)): ONE fma per entry (round 6; it was add, multiply, add, min -- the scan is
+    // VALU-issue-bound).  |x| <= A_j, so the real value lies in [0.5, 65535.5]; roundings: the fma's (half an
+    // ulp at < 2^16: 2^-8) and the constant's two (2^-9 each) -- the 0.008 the band's 0.51 per entry allows for; the
+    // truncation of a value in (0.49, 65535.51) needs no clamp.
+    const float k0 = __uint_as_float(jmax[j]) * inv + 0.5f;
+    auto qz = [&](float x) -> uint16_t { return (uint16_t)(unsigned)fmaf(x, inv, k0); };
     lut16[scan_layout::lut16_halfword(M, j, c + 0)] = qz(ent[u].x);
     lut16[scan_layout::lut16_halfword(M, j, c + 1)] = qz(ent[u].y);
     lut16[scan_layout::lut16_halfword(M, j, c + 2)] = qz(ent[u].z);
@@ -1011,12 +1018,15 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
   TPQ_PROF(a, blockIdx.x, 1);
   const float* part1 = RES ? ra.part1 : nullptr;
   if (!a.lut && !part1) stage_query(a, q, xq, NW * 64);
+  TPQ_PROF(a, blockIdx.x, 10);  // (dump modes: sub-phases of the prologue, slots 10 ... 14)
   [[maybe_unused]] float inv16 = 0.f;  // SEL16: table units per unit of value
   if constexpr (SEL16) {
     float4 ent[M * 64 / (NW * 64)];
     lut16_compute<M, NW * 64>(a, q, xq, jmax, ent);
+    TPQ_PROF(a, blockIdx.x, 11);
     if (wave == 0) build_probe_table(a, q, n_probe, tab, packed_tile_shift(M), &probes0);
     __syncthreads();
+    TPQ_PROF(a, blockIdx.x, 12);
     unsigned jb = 0u;
     float sum = 0.f;
 #pragma unroll
@@ -1040,9 +1050,12 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
     if (!scalable) return;  // (workgroup-uniform: every wave reduced the same words)
     inv16 = 65535.f / (2.f * J);
     lut16_store<M, NW * 64>(ent, jmax, inv16, reinterpret_cast<uint16_t*>(lut));
+    TPQ_PROF(a, blockIdx.x, 13);
   } else {
     stage_lut_blocked<M>(a, q, lut, NW * 64, jmax, xq, part1);
+    TPQ_PROF(a, blockIdx.x, 11);
     if (wave == 0) build_probe_table(a, q, n_probe, tab, packed_tile_shift(M), &probes0);
+    TPQ_PROF(a, blockIdx.x, 13);
   }
   float probe_mx = 0.f;
   if constexpr (RES) {
@@ -1173,6 +1186,9 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
         m0 = locate(T);
         if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
       }
+#ifdef TPQ_SCAN_PROFILE
+      bool first_tile = true;
+#endif
       while (T < t_end) {
         int Tn = T + NW;
         if (Tn < t_end) {
@@ -1180,6 +1196,10 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
           if (m1.valid) L::load(a.packed, a.n_slots, m1.s, w1);
         }
         consume(w0, m0);
+#ifdef TPQ_SCAN_PROFILE
+        if (first_tile) TPQ_PROF(a, blockIdx.x, 14);
+        first_tile = false;
+#endif
         T = Tn;
         if (T >= t_end) break;
         Tn = T + NW;

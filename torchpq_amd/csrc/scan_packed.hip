@@ -112,6 +112,12 @@ static int launch_finish(const ScanArgs& a, int nw_scan, int RL, hipStream_t st)
         return T <= 4 ? go(scan_finish_exact_kernel<RM, M, 0, 4, true>)
                       : (T <= 8 ? go(scan_finish_exact_kernel<RM, M, 0, 8, true>)
                                 : go(scan_finish_exact_kernel<RM, M, 0, 16, true>));
+      // (the sub-vector length of a 128-dimensional index compiled in: SIFT's m = 32 -> ds = 4; others read it)
+      constexpr int DSF = 128 / M;
+      if (a.ds == DSF)
+        return T <= 4 ? go(scan_finish_exact_kernel<RM, M, DSF, 4>)
+                      : (T <= 8 ? go(scan_finish_exact_kernel<RM, M, DSF, 8>)
+                                : go(scan_finish_exact_kernel<RM, M, DSF, 16>));
       return T <= 4 ? go(scan_finish_exact_kernel<RM, M, 0, 4>)
                     : (T <= 8 ? go(scan_finish_exact_kernel<RM, M, 0, 8>) : go(scan_finish_exact_kernel<RM, M, 0, 16>));
     }
