@@ -63,7 +63,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix-core peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix-core peak (MI355X_MICROARCH.md; not the 2:1-sparsity figure)
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 
 
 # ---------------------------------------------------------------------------------------------
@@ -650,6 +650,9 @@ def secondary_c4(device, stream_peak, steps=5):
     g = torch.Generator(device=device)
     g.manual_seed(4236)
     queries = torch.randn(d, nq, generator=g, device=device)
+    if C4_VARIANT["mode"] == "cold":  # (profiling / counter passes of the cold variant alone)
+        return {"workload": "the cold variant of configs[3] alone", "cold": c4_cold_variant(idx, device, stream_peak, k, steps, {}),
+                "roofline": {}}
     dt, scan_ms, nb, vals, ids, stats = time_search(idx, queries, k, steps, 1)
     algo = scanned_bytes(idx, queries, m)
     host = {}
@@ -661,6 +664,8 @@ def secondary_c4(device, stream_peak, steps=5):
                                     "16-bit selection table) + scan_finish_exact_kernel; kernel_ms brackets both",
                                     stream_peak, resident_bytes=idx._storage.numel(), stats=stats,
                                     launches_per_step=nb, bytes_per_query=round(algo / nq, 1))}
+    if C4_VARIANT["mode"] == "warm":  # (profiling / counter passes: per-kernel averages of the timed batch alone)
+        return rec
     try:
         rec["cold"] = c4_cold_variant(idx, device, stream_peak, k, steps, host)
         rec["roofline"]["dram_frac"] = rec["cold"]["roofline"]["frac"]
@@ -673,6 +678,7 @@ def secondary_c4(device, stream_peak, steps=5):
     return rec
 
 
+C4_VARIANT = {"mode": "both"}   # --c4-variant: "warm" / "cold" run one half of the record (profiles, counter passes)
 C4_COLD_QUERIES = 2048  # (two rounds of the chip's 1 024 workgroup slots: 1 024 x 16 / 2 048 x 8 / 4 096 x 4 / 8 192 x 2
 #                          measured 5.19 / 5.49 / 5.40 / 5.05 TB/s on one box, tools/ab_stream.py)
 
@@ -1088,12 +1094,13 @@ def secondary_pass(device, budget_s, only=None, skip=(), stream_peak=None):
             elif name == "c4":
                 # the timed batch (10 000 four-wave workgroups) and the cold variant (2 048) run the same kernel: one
                 # counter pass each, told apart by the launch's thread count
-                if not measured_traffic(out[name]["roofline"], ["--secondary-only", name], counted,
+                if not measured_traffic(out[name]["roofline"], ["--secondary-only", name, "--c4-variant", "warm"], counted,
                                         grid_threads=10000 * 256):
                     attach_traffic(out[name]["roofline"], name)
                 cold = out[name].get("cold", {}).get("roofline")
-                if cold is not None:
-                    measured_traffic(cold, ["--secondary-only", name], counted, grid_threads=C4_COLD_QUERIES * 256)
+                if cold is not None and C4_VARIANT["mode"] == "both":
+                    measured_traffic(cold, ["--secondary-only", name, "--c4-variant", "cold"], counted,
+                                     grid_threads=C4_COLD_QUERIES * 256)
             elif not (counted and measured_traffic(out[name]["roofline"], ["--secondary-only", name], counted)):
                 attach_traffic(out[name]["roofline"], name)
             if prefix:
@@ -1160,6 +1167,8 @@ def parse_args(argv=None):
                     help="do not run the rocprofv3 --pmc child pass that measures `traffic` in this run")
     ap.add_argument("--secondary-only", default=None, help="comma list of c1,c3,c4,c5,wide,residual,flat (profiling)")
     ap.add_argument("--secondary-budget", type=float, default=150.0)
+    ap.add_argument("--c4-variant", choices=["both", "warm", "cold"], default="both",
+                    help="--secondary-only c4: the timed batch, the cold variant, or both (profiles / counter passes)")
     ap.add_argument("--dist-timeout", type=float, default=300.0,
                     help="N > 1: timeout of the process groups (rendezvous, RCCL probe, broadcast)")
     ap.add_argument("--deadline", type=float, default=900.0,
@@ -1167,6 +1176,7 @@ def parse_args(argv=None):
     args = ap.parse_args(argv)
     if args.no_traffic_pass:
         TRAFFIC_PASS["enabled"] = False
+    C4_VARIANT["mode"] = args.c4_variant
     c4 = args.workload == "c4"
     args.n_base = args.n_base or (100_000_000 if c4 else 1_000_000)
     args.n_cells = args.n_cells or (16384 if c4 else 1024)

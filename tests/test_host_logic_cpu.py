@@ -203,6 +203,7 @@ def test_scan_route_rules():
     assert r(64, 10000, 100, hint=32 * 977) == "dump_sel16"
     assert r(64, 10000, 100, n_probe=64, hint=64 * 6103) == "dump_sel16"
     assert r(64, 10000, 300, hint=32 * 977) == "dump_sel16_w8"      # k in (248, 504] on long cells: eight waves
+    assert r(64, 10000, 500, hint=32 * 977) == "dump_sel16_w8"      # round 6: the finish kernel's exact list of 1 024
     assert r(64, 10000, 600) == "pools"
     assert r(64, 1023, 100) == "one_launch_finish"                  # below the route's batch size
     assert r(64, 10000, 100, has_lut=True) == "one_launch_finish"   # m = 64 needs query + codebook for the finish

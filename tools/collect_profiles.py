@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
-    for w in ("c2", "c3", "c4", "c5", "wide"):
+    for w in ("c2", "c3", "c4", "c4cold", "c5", "wide"):
         src = os.path.join(ROOT, "gpurun_out", tag, w)
         if not os.path.isdir(src):
             continue

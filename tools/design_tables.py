@@ -48,9 +48,13 @@ def driver_table(tag):
                    f"{rng([r.get('queries_redone_exactly') for r in rf], '{:d}')} | {chk} |")
 
     scan_row("**C2** headline (configs[1])", lambda r: r)
-    for k, label in (("c3", "C3 GIST shape (configs[2])"), ("c4", "C4 100 M slots (configs[3], one GPU)")):
+    for k, label in (("c3", "C3 GIST shape (configs[2])"), ("c4", "C4 100 M slots (configs[3], one GPU), the timed batch")):
         if all(k in r.get("secondary", {}) and "roofline" in r["secondary"][k] for r in runs):
             scan_row(label, lambda r, k=k: r["secondary"][k])
+    if all("roofline" in r.get("secondary", {}).get("c4", {}).get("cold", {}) for r in runs):
+        scan_row("C4 COLD: every cell probed once per launch (the DRAM figure)", lambda r: r["secondary"]["c4"]["cold"])
+    if all("roofline" in r.get("secondary", {}).get("residual", {}) for r in runs):
+        scan_row("residual PQ at the C2 shape (SURVEY 8f-3; (m + 4) B per slot)", lambda r: r["secondary"]["residual"])
     c5 = [r["secondary"]["c5"] for r in runs if "c5" in r.get("secondary", {}) and "iter_ms" in r["secondary"]["c5"]]
     if c5:
         out.append(f"| C5 Lloyd iteration (configs[4]) | iteration {rng([c['iter_ms'] for c in c5])} ms = assign "
@@ -72,7 +76,30 @@ def driver_table(tag):
                    f"{c['cpu']['add_s']} s, search {c['cpu']['search_queries_per_s']:.0f} q/s; the same index on the GPU: "
                    f"{rng([x['gpu']['search_queries_per_s'] / 1e6 for x in c1])} M q/s | — | — | — | — | — | — | ids equal "
                    f"{c['ids_equal_to_oracle']}, values within {c['values_max_rel_diff_vs_oracle']:.1e} |")
+    fl = [r["secondary"]["flat"] for r in runs if "value" in r.get("secondary", {}).get("flat", {})]
+    if fl:
+        out.append(f"| FlatIndex exact search, 1 M x 128, 1 000 queries (SURVEY 8f-4) | {rng([f['value'] / 1e3 for f in fl], '{:.1f}')} k q/s | "
+                   f"{rng([f['roofline']['kernel_ms'] for f in fl])} (whole search()) | "
+                   f"{rng([f['roofline']['achieved'] / 1e3 for f in fl])} TB/s of the sims matrix written + read | "
+                   f"{rng([f['roofline']['frac'] for f in fl], '{:.3f}')} | — | — | — | top-k overlap with float64 brute force "
+                   f"{rng([f['oracle_check']['top_k_overlap_with_float64_brute_force'] for f in fl], '{:.4f}')} |")
     r0 = runs[0]
+
+    def checks(r):
+        rows = [("C2", r.get("oracle_check"))]
+        sec = r.get("secondary", {})
+        rows += [(k, sec.get(k, {}).get("oracle_check")) for k in ("c3", "c4", "residual")]
+        rows.append(("c4 cold", sec.get("c4", {}).get("cold", {}).get("oracle_check")))
+        return [(k, c) for k, c in rows if c]
+    out += ["", "Oracle check ON the record (rows of the timed search() call vs the C oracle on the GPU's probed cells; run 1): " +
+            "; ".join(f"{k}: {c['queries_checked']} rows, ids equal {c['ids_equal_to_oracle']}, values bit-equal "
+                      f"{c['values_bit_equal']}" + (f", addresses beyond 2^24: {c['addresses_beyond_2p24']}"
+                                                     if c.get("addresses_beyond_2p24") else "")
+                      for k, c in checks(r0)) + "."]
+    sp = r0["secondary"]["stream_peak"]
+    if "settings_GBps" in sp:
+        out += ["", "Stream-read settings of run 1 (8 GiB read once per launch, TB/s): " +
+                "; ".join(f"{k}: {v / 1e3:.2f}" for k, v in sp["settings_GBps"].items()) + "."]
     out += ["", f"Stream peak of the box (8 GiB, dwordx4): {rng([r['secondary']['stream_peak']['value'] / 1e3 for r in runs])} "
             f"TB/s. CPU baseline (oracle, {r0['cpu_baseline']['cores']} threads, {r0['cpu_baseline']['sample'].split(',')[0]}): "
             f"{rng([r['cpu_baseline']['value'] for r in runs], '{:.0f}')} q/s, split {r0['cpu_baseline']['split_s']}. "
@@ -82,7 +109,7 @@ def driver_table(tag):
     return "\n".join(out)
 
 
-def grid_table(tag, prev="r04"):
+def grid_table(tag, prev="r05"):
     g = json.load(open(os.path.join(P, f"{tag}_reference_grid.json")))
     t = {(p["m"], p["n_cells"], p["n_probe"]): p for p in g["points"] if p["k"] == 100}
     t4 = {}
@@ -137,10 +164,28 @@ def sweeps(tag):
     return "\n\n".join(out)
 
 
+def counters(tag):
+    f = os.path.join(P, f"{tag}_scan_counters.jsonl")
+    if not os.path.exists(f):
+        return ""
+    rows = [json.loads(l) for l in open(f) if l.startswith("{")]
+    out = ["What bounds the scan (`tools/scan_counters.sh`: rocprofv3 --pmc, counters only; 10 000 queries, 32 probes, k = 100):", "",
+           "| m, cells x slots | kernels (us) | VALU instructions per query | per code byte | VALU issue share | LDS instructions "
+           "per query | wave cycles waiting | LDS conflict / active |", "|---|---|---|---|---|---|---|---|"]
+    for r in rows:
+        ks = ", ".join(f"{k.split('<')[0].replace('scan_', '')} {v}" for k, v in r["kernels_us"].items())
+        out.append(f"| {r['m']}, {r['n_cells']} x {r['cell_slots']} | {ks} | {r['valu_instructions_per_query']} | "
+                   f"{r['valu_instructions_per_code_byte']} | **{r['valu_issue_share']:.2f}** | {r['lds_instructions_per_query']} | "
+                   f"{r['wait_any_share_of_wave_cycles']:.2f} | {r['lds_bank_conflict_over_active']:.2f} |")
+    return "\n".join(out)
+
+
 if __name__ == "__main__":
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
     print(driver_table(tag))
     print()
     print(grid_table(tag))
     print()
     print(sweeps(tag))
+    print()
+    print(counters(tag))

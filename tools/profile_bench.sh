@@ -20,7 +20,8 @@ for W in $WORKLOADS; do
   case "$W" in
     c2) BENCH="python ${ROOT}/bench.py --steps 20 --warmup 3 --no-secondary --no-traffic-pass"; KERNEL="scan_packed_kernel";;
     c3) BENCH="python ${ROOT}/bench.py --secondary-only c3 --no-traffic-pass"; KERNEL="scan_packed_kernel";;
-    c4) BENCH="python ${ROOT}/bench.py --secondary-only c4 --no-traffic-pass"; KERNEL="scan_packed_kernel";;
+    c4) BENCH="python ${ROOT}/bench.py --secondary-only c4 --c4-variant warm --no-traffic-pass"; KERNEL="scan_packed_kernel";;
+    c4cold) BENCH="python ${ROOT}/bench.py --secondary-only c4 --c4-variant cold --no-traffic-pass"; KERNEL="scan_packed_kernel";;
     c5) BENCH="python ${ROOT}/bench.py --secondary-only c5 --no-traffic-pass"; KERNEL="coarse_kernel";;
     wide) BENCH="python ${ROOT}/bench.py --secondary-only wide --no-traffic-pass"; KERNEL="gemm_kernel";;
   esac
@@ -29,7 +30,8 @@ for W in $WORKLOADS; do
   ALGO=$(python - "$OUT/bench.json" "$W" <<'PY'
 import json, sys
 j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
-r = j["roofline"] if sys.argv[2] == "c2" else j["secondary"][sys.argv[2]]["roofline"]
+w = sys.argv[2]
+r = j["roofline"] if w == "c2" else (j["secondary"]["c4"]["cold"]["roofline"] if w == "c4cold" else j["secondary"][w]["roofline"])
 print(r.get("algorithmic_bytes_per_launch", r.get("algorithmic_flops_per_launch", 0)))
 PY
 )

@@ -1,14 +1,14 @@
 #!/bin/bash
 # Everything DESIGN section 4 quotes for a round, in one gpurun call (writes under gpurun_out/<tag>_* and copies the judged
 # artefacts into profiles/ on the box -- they come back under gpurun_out/profiles_<tag>/; cp them into profiles/):
-#   bash tools/round_profiles.sh r05
-TAG="${1:-r05}"
+#   bash tools/round_profiles.sh r06
+TAG="${1:-r06}"
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 OUT="$ROOT/gpurun_out"
 mkdir -p "$OUT"
 cd "$ROOT"
 # 1. per workload: plain run, rocprofv3 --kernel-trace --stats, separate --pmc passes, summary
-bash tools/profile_bench.sh "$TAG" c2 c3 c4 c5 wide > "$OUT/${TAG}_profile_bench.log" 2>&1
+bash tools/profile_bench.sh "$TAG" c2 c3 c4 c4cold c5 wide > "$OUT/${TAG}_profile_bench.log" 2>&1
 python tools/collect_profiles.py "$TAG" >> "$OUT/${TAG}_profile_bench.log" 2>&1
 # 2. the DRIVER's command, three times, with those summaries in place (its lines carry kernel_ms_profile /
 #    profile_mismatch against them, and the traffic of their own counter pass)
@@ -36,10 +36,28 @@ python tools/probe_bench.py --n-cells 1024,4096,16384 --n-probe 1,16,32,64,128 >
 python tools/selection_soak.py --mode probe --cases 240 --seed 11 --big > "$OUT/${TAG}_soak_probe.json" 2>/dev/null
 python tools/selection_soak.py --mode cascade --cases 120 --seed 12 > "$OUT/${TAG}_soak_cascade.json" 2>/dev/null
 python tools/build_100m.py > "$OUT/${TAG}_build_100m.json" 2> /dev/null
+# round 6: what bounds the scan (counters), the prologue's phases (a -DTPQ_SCAN_PROFILE variant, when one was built:
+# tools/build_variant.sh prof "-DTPQ_SCAN_PROFILE" scan scan_packed_64 scan_packed_32), the batch-size breakdown
+bash tools/scan_counters.sh > "$OUT/${TAG}_scan_counters.jsonl" 2> /dev/null
+if [ -f torchpq_amd/variants/libtorchpq_amd_prof.so ]; then
+  {
+    export TPQ_AMD_LIB=$PWD/torchpq_amd/variants/libtorchpq_amd_prof.so
+    P="python tools/scan_phase_profile.py --fused"
+    $P --m 64 --ds 2 --n-cells 16384 --cell 61 --n-probe 32
+    $P --m 64 --ds 2 --n-cells 16384 --cell 61 --n-probe 8
+    $P --m 64 --ds 2 --n-cells 4096 --cell 244 --n-probe 32
+    $P --m 64 --ds 2 --n-cells 1024 --cell 977 --n-probe 32
+    $P --m 32 --ds 4 --n-cells 4096 --cell 244 --n-probe 32
+    unset TPQ_AMD_LIB
+  } 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_scan_phases.txt"
+fi
+python tools/batch_breakdown.py 2>/dev/null | grep '^{' > "$OUT/${TAG}_batch_breakdown.jsonl"
+python tools/ab_stream.py 2>/dev/null | grep '^{' > "$OUT/${TAG}_stream_regimes.json"
 mkdir -p "$OUT/profiles_${TAG}"
 cp profiles/${TAG}_* "$OUT/profiles_${TAG}/" 2>/dev/null
 for f in scan_sweeps.json batch_sweep.json reference_grid.json probe_routes.jsonl small_batches.json dump_route.jsonl \
-         soak_probe.json soak_cascade.json build_100m.json; do
+         soak_probe.json soak_cascade.json build_100m.json scan_counters.jsonl scan_phases.txt batch_breakdown.jsonl \
+         stream_regimes.json; do
   cp "$OUT/${TAG}_$f" "$OUT/profiles_${TAG}/${TAG}_$f" 2>/dev/null
 done
 for i in 1 2 3; do cp "$OUT/${TAG}_bench_full_$i.json" "$OUT/profiles_${TAG}/${TAG}_bench_full_run$i.json"; done

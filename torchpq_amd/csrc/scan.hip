@@ -341,16 +341,17 @@ static int packed_route(const ScanArgs& a, bool residual, int* dump_regs = nullp
   // 6.1 / 6.9 ms against 7.1 / 8.3; m = 120 (1 000 queries), k = 1000: 2.0 against 3.4 -- and k = 600: 1.9 against 1.6;
   // m = 16, 32: within 2 %; k = 300, 500 at m = 64: 4.1 / 4.5 against 3.6 / 4.0)
   const bool pools = !residual && R >= pool_min_list_regs(m) && (packed_waves(m) < 16 || k > 768) && fuse_enabled();
-  if (!pools) {  // (large batches: dump_route)
+  // large batches: dump_route.  (Where the pools apply as well -- k in (248, 504] of the short codes -- the pools keep the
+  // call: dump_route's own k limit for m <= 32, kDumpShortMaxK, says so; variant builds move it for the A/B.)
+  {
     const int Rf = dump_finish_regs(k, a.slots_hint);
     if (dump_regs) *dump_regs = Rf;
     const int mode = dump_route(a, residual, Rf);
-    if (mode == kDumpSel16) return TPQ_SCAN_ROUTE_DUMP_SEL16;
-    if (mode == kDumpSel16W8) return TPQ_SCAN_ROUTE_DUMP_SEL16_W8;
+    if (mode == kDumpSel16 && !pools) return TPQ_SCAN_ROUTE_DUMP_SEL16;
+    if (mode == kDumpSel16W8 && !pools) return TPQ_SCAN_ROUTE_DUMP_SEL16_W8;
     if (mode == kDumpF32) return TPQ_SCAN_ROUTE_DUMP_F32;
-  } else {
-    return TPQ_SCAN_ROUTE_POOLS;
   }
+  if (pools) return TPQ_SCAN_ROUTE_POOLS;
   const int RL = list_regs_scan(k, m, a.max_nprobe, a.slots_hint);
   if (!residual && fuse_enabled() && fuse_fits(m, R) && packed_waves(m) * RL >= R && (a.n_split == 1 || a.tickets))
     return TPQ_SCAN_ROUTE_ONE_LAUNCH;

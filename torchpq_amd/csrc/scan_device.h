@@ -94,6 +94,24 @@ constexpr int kDumpShortMaxK = 248;    // m = 8, 16, 32 (kDumpF32): the pools ta
 #define TPQ_PROF(a, q, i) ((void)0)
 #endif
 
+// Volatile accesses to LDS words other waves update (the shared admission threshold, the waves' quantiles) go through an
+// LDS-ADDRESS-SPACE pointer.  A `volatile T*` cast of a generic pointer compiles to FLAT loads, and FLAT counts on vmcnt:
+// the `s_waitcnt vmcnt(0)` hipcc put behind the per-tile threshold poll made every wave wait, once per tile, until the NEXT
+// tile's code loads -- the software pipeline's prefetch, issued a few hundred cycles earlier -- had landed (round 6, read
+// off the ISA of the tile loop: `flat_load_dword ... sc0 sc1` + `s_waitcnt vmcnt(0)`).  ds_read_b32 counts on lgkmcnt only.
+__device__ __forceinline__ unsigned lds_poll_u32(const unsigned* p) {
+  typedef const volatile __attribute__((address_space(3))) unsigned* lds_ptr;
+  return *(lds_ptr)p;
+}
+__device__ __forceinline__ float lds_poll_f32(const float* p) {
+  typedef const volatile __attribute__((address_space(3))) float* lds_ptr;
+  return *(lds_ptr)p;
+}
+__device__ __forceinline__ void lds_post_f32(float* p, float v) {
+  typedef volatile __attribute__((address_space(3))) float* lds_ptr;
+  *(lds_ptr)p = v;
+}
+
 // ---- shared pieces -----------------------------------------------------------------------
 
 struct ProbeTable {  // lives in LDS
@@ -324,7 +342,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_ref_kernel(ScanArgs a) {
       }
     }
     // workgroup-shared admission threshold: any wave's k-th best bounds the final k-th best
-    const float tau_s = key2f(*reinterpret_cast<volatile unsigned*>(tau_key));
+    const float tau_s = key2f(lds_poll_u32(tau_key));
     sel.tau = fmaxf(sel.tau, tau_s);
     const float tau_before = sel.tau;
     sel.push(live && (v >= sel.tau), v, s);
@@ -440,7 +458,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_residual_kernel(ScanArgs a,
           v += row[768 + (w >> 24)];
         }
       }
-      const float tau_s = key2f(*reinterpret_cast<volatile unsigned*>(tau_key));
+      const float tau_s = key2f(lds_poll_u32(tau_key));
       sel.tau = fmaxf(sel.tau, tau_s);
       const float tau_before = sel.tau;
       sel.push(live && (v >= sel.tau), v + 0.0f, s);
@@ -983,7 +1001,9 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
   float* pbase = wave_q + NW;                  // RES: [max_nprobe] base_sims of the probe
   int* pcell = reinterpret_cast<int*>(pbase + (RES ? a.max_nprobe : 0));  // RES: [max_nprobe] cell
   float* xq = reinterpret_cast<float*>(pcell + (RES ? a.max_nprobe : 0));
-  const int wave = threadIdx.x >> 6;
+  // (wave-uniform by construction: told to the compiler, so that the tile index, the probe cursor and their compares
+  // live on the scalar unit instead of in VGPRs behind exec masks -- the scan is VALU-issue-bound)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = lane_id();
   int q, part, parts;  // query, this workgroup's part of it, the parts it is dealt in
   if (DUMP && (int)blockIdx.x < a.unsplit) {  // (tail split, ScanArgs::unsplit: the leading queries are not split)
@@ -1128,17 +1148,17 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
   const int r_share = (a.k + NW - 1) / NW;
   // readers poll ONE word per tile; the (rare) publisher folds bound (b) into it
   auto refresh_tau = [&]() {
-    sel.tau = fmaxf(sel.tau, key2f(*reinterpret_cast<volatile unsigned*>(tau_key)));
+    sel.tau = fmaxf(sel.tau, key2f(lds_poll_u32(tau_key)));
   };
   auto publish = [&](float /*tau_before*/) {
     // readlane must run with every lane active: inside `if (lane == 0)` the source lane is
     // inactive and its register contents are undefined to the compiler
     const float mine = sel.top.kth_value(r_share);
     if (lane == 0) {
-      reinterpret_cast<volatile float*>(wave_q)[wave] = mine;
-      float qmin = reinterpret_cast<volatile float*>(wave_q)[0];
+      lds_post_f32(wave_q + wave, mine);
+      float qmin = lds_poll_f32(wave_q);
 #pragma unroll
-      for (int w = 1; w < NW; ++w) qmin = fminf(qmin, reinterpret_cast<volatile float*>(wave_q)[w]);
+      for (int w = 1; w < NW; ++w) qmin = fminf(qmin, lds_poll_f32(wave_q + w));
       atomicMax(tau_key, f2key(fmaxf(sel.tau, qmin)));
     }
   };
@@ -1365,10 +1385,10 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
     TPQ_PROF(a, blockIdx.x, 6);
     float shared_tau;
     {
-      float qmin = reinterpret_cast<volatile float*>(wave_q)[0];
+      float qmin = lds_poll_f32(wave_q);
 #pragma unroll
-      for (int w = 1; w < NW; ++w) qmin = fminf(qmin, reinterpret_cast<volatile float*>(wave_q)[w]);
-      shared_tau = fmaxf(qmin, key2f(*reinterpret_cast<volatile unsigned*>(tau_key)));
+      for (int w = 1; w < NW; ++w) qmin = fminf(qmin, lds_poll_f32(wave_q + w));
+      shared_tau = fmaxf(qmin, key2f(lds_poll_u32(tau_key)));
     }
     constexpr int PR = RM == -1 ? 16 : 32;  // pool registers: pool_cap = 64 PR entries (1024 / 2048)
     const bool overflow = pool.n > pool.cap;
@@ -1413,7 +1433,7 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
       for (int round = 0; round < (RM == -3 ? 0 : 3); ++round) {
         unsigned my_t = 0;
         if (round == 0) {
-          if (lane < NW) my_t = f2key(reinterpret_cast<volatile float*>(wave_q)[lane]);
+          if (lane < NW) my_t = f2key(lds_poll_f32(wave_q + lane));
         } else {
           const unsigned long long span = (unsigned long long)(hi - lo);
           my_t = lo + (unsigned)((span * (unsigned)(lane + 1)) / (unsigned)(NW + 1));
@@ -1500,10 +1520,10 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
     TPQ_PROF(a, blockIdx.x, 6);
     float shared_tau;  // identical in every wave (the loop below must be workgroup-uniform)
     {
-      float qmin = reinterpret_cast<volatile float*>(wave_q)[0];
+      float qmin = lds_poll_f32(wave_q);
 #pragma unroll
-      for (int w = 1; w < NW; ++w) qmin = fminf(qmin, reinterpret_cast<volatile float*>(wave_q)[w]);
-      shared_tau = fmaxf(qmin, key2f(*reinterpret_cast<volatile unsigned*>(tau_key)));
+      for (int w = 1; w < NW; ++w) qmin = fminf(qmin, lds_poll_f32(wave_q + w));
+      shared_tau = fmaxf(qmin, key2f(lds_poll_u32(tau_key)));
       sel.tau = fmaxf(sel.tau, shared_tau);
     }
     // Two counting rounds pull the bound up to (nearly) the exact k-th best fast value of the
@@ -1534,7 +1554,7 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
       for (int round = 0; round < 2; ++round) {
         unsigned my_t = 0;  // lane j < NW: threshold j of this round
         if (round == 0) {
-          if (lane < NW) my_t = f2key(reinterpret_cast<volatile float*>(wave_q)[lane]);
+          if (lane < NW) my_t = f2key(lds_poll_f32(wave_q + lane));
         } else {
           const unsigned long long span = (unsigned long long)(hi - lo);
           my_t = lo + (unsigned)((span * (unsigned)(lane + 1)) / (unsigned)(NW + 1));
@@ -1765,7 +1785,7 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
           }
           bool live = valid;
           if (valid && a.is_empty) live = (a.is_empty[sidx] == 0);
-          xs.tau = fmaxf(xs.tau, key2f(*reinterpret_cast<volatile unsigned*>(tau_key)));
+          xs.tau = fmaxf(xs.tau, key2f(lds_poll_u32(tau_key)));
           const float tau_before = xs.tau;
           xs.push(live && (e >= xs.tau), e, sidx);
           if (xs.tau > tau_before && lane == 0) atomicMax(tau_key, f2key(xs.tau));
@@ -1882,7 +1902,9 @@ __global__ __launch_bounds__(512) void scan_merge_refine_kernel(ScanArgs a) {
 // (tpq_adc_lut's output, the reference boundary: IVFPQTopkCuda.topk(precomputed=...), kernels/IVFPQTopkCuda.py:81-142),
 // gathered per survivor (m independent loads per lane, ascending-j adds); nothing is staged in LDS then.
 constexpr int finish_waves(int RM) { return RM <= 8 ? 16 : 8; }
-constexpr int kDumpMaxR = 8;  // registers of the finish kernel's exact list: k <= 504
+// registers of the finish kernel's exact list.  Round 6: 16 (eight waves per workgroup: 128 KiB of codebook + 32 KiB of
+// survivor queues) -- k in (440, 504] on long cells, whose band holds more than the 512 candidates of RM = 8
+constexpr int kDumpMaxR = 16;
 static size_t finish_lds_bytes(int m, int ds, int RM, bool from_lut) {
   return (from_lut ? 0 : (size_t)m * ds * 1024) + (size_t)finish_waves(RM) * RM * 64 * 4;
 }

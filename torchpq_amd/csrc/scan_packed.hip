@@ -149,9 +149,10 @@ template <int M, int MODE>
 static int dispatch_dump_mode(const ScanArgs& a, int RL, int R, hipStream_t st) {
 #define TPQ_PAIR(A, B) if (RL == A && R == B) return launch_dump<A, B, M, MODE>(a, st);
   if constexpr (MODE == kDumpSel16W8) {
-    TPQ_PAIR(1, 8) TPQ_PAIR(2, 8)
+    TPQ_PAIR(1, 8) TPQ_PAIR(2, 8) TPQ_PAIR(2, 16)
   } else if constexpr (MODE == kDumpF32) {
     TPQ_PAIR(1, 1) TPQ_PAIR(1, 2) TPQ_PAIR(2, 2) TPQ_PAIR(1, 4) TPQ_PAIR(2, 4) TPQ_PAIR(4, 4) TPQ_PAIR(2, 8) TPQ_PAIR(4, 8)
+    TPQ_PAIR(4, 16)
   } else {
     TPQ_PAIR(1, 1) TPQ_PAIR(1, 2) TPQ_PAIR(2, 2) TPQ_PAIR(1, 4) TPQ_PAIR(2, 4) TPQ_PAIR(2, 8) TPQ_PAIR(4, 8)
   }
