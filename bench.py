@@ -699,7 +699,9 @@ def c4_cold_variant(idx, device, stream_peak, k, steps, host):
     npl = torch.full((nq,), n_probe, device=device, dtype=torch.long)
     scan = idx._ivfpq_topk._scan
     run = lambda: idx.search_cells(queries, cells, n_probe_list=npl, k=k)  # noqa: E731
-    run()
+    steps = max(steps, 20)   # (1.2 ms a step: the spread of five was 1.22 ... 1.40)
+    for _ in range(2):
+        run()
     torch.cuda.synchronize()
     scan.record_events = []
     t0 = time.perf_counter()

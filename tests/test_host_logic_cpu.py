@@ -212,7 +212,10 @@ def test_scan_route_rules():
     # round 6: the short codes
     for m, ds in ((32, 4), (16, 8), (8, 16), (32, 1)):
         assert r(m, 10000, 100, ds=ds, hint=32 * 244) == "dump_f32"
-        assert r(m, 10000, 100, has_lut=True) == "dump_f32"         # the caller's table: entries gathered per survivor
+        # the caller's table: entries gathered per survivor -- behind long scans only
+        assert r(m, 10000, 100, has_lut=True, hint=32 * 977) == "dump_f32"
+        assert r(m, 10000, 100, has_lut=True, hint=32 * 244) == "one_launch_finish"
+        assert r(m, 10000, 100, has_lut=True) == "one_launch_finish"
         assert r(m, 1000, 100, ds=ds) == "one_launch_finish"
     assert r(32, 10000, 100, ds=8) == "one_launch_finish"           # fused, m * ds > 128: the codebook would not fit
     assert r(32, 10000, 300, ds=4) == "pools"                       # k > 248 at m <= 32

@@ -155,6 +155,10 @@ static int dump_route(const ScanArgs& a, bool residual, int R) {
     const int kmax = ek ? atoi(ek) : kDumpShortMaxK;
     if (a.k > kmax || rl4 > 4) return 0;
     if (!a.lut && a.m * a.ds > 128) return 0;
+    // a caller's table: the finish kernel gathers m entries per survivor from it -- pays only behind long scans (the
+    // reference grid at m = 16, IVF4096 cells of 244 slots, scan fraction of 8 TB/s, one-launch finish / this route:
+    // 32 probes 0.44 / 0.39, 64 probes 0.49 / 0.50, 128 probes 0.58 / 0.63)
+    if (a.lut && a.slots_hint < kDumpLutMinSlots) return 0;
     return kDumpF32;
   }
   // m = 64: the 16-bit table.  The finish kernel recomputes the survivors' table entries from the codebook, held in

@@ -84,6 +84,7 @@ constexpr int kDumpSel16W8 = -17;  // the same with the eight waves of the other
 constexpr bool is_sel16(int RM) { return RM == kDumpSel16 || RM == kDumpSel16W8; }
 constexpr int kDumpMinQueries = 1024;  // batches that fill the chip's 4 x 256 workgroup slots at least once
 constexpr int kDumpShortMaxK = 248;    // m = 8, 16, 32 (kDumpF32): the pools take the larger k
+constexpr int kDumpLutMinSlots = 24576;  // ... with a caller's table: from this many expected slots per query on
 
 #ifdef TPQ_SCAN_PROFILE
 #define TPQ_PROF(a, q, i)                                                        \
@@ -1003,6 +1004,8 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
   float* xq = reinterpret_cast<float*>(pcell + (RES ? a.max_nprobe : 0));
   // (wave-uniform by construction: told to the compiler, so that the tile index, the probe cursor and their compares
   // live on the scalar unit instead of in VGPRs behind exec masks -- the scan is VALU-issue-bound)
+  // (same box, caller-supplied table, C2 shape, TB/s without / with the hint: m = 16 4.60 / 4.71, 20 4.37 / 4.71,
+  // 24 4.69 / 5.02, 32 5.88 / 5.90, 64 6.92 / 7.07)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = lane_id();
   int q, part, parts;  // query, this workgroup's part of it, the parts it is dealt in
@@ -1167,23 +1170,37 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
     struct Tile {
       int s;
       bool valid;
-      float add;  // RES: base_p + slot_term[s]
+      float add;      // RES: base_p + slot_term[s]
+      unsigned hole;  // is_empty[s] (0 when the caller passed no tombstones)
     };
     int p = 0;
+    // Every global load of the tile loop is UNCONDITIONAL, on a clamped address (round 6).  With the prefetch under
+    // `if (next tile exists) if (lane has a slot)` hipcc's waitcnt bookkeeping merged the two paths at the join and
+    // put `s_waitcnt vmcnt(3 .. 0)` in front of the four chunks of the CURRENT tile's look-ups -- i.e. the wave waited for
+    // the first chunks of the tile it had just prefetched before consuming the tile already in its registers (the ISA
+    // of the loop: eight loads in flight wanted vmcnt(7 .. 4)).  A lane without a slot, and the whole wave past its
+    // last tile, read slot 0's bytes instead (a tile exists, so slot 0 does) and drop the value.
     auto locate = [&](int T) -> Tile {
       while (T >= tab.tile_begin[p + 1]) ++p;
       const int off = ((T - tab.tile_begin[p]) << 6) + lane;
-      Tile t{tab.start[p] + off, off < tab.size[p], 0.f};
-      if constexpr (RES) {
-        if (t.valid) t.add = pbase[p] + ra.slot_term[t.s];
-      }
+      Tile t{tab.start[p] + off, off < tab.size[p], 0.f, 0u};
       return t;
+    };
+    auto fetch = [&](int T, Tile& t, typename L::chunk_t (&w)[L::kChunks]) {
+      if (T < t_end) {  // (wave-uniform; nothing is loaded from global memory inside)
+        t = locate(T);
+      } else {
+        t.valid = false;
+      }
+      const int s = t.valid ? t.s : 0;
+      L::load(a.packed, a.n_slots, s, w);
+      if constexpr (RES) t.add = (T < t_end ? pbase[p] : 0.f) + ra.slot_term[s];
+      if (a.is_empty) t.hole = a.is_empty[s];  // (wave-uniform branch: a foreign index with tombstones inside cells)
     };
     auto consume = [&](const typename L::chunk_t(&w)[L::kChunks], const Tile& t) {
       float v = 0.f;
-      bool live = t.valid;
+      const bool live = t.valid && t.hole == 0u;
       if (t.valid) {
-        if (a.is_empty) live = (a.is_empty[t.s] == 0);
         if constexpr (SEL16) v = (float)L::accumulate16(w, t.s, reinterpret_cast<const uint16_t*>(lut));
         else v = L::accumulate(w, t.s, lut);
         if constexpr (RES) v += t.add;
@@ -1200,35 +1217,24 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
     // (m <= 64; larger m runs 16 waves per workgroup under a 128-VGPR cap and relies on them)
     if constexpr (M <= 64) {
       typename L::chunk_t w0[L::kChunks], w1[L::kChunks];
-      Tile m0{0, false, 0.f}, m1{0, false, 0.f};
+      Tile m0{0, false, 0.f, 0u}, m1{0, false, 0.f, 0u};
       int T = t_begin + wave;
-      if (T < t_end) {
-        m0 = locate(T);
-        if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
-      }
+      if (T < t_end) fetch(T, m0, w0);  // (a wave without a tile loads nothing: slot 0 need not exist)
 #ifdef TPQ_SCAN_PROFILE
       bool first_tile = true;
 #endif
       while (T < t_end) {
-        int Tn = T + NW;
-        if (Tn < t_end) {
-          m1 = locate(Tn);
-          if (m1.valid) L::load(a.packed, a.n_slots, m1.s, w1);
-        }
+        fetch(T + NW, m1, w1);
         consume(w0, m0);
 #ifdef TPQ_SCAN_PROFILE
         if (first_tile) TPQ_PROF(a, blockIdx.x, 14);
         first_tile = false;
 #endif
-        T = Tn;
+        T += NW;
         if (T >= t_end) break;
-        Tn = T + NW;
-        if (Tn < t_end) {
-          m0 = locate(Tn);
-          if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
-        }
+        fetch(T + NW, m0, w0);
         consume(w1, m1);
-        T = Tn;
+        T += NW;
       }
     } else {
       // One 16-wave workgroup per CU and one tile in flight per wave: with a static deal the waves
@@ -1243,10 +1249,10 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
         return t_begin + __builtin_amdgcn_readfirstlane(t);
       };
       typename L::chunk_t w0[L::kChunks];
+      Tile m0{0, false, 0.f, 0u};
       int T = grab();
       while (T < t_end) {
-        const Tile m0 = locate(T);
-        if (m0.valid) L::load(a.packed, a.n_slots, m0.s, w0);
+        fetch(T, m0, w0);
         const int Tn = grab();
         consume(w0, m0);
         T = Tn;
@@ -1268,17 +1274,26 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
       if constexpr (RES) t.add = pbase[p];
       return t;
     };
-    auto load_tile = [&](const Tile& t, typename L::chunk_t (&w)[S][L::kChunks], float (&term)[S]) {
+    // (every global load unconditional, on a clamped address: see the one-slot-per-lane loop above)
+    struct Side {
+      float term[S];     // RES: slot_term of the lane's slots
+      unsigned hole[S];  // is_empty of the lane's slots (0 when the caller passed no tombstones)
+    };
+    auto fetch = [&](int T, Tile& t, typename L::chunk_t (&w)[S][L::kChunks], Side& sd) {
+      if (T < t_end) {  // (wave-uniform; nothing is loaded from global memory inside)
+        t = locate(T);
+      } else {
+        t.rem = 0;
+      }
   #pragma unroll
       for (int u = 0; u < S; ++u) {
-        if (64 * u < t.rem) {
-          L::load(a.packed, a.n_slots, t.s + 64 * u, w[u]);
-          if constexpr (RES) term[u] = ra.slot_term[t.s + 64 * u];
-        }
+        const int su = 64 * u < t.rem ? t.s + 64 * u : 0;
+        L::load(a.packed, a.n_slots, su, w[u]);
+        if constexpr (RES) sd.term[u] = ra.slot_term[su];
+        if (a.is_empty) sd.hole[u] = a.is_empty[su];  // (wave-uniform branch)
       }
     };
-    auto consume = [&](const typename L::chunk_t (&w)[S][L::kChunks], const float (&term)[S],
-                       const Tile& t) {
+    auto consume = [&](const typename L::chunk_t (&w)[S][L::kChunks], const Side& sd, const Tile& t) {
       float v[S];
       bool live[S];
   #pragma unroll
@@ -1286,10 +1301,10 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
         v[u] = 0.f;
         live[u] = 64 * u < t.rem;
         if (live[u]) {
-          if (a.is_empty) live[u] = (a.is_empty[t.s + 64 * u] == 0);
+          live[u] = sd.hole[u] == 0u;
           if constexpr (SEL16) v[u] = (float)L::accumulate16(w[u], t.s + 64 * u, reinterpret_cast<const uint16_t*>(lut));
           else v[u] = L::accumulate(w[u], t.s + 64 * u, lut);
-          if constexpr (RES) v[u] += t.add + term[u];
+          if constexpr (RES) v[u] += t.add + sd.term[u];
         }
       }
       refresh_tau();
@@ -1313,29 +1328,18 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
     // (m <= 64; larger m runs 16 waves per workgroup under a 128-VGPR cap and relies on them)
     if constexpr (M <= 64) {
       typename L::chunk_t w0[S][L::kChunks], w1[S][L::kChunks];
-      float r0[S] = {}, r1[S] = {};
+      Side r0 = {}, r1 = {};
       Tile m0{0, 0, 0.f}, m1{0, 0, 0.f};
       int T = t_begin + wave;
-      if (T < t_end) {
-        m0 = locate(T);
-        load_tile(m0, w0, r0);
-      }
+      if (T < t_end) fetch(T, m0, w0, r0);  // (a wave without a tile loads nothing: slot 0 need not exist)
       while (T < t_end) {
-        int Tn = T + NW;
-        if (Tn < t_end) {
-          m1 = locate(Tn);
-          load_tile(m1, w1, r1);
-        }
+        fetch(T + NW, m1, w1, r1);
         consume(w0, r0, m0);
-        T = Tn;
+        T += NW;
         if (T >= t_end) break;
-        Tn = T + NW;
-        if (Tn < t_end) {
-          m0 = locate(Tn);
-          load_tile(m0, w0, r0);
-        }
+        fetch(T + NW, m0, w0, r0);
         consume(w1, r1, m1);
-        T = Tn;
+        T += NW;
       }
     } else {
       // One 16-wave workgroup per CU and one tile in flight per wave: with a static deal the waves
@@ -1350,11 +1354,11 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
         return t_begin + __builtin_amdgcn_readfirstlane(t);
       };
       typename L::chunk_t w0[S][L::kChunks];
-      float r0[S] = {};
+      Side r0 = {};
+      Tile m0{0, 0, 0.f};
       int T = grab();
       while (T < t_end) {
-        const Tile m0 = locate(T);
-        load_tile(m0, w0, r0);
+        fetch(T, m0, w0, r0);
         const int Tn = grab();
         consume(w0, r0, m0);
         T = Tn;
