@@ -30,6 +30,9 @@ def main():
                     help="queries probe a window of adjacent cells (correlated probe lists)")
     ap.add_argument("--sort", action="store_true", help="with --neighbors: sort queries by first cell")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--conflict-free", action="store_true",
+                    help="m = 4 / 8 / 16: codes crafted so that the look-ups of 32 consecutive slots fall into 32 "
+                         "distinct LDS banks (c mod (32 / m) = (slot / m) mod (32 / m)): what a replicated table would buy")
     args = ap.parse_args()
     from torchpq_amd import kernels as K
     dev = "cuda:0"
@@ -41,6 +44,11 @@ def main():
     start = torch.cumsum(cap, 0) - cap
     n_slots = int(cap.sum().item())
     storage = torch.randint(0, 256, (m // 4, n_slots, 4), generator=g, device=dev, dtype=torch.uint8)
+    if args.conflict_free:
+        reps = 32 // m
+        sl = torch.arange(n_slots, device=dev)
+        low = ((sl // m) % reps).to(torch.uint8)[None, :, None]
+        storage = (storage // reps) * reps + low
     lut = torch.randn(m, args.nq, 256, generator=g, device=dev) * 50 - 300
     if args.neighbors:
         base = torch.randint(0, nc, (args.nq, 1), generator=g, device=dev)

@@ -153,29 +153,67 @@ struct Layout {
     for (int h = 0; h < 4; ++h)
       lane64[h] = ((((uint32_t)h ^ ((uint32_t)(s >> 4) & 3u)) << 6) | (((uint32_t)s & 15u) << 2));
     const char* __restrict__ lut_bytes = reinterpret_cast<const char*>(lut);
+    // Blocks of 32 / 16 / 8 / 4 (every m but the multiples of 64; m = 8, 16, 32 are nothing else): byte address
+    //   block base + (c << (log2 B + 2)) + (((rel ^ (s & (B-1))) << 2)
+    // = (lane constant ^ ((rel & 15) << 2)) + (c << (log2 B + 2)),  lane constant = table + block base +
+    //   (((s & (B-1)) << 2) ^ ((rel >> 4) << 6))   [one per block and 16-position quarter, hoisted out of the tile loop]
+    // -- the byte shifted straight out of the code dword (SDWA), the XOR and the add in ONE v_xad_u32: two VALU per
+    // look-up like the 64-blocks.  (Round 6; written as c * B + lane part, hipcc emitted the shift, a v_bitop3 XOR and a
+    // v_lshl_add per look-up, plus an AND for byte 0: 3.25 VALU per look-up at m = 8 / 16 / 32, the instruction-bound
+    // codes.)  The table sits at a multiple of 128 bytes in LDS (the start of the dynamic allocation) and a block base
+    // is a multiple of 1 024: both commute with the XOR of the position bits.
+    typedef const __attribute__((address_space(3))) float* lds_f32_ptr;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(lds_f32_ptr)lut;
+    uint32_t shift_of[4];  // log2 B + 2 for B = 32, 16, 8, 4 (SDWA takes the shift from a register)
 #pragma unroll
-    for (int p = 0; p < M; p += 2) {
+    for (int i = 0; i < 4; ++i) shift_of[i] = (uint32_t)(7 - i);
+    static_for_p<0, M / 2>([&](auto p_c) {
+      constexpr int p = 2 * decltype(p_c)::value;
       float t[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int pp = p + u;
-        const BlockAt<M> kb(pp);
+      static_for_p<0, 2>([&](auto u_c) {
+        constexpr int u = decltype(u_c)::value;
+        constexpr int pp = p + u;
+        constexpr BlockAt<M> kb(pp);
         const uint32_t wd = word(w, pp >> 2);
-        if (kb.size == 64) {
-          const int rel = pp - kb.base;
-          const uint32_t sel = 0x0c0c0000u | ((4u + (uint32_t)(pp & 3)) << 8);
+        if constexpr (kb.size == 64) {
+          constexpr int rel = pp - kb.base;
+          constexpr uint32_t sel = 0x0c0c0000u | ((4u + (uint32_t)(pp & 3)) << 8);
           const uint32_t a = __builtin_amdgcn_perm(wd, lane64[rel >> 4], sel) ^ ((uint32_t)(rel & 15) << 2);
           t[u] = *reinterpret_cast<const float*>(lut_bytes + kb.base * 1024 + a);
         } else {
-          const unsigned c = (wd >> (8 * (pp & 3))) & 255u;
-          const int lane_part = (pp - kb.base) ^ (s & (kb.size - 1));
-          t[u] = lut[kb.base * 256 + (int)c * kb.size + lane_part];
+          constexpr int rel = pp - kb.base;
+          constexpr int LOGB = kb.size == 32 ? 5 : (kb.size == 16 ? 4 : (kb.size == 8 ? 3 : 2));
+          const uint32_t lane_c = lbase + (uint32_t)(kb.base * 1024) +
+                                  ((((uint32_t)s & (uint32_t)(kb.size - 1)) << 2) ^ (uint32_t)((rel >> 4) << 6));
+          const uint32_t a = sdwa_shl_xad<pp & 3, (rel & 15) << 2>(lane_c, shift_of[5 - LOGB], wd);
+          t[u] = *(lds_f32_ptr)(uintptr_t)a;
         }
-      }
+      });
       const f32x2 tv = {t[0], t[1]};
       acc += tv;
-    }
+    });
     return acc.x + acc.y;
+  }
+
+  // (lane ^ IMM) + (byte BYTE of wd << shift): v_lshlrev_b32_sdwa + v_xad_u32.  Written as asm: hipcc, seeing that the
+  // two parts share no bits, rewrites the sum into bfe + lshl_or + xor (accumulate16's note).
+  template <int BYTE, int IMM>
+  __device__ static __forceinline__ uint32_t sdwa_shl_xad(uint32_t lane, uint32_t shift, uint32_t wd) {
+    static_assert(IMM >= 0 && IMM <= 64, "an inline constant");
+    uint32_t a;
+    if constexpr (BYTE == 0)
+      asm("v_lshlrev_b32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"
+          "v_xad_u32 %0, %1, %4, %0" : "=&v"(a) : "v"(lane), "v"(shift), "v"(wd), "n"(IMM));
+    else if constexpr (BYTE == 1)
+      asm("v_lshlrev_b32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+          "v_xad_u32 %0, %1, %4, %0" : "=&v"(a) : "v"(lane), "v"(shift), "v"(wd), "n"(IMM));
+    else if constexpr (BYTE == 2)
+      asm("v_lshlrev_b32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
+          "v_xad_u32 %0, %1, %4, %0" : "=&v"(a) : "v"(lane), "v"(shift), "v"(wd), "n"(IMM));
+    else
+      asm("v_lshlrev_b32_sdwa %0, %2, %3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"
+          "v_xad_u32 %0, %1, %4, %0" : "=&v"(a) : "v"(lane), "v"(shift), "v"(wd), "n"(IMM));
+    return a;
   }
 
   // The same walk over the 16-bit selection table (lut16_halfword): an exact integer sum of m u16 entries.
