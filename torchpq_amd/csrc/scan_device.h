@@ -933,8 +933,11 @@ constexpr int packed_tile_shift(int M) { return 6 + TPQ_SLOTS_LOG2; }
 // m=64 3.09 / 5.84 / -: the 16-byte-chunk layouts (m % 16 == 0) gain until the second tile's
 // registers spill; with 4-wave workgroups (m <= 32): m=16 1.17 / 1.13 / 1.12, m=24 1.62 / 1.52 /
 // 1.58, m=28 1.93 / 1.81 / 1.78, m=32 2.02 / 1.82 / 1.76)
+// (round 6, after the look-ups of the small blocks went from 3.25 to 2 VALU: the per-tile part weighs more, and four
+// slots per lane now win from m = 12 on -- same box, S = 2 -> 4, C2 shape k = 100 / k = 1 / 244-slot cells: m = 12 +5 / +6 /
+// +2 %, 16 +7 / +9 / +7 %, 20 +8 / +6 / +4 %, 24 0 / +3 / +3 %; m = 40 -13 %, 48 -10 %, 56 -26 %: those keep theirs)
 constexpr int packed_slots(int M) {
-  return M <= 8 ? 4 : (M <= 24 ? 2 : (M <= 32 ? 4 : ((M == 48 || M == 56) ? 2 : 1)));
+  return M <= 32 ? 4 : ((M == 48 || M == 56) ? 2 : 1);
 }
 constexpr int packed_tile_shift(int M) { return packed_slots(M) == 4 ? 8 : (packed_slots(M) == 2 ? 7 : 6); }
 #endif
@@ -1172,6 +1175,7 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
       bool valid;
       float add;      // RES: base_p + slot_term[s]
       unsigned hole;  // is_empty[s] (0 when the caller passed no tombstones)
+      uint32_t lim;   // the cell's last slot (a wave past its last tile: slot 0)
     };
     int p = 0;
     // Every global load of the tile loop is UNCONDITIONAL, on a clamped address (round 6).  With the prefetch under
@@ -1179,11 +1183,14 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
     // put `s_waitcnt vmcnt(3 .. 0)` in front of the four chunks of the CURRENT tile's look-ups -- i.e. the wave waited for
     // the first chunks of the tile it had just prefetched before consuming the tile already in its registers (the ISA
     // of the loop: eight loads in flight wanted vmcnt(7 .. 4)).  A lane without a slot, and the whole wave past its
-    // last tile, read slot 0's bytes instead (a tile exists, so slot 0 does) and drop the value.
+    // last tile, read the LAST slot of the tile's cell instead (one v_min_u32 against a wave-uniform bound -- was compare +
+    // select of slot 0; the line is one the live lanes touch anyway; a wave past its last tile: slot 0, a tile exists, so
+    // slot 0 does) and drop the value.
     auto locate = [&](int T) -> Tile {
       while (T >= tab.tile_begin[p + 1]) ++p;
       const int off = ((T - tab.tile_begin[p]) << 6) + lane;
-      Tile t{tab.start[p] + off, off < tab.size[p], 0.f, 0u};
+      const int st = tab.start[p], sz = tab.size[p];
+      Tile t{st + off, off < sz, 0.f, 0u, (uint32_t)(st + sz - 1)};
       return t;
     };
     auto fetch = [&](int T, Tile& t, typename L::chunk_t (&w)[L::kChunks]) {
@@ -1191,16 +1198,20 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
         t = locate(T);
       } else {
         t.valid = false;
+        t.lim = 0u;
       }
-      const int s = t.valid ? t.s : 0;
-      L::load(a.packed, a.n_slots, s, w);
+      const uint32_t s = min((uint32_t)t.s, t.lim);
+      L::load_u(a.packed, a.n_slots, s, w);
       if constexpr (RES) t.add = (T < t_end ? pbase[p] : 0.f) + ra.slot_term[s];
       if (a.is_empty) t.hole = a.is_empty[s];  // (wave-uniform branch: a foreign index with tombstones inside cells)
     };
+    // (a lane without a live slot carries NaN: it fails the admission compare by itself -- no `live` flag is kept in a
+    // register next to the value, and the tombstone test sits behind a wave-uniform branch; the scan is VALU-issue-bound)
     auto consume = [&](const typename L::chunk_t(&w)[L::kChunks], const Tile& t) {
-      float v = 0.f;
-      const bool live = t.valid && t.hole == 0u;
-      if (t.valid) {
+      float v = __builtin_nanf("");
+      bool live = t.valid;
+      if (a.is_empty) live = live && t.hole == 0u;
+      if (live) {
         if constexpr (SEL16) v = (float)L::accumulate16(w, t.s, reinterpret_cast<const uint16_t*>(lut));
         else v = L::accumulate(w, t.s, lut);
         if constexpr (RES) v += t.add;
@@ -1208,8 +1219,8 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
       refresh_tau();
       const float tau_before = sel.tau;
       const int flushes_before = sel.n_flush;
-      if constexpr (POOL) sel.push_pool(pool, live && (v >= sel.tau - delta2), v, t.s);
-      else sel.push(live && (v >= sel.tau - delta2), v, t.s);
+      if constexpr (POOL) sel.push_pool(pool, v >= sel.tau - delta2, v, t.s);
+      else sel.push(v >= sel.tau - delta2, v, t.s);
       if (sel.n_flush != flushes_before) publish(tau_before);
     };
 
@@ -1217,7 +1228,7 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
     // (m <= 64; larger m runs 16 waves per workgroup under a 128-VGPR cap and relies on them)
     if constexpr (M <= 64) {
       typename L::chunk_t w0[L::kChunks], w1[L::kChunks];
-      Tile m0{0, false, 0.f, 0u}, m1{0, false, 0.f, 0u};
+      Tile m0{0, false, 0.f, 0u, 0u}, m1{0, false, 0.f, 0u, 0u};
       int T = t_begin + wave;
       if (T < t_end) fetch(T, m0, w0);  // (a wave without a tile loads nothing: slot 0 need not exist)
 #ifdef TPQ_SCAN_PROFILE
@@ -1249,7 +1260,7 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
         return t_begin + __builtin_amdgcn_readfirstlane(t);
       };
       typename L::chunk_t w0[L::kChunks];
-      Tile m0{0, false, 0.f, 0u};
+      Tile m0{0, false, 0.f, 0u, 0u};
       int T = grab();
       while (T < t_end) {
         fetch(T, m0, w0);
@@ -1265,12 +1276,14 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
       int s;      // the lane's first slot; its u-th slot is s + 64 u
       int rem;    // slots of the cell from s on: the u-th slot exists iff 64 u < rem
       float add;  // RES: base_p (slot_term is added per slot)
+      uint32_t lim;  // the cell's last slot (a wave past its last tile: slot 0)
     };
     int p = 0;
     auto locate = [&](int T) -> Tile {
       while (T >= tab.tile_begin[p + 1]) ++p;
       const int off = ((T - tab.tile_begin[p]) << TS) + lane;
-      Tile t{tab.start[p] + off, tab.size[p] - off, 0.f};
+      const int st = tab.start[p], sz = tab.size[p];
+      Tile t{st + off, sz - off, 0.f, (uint32_t)(st + sz - 1)};
       if constexpr (RES) t.add = pbase[p];
       return t;
     };
@@ -1284,24 +1297,27 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
         t = locate(T);
       } else {
         t.rem = 0;
+        t.lim = 0u;
       }
   #pragma unroll
       for (int u = 0; u < S; ++u) {
-        const int su = 64 * u < t.rem ? t.s + 64 * u : 0;
-        L::load(a.packed, a.n_slots, su, w[u]);
+        // (a slot past the end of the cell: the cell's last slot; a wave past its last tile: slot 0 -- read and dropped)
+        const uint32_t su = min((uint32_t)(t.s + 64 * u), t.lim);
+        L::load_u(a.packed, a.n_slots, su, w[u]);
         if constexpr (RES) sd.term[u] = ra.slot_term[su];
         if (a.is_empty) sd.hole[u] = a.is_empty[su];  // (wave-uniform branch)
       }
     };
     auto consume = [&](const typename L::chunk_t (&w)[S][L::kChunks], const Side& sd, const Tile& t) {
+      // (a slot that is not live carries NaN: it fails the admission compare by itself -- no `live` flags are kept in
+      // registers next to the values, and the tombstone test sits behind a wave-uniform branch)
       float v[S];
-      bool live[S];
   #pragma unroll
       for (int u = 0; u < S; ++u) {
-        v[u] = 0.f;
-        live[u] = 64 * u < t.rem;
-        if (live[u]) {
-          live[u] = sd.hole[u] == 0u;
+        v[u] = __builtin_nanf("");
+        bool live = 64 * u < t.rem;
+        if (a.is_empty) live = live && sd.hole[u] == 0u;
+        if (live) {
           if constexpr (SEL16) v[u] = (float)L::accumulate16(w[u], t.s + 64 * u, reinterpret_cast<const uint16_t*>(lut));
           else v[u] = L::accumulate(w[u], t.s + 64 * u, lut);
           if constexpr (RES) v[u] += t.add + sd.term[u];
@@ -1311,15 +1327,15 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
       if constexpr (S > 1) {
         bool any = false;
   #pragma unroll
-        for (int u = 0; u < S; ++u) any = any || (live[u] && (v[u] >= sel.tau - delta2));
+        for (int u = 0; u < S; ++u) any = any || (v[u] >= sel.tau - delta2);
         if (__ballot(any) == 0ull) return;  // the common case: one ballot for S x 64 slots
       }
   #pragma unroll
       for (int u = 0; u < S; ++u) {
         const float tau_before = sel.tau;
         const int flushes_before = sel.n_flush;
-        if constexpr (POOL) sel.push_pool(pool, live[u] && (v[u] >= sel.tau - delta2), v[u], t.s + 64 * u);
-        else sel.push(live[u] && (v[u] >= sel.tau - delta2), v[u], t.s + 64 * u);
+        if constexpr (POOL) sel.push_pool(pool, v[u] >= sel.tau - delta2, v[u], t.s + 64 * u);
+        else sel.push(v[u] >= sel.tau - delta2, v[u], t.s + 64 * u);
         if (sel.n_flush != flushes_before) publish(tau_before);
       }
     };
@@ -1329,7 +1345,7 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
     if constexpr (M <= 64) {
       typename L::chunk_t w0[S][L::kChunks], w1[S][L::kChunks];
       Side r0 = {}, r1 = {};
-      Tile m0{0, 0, 0.f}, m1{0, 0, 0.f};
+      Tile m0{0, 0, 0.f, 0u}, m1{0, 0, 0.f, 0u};
       int T = t_begin + wave;
       if (T < t_end) fetch(T, m0, w0, r0);  // (a wave without a tile loads nothing: slot 0 need not exist)
       while (T < t_end) {
@@ -1355,7 +1371,7 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
       };
       typename L::chunk_t w0[S][L::kChunks];
       Side r0 = {};
-      Tile m0{0, 0, 0.f};
+      Tile m0{0, 0, 0.f, 0u};
       int T = grab();
       while (T < t_end) {
         fetch(T, m0, w0, r0);

@@ -120,6 +120,14 @@ struct Layout {
 #pragma unroll
     for (int c = 0; c < kChunks; ++c) w[c] = src[(int64_t)c * n_slots + s];
   }
+  // the tile loop's form: the slot index is UNSIGNED (no sign extension per address) and the caller clamps it with one
+  // v_min_u32 against the last slot of the array (was: compare + select 0 -- the scan is VALU-issue-bound)
+  __device__ static __forceinline__ void load_u(const uint8_t* __restrict__ packed, int64_t n_slots,
+                                                uint32_t s, chunk_t (&w)[kChunks]) {
+    const chunk_t* __restrict__ src = reinterpret_cast<const chunk_t*>(packed);
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) w[c] = src[(int64_t)c * n_slots + (int64_t)(uint64_t)s];
+  }
 
   __device__ static __forceinline__ uint32_t word(const chunk_t (&w)[kChunks], int d) {
     // d = dword index inside the slot (compile-time after unrolling)
