@@ -115,6 +115,13 @@ __device__ __forceinline__ void lds_post_f32(float* p, float v) {
 
 // ---- shared pieces -----------------------------------------------------------------------
 
+// s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt [3:0] and [15:14], expcnt [6:4] and lgkmcnt [11:8] left at their maxima)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "six bits");
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
 struct ProbeTable {  // lives in LDS
   int* start;        // [max_nprobe]
   int* size;         // [max_nprobe]
@@ -1170,11 +1177,11 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
   };
 
   if constexpr (packed_slots(M) == 1) {
+    constexpr int kFetchLoads = L::kChunks + (RES ? 1 : 0);  // global loads of one fetch (without tombstones)
     struct Tile {
       int s;
       bool valid;
       float add;      // RES: base_p + slot_term[s]
-      unsigned hole;  // is_empty[s] (0 when the caller passed no tombstones)
       uint32_t lim;   // the cell's last slot (a wave past its last tile: slot 0)
     };
     int p = 0;
@@ -1190,7 +1197,7 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
       while (T >= tab.tile_begin[p + 1]) ++p;
       const int off = ((T - tab.tile_begin[p]) << 6) + lane;
       const int st = tab.start[p], sz = tab.size[p];
-      Tile t{st + off, off < sz, 0.f, 0u, (uint32_t)(st + sz - 1)};
+      Tile t{st + off, off < sz, 0.f, (uint32_t)(st + sz - 1)};
       return t;
     };
     auto fetch = [&](int T, Tile& t, typename L::chunk_t (&w)[L::kChunks]) {
@@ -1203,24 +1210,35 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
       const uint32_t s = min((uint32_t)t.s, t.lim);
       L::load_u(a.packed, a.n_slots, s, w);
       if constexpr (RES) t.add = (T < t_end ? pbase[p] : 0.f) + ra.slot_term[s];
-      if (a.is_empty) t.hole = a.is_empty[s];  // (wave-uniform branch: a foreign index with tombstones inside cells)
     };
-    // (a lane without a live slot carries NaN: it fails the admission compare by itself -- no `live` flag is kept in a
-    // register next to the value, and the tombstone test sits behind a wave-uniform branch; the scan is VALU-issue-bound)
+    // (a lane without a slot carries NaN: it fails the admission compare by itself -- no `live` flag is kept in a register
+    // next to the value; the scan is VALU-issue-bound.  Tombstones -- a foreign index with holes inside its cells,
+    // ivfpq_topk.cu:878,883-884 -- are looked up for the candidates that PASS the threshold only (round 6; the flag bytes
+    // used to travel with the prefetch: one more load per slot in flight, a number of loads per fetch that depended on the
+    // call, and a fetch whose loads hipcc's waitcnt bookkeeping could not count exactly).)
     auto consume = [&](const typename L::chunk_t(&w)[L::kChunks], const Tile& t) {
       float v = __builtin_nanf("");
-      bool live = t.valid;
-      if (a.is_empty) live = live && t.hole == 0u;
-      if (live) {
+      if (t.valid) {
         if constexpr (SEL16) v = (float)L::accumulate16(w, t.s, reinterpret_cast<const uint16_t*>(lut));
         else v = L::accumulate(w, t.s, lut);
         if constexpr (RES) v += t.add;
       }
+      // Every load of THIS tile has landed on every path past this point -- said explicitly (round 6): a wave whose tile has
+      // no live lane branches around the look-ups and their `s_waitcnt vmcnt(7 .. 4)`, hipcc's waitcnt bookkeeping merged
+      // that path in at the loop header, saw a load pending on the registers the next fetch reuses as temporaries and put
+      // `s_waitcnt vmcnt(0)` in front of every other prefetch: the wave drained its loads before issuing the next tile's.
+      // What remains in flight here is the prefetched tile (one fetch = kFetchLoads loads; with tombstones one more per
+      // slot: that call waits for the first of them too).
+      if constexpr (M <= 64) wait_vmcnt<kFetchLoads>();
       refresh_tau();
       const float tau_before = sel.tau;
       const int flushes_before = sel.n_flush;
-      if constexpr (POOL) sel.push_pool(pool, v >= sel.tau - delta2, v, t.s);
-      else sel.push(v >= sel.tau - delta2, v, t.s);
+      bool pass = v >= sel.tau - delta2;
+      if (a.is_empty) {  // (wave-uniform)
+        if (pass) pass = a.is_empty[t.s] == 0;
+      }
+      if constexpr (POOL) sel.push_pool(pool, pass, v, t.s);
+      else sel.push(pass, v, t.s);
       if (sel.n_flush != flushes_before) publish(tau_before);
     };
 
@@ -1228,7 +1246,7 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
     // (m <= 64; larger m runs 16 waves per workgroup under a 128-VGPR cap and relies on them)
     if constexpr (M <= 64) {
       typename L::chunk_t w0[L::kChunks], w1[L::kChunks];
-      Tile m0{0, false, 0.f, 0u, 0u}, m1{0, false, 0.f, 0u, 0u};
+      Tile m0{0, false, 0.f, 0u}, m1{0, false, 0.f, 0u};
       int T = t_begin + wave;
       if (T < t_end) fetch(T, m0, w0);  // (a wave without a tile loads nothing: slot 0 need not exist)
 #ifdef TPQ_SCAN_PROFILE
@@ -1260,7 +1278,7 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
         return t_begin + __builtin_amdgcn_readfirstlane(t);
       };
       typename L::chunk_t w0[L::kChunks];
-      Tile m0{0, false, 0.f, 0u, 0u};
+      Tile m0{0, false, 0.f, 0u};
       int T = grab();
       while (T < t_end) {
         fetch(T, m0, w0);
@@ -1272,6 +1290,7 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
   } else {
     constexpr int S = packed_slots(M);          // slots per lane per tile, 64 apart
     constexpr int TS = packed_tile_shift(M);    // log2(slots per tile)
+    constexpr int kFetchLoads = S * (L::kChunks + (RES ? 1 : 0));  // global loads of one fetch (without tombstones)
     struct Tile {
       int s;      // the lane's first slot; its u-th slot is s + 64 u
       int rem;    // slots of the cell from s on: the u-th slot exists iff 64 u < rem
@@ -1290,7 +1309,6 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
     // (every global load unconditional, on a clamped address: see the one-slot-per-lane loop above)
     struct Side {
       float term[S];     // RES: slot_term of the lane's slots
-      unsigned hole[S];  // is_empty of the lane's slots (0 when the caller passed no tombstones)
     };
     auto fetch = [&](int T, Tile& t, typename L::chunk_t (&w)[S][L::kChunks], Side& sd) {
       if (T < t_end) {  // (wave-uniform; nothing is loaded from global memory inside)
@@ -1305,24 +1323,23 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
         const uint32_t su = min((uint32_t)(t.s + 64 * u), t.lim);
         L::load_u(a.packed, a.n_slots, su, w[u]);
         if constexpr (RES) sd.term[u] = ra.slot_term[su];
-        if (a.is_empty) sd.hole[u] = a.is_empty[su];  // (wave-uniform branch)
       }
     };
     auto consume = [&](const typename L::chunk_t (&w)[S][L::kChunks], const Side& sd, const Tile& t) {
-      // (a slot that is not live carries NaN: it fails the admission compare by itself -- no `live` flags are kept in
-      // registers next to the values, and the tombstone test sits behind a wave-uniform branch)
+      // (a lane's missing slot carries NaN: it fails the admission compare by itself; tombstones are looked up for the
+      // passing candidates only: see the one-slot-per-lane loop above)
       float v[S];
   #pragma unroll
       for (int u = 0; u < S; ++u) {
         v[u] = __builtin_nanf("");
-        bool live = 64 * u < t.rem;
-        if (a.is_empty) live = live && sd.hole[u] == 0u;
-        if (live) {
+        if (64 * u < t.rem) {
           if constexpr (SEL16) v[u] = (float)L::accumulate16(w[u], t.s + 64 * u, reinterpret_cast<const uint16_t*>(lut));
           else v[u] = L::accumulate(w[u], t.s + 64 * u, lut);
           if constexpr (RES) v[u] += t.add + sd.term[u];
         }
       }
+      // (this tile's loads have landed on every path: see the one-slot-per-lane loop above)
+      if constexpr (M <= 64) wait_vmcnt<kFetchLoads>();
       refresh_tau();
       if constexpr (S > 1) {
         bool any = false;
@@ -1334,8 +1351,12 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
       for (int u = 0; u < S; ++u) {
         const float tau_before = sel.tau;
         const int flushes_before = sel.n_flush;
-        if constexpr (POOL) sel.push_pool(pool, v[u] >= sel.tau - delta2, v[u], t.s + 64 * u);
-        else sel.push(v[u] >= sel.tau - delta2, v[u], t.s + 64 * u);
+        bool pass = v[u] >= sel.tau - delta2;
+        if (a.is_empty) {  // (wave-uniform)
+          if (pass) pass = a.is_empty[t.s + 64 * u] == 0;
+        }
+        if constexpr (POOL) sel.push_pool(pool, pass, v[u], t.s + 64 * u);
+        else sel.push(pass, v[u], t.s + 64 * u);
         if (sel.n_flush != flushes_before) publish(tau_before);
       }
     };
