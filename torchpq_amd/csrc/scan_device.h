@@ -1247,23 +1247,32 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
     if constexpr (M <= 64) {
       typename L::chunk_t w0[L::kChunks], w1[L::kChunks];
       Tile m0{0, false, 0.f, 0u}, m1{0, false, 0.f, 0u};
+      // TWO tiles ahead (round 6): a register set is refilled -- with the tile after next -- right behind its own
+      // look-ups, so one to two tiles of loads are in flight at every moment and the probe-table walk of a fetch uses the
+      // registers of the tile just consumed as its temporaries.  (One tile ahead -- fetch(T + NW) into the OTHER set, then
+      // consume(T) -- had the walk's temporaries land in the other set's registers at the loop header: hipcc put
+      // `s_waitcnt vmcnt(0)` in front of every other prefetch, the wave drained its loads before issuing the next ones.)
       int T = t_begin + wave;
-      if (T < t_end) fetch(T, m0, w0);  // (a wave without a tile loads nothing: slot 0 need not exist)
-#ifdef TPQ_SCAN_PROFILE
-      bool first_tile = true;
-#endif
-      while (T < t_end) {
+      if (T < t_end) {  // (a wave without a tile loads nothing: slot 0 need not exist)
+        fetch(T, m0, w0);
         fetch(T + NW, m1, w1);
-        consume(w0, m0);
 #ifdef TPQ_SCAN_PROFILE
-        if (first_tile) TPQ_PROF(a, blockIdx.x, 14);
-        first_tile = false;
+        bool first_tile = true;
 #endif
-        T += NW;
-        if (T >= t_end) break;
-        fetch(T + NW, m0, w0);
-        consume(w1, m1);
-        T += NW;
+        while (true) {
+          consume(w0, m0);
+#ifdef TPQ_SCAN_PROFILE
+          if (first_tile) TPQ_PROF(a, blockIdx.x, 14);
+          first_tile = false;
+#endif
+          fetch(T + 2 * NW, m0, w0);
+          T += NW;
+          if (T >= t_end) break;
+          consume(w1, m1);
+          fetch(T + 2 * NW, m1, w1);
+          T += NW;
+          if (T >= t_end) break;
+        }
       }
     } else {
       // One 16-wave workgroup per CU and one tile in flight per wave: with a static deal the waves
@@ -1367,16 +1376,21 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
       typename L::chunk_t w0[S][L::kChunks], w1[S][L::kChunks];
       Side r0 = {}, r1 = {};
       Tile m0{0, 0, 0.f, 0u}, m1{0, 0, 0.f, 0u};
+      // (two tiles ahead: see the one-slot-per-lane loop above)
       int T = t_begin + wave;
-      if (T < t_end) fetch(T, m0, w0, r0);  // (a wave without a tile loads nothing: slot 0 need not exist)
-      while (T < t_end) {
+      if (T < t_end) {  // (a wave without a tile loads nothing: slot 0 need not exist)
+        fetch(T, m0, w0, r0);
         fetch(T + NW, m1, w1, r1);
-        consume(w0, r0, m0);
-        T += NW;
-        if (T >= t_end) break;
-        fetch(T + NW, m0, w0, r0);
-        consume(w1, r1, m1);
-        T += NW;
+        while (true) {
+          consume(w0, r0, m0);
+          fetch(T + 2 * NW, m0, w0, r0);
+          T += NW;
+          if (T >= t_end) break;
+          consume(w1, r1, m1);
+          fetch(T + 2 * NW, m1, w1, r1);
+          T += NW;
+          if (T >= t_end) break;
+        }
       }
     } else {
       // One 16-wave workgroup per CU and one tile in flight per wave: with a static deal the waves
