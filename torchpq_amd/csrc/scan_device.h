@@ -1366,7 +1366,12 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
         }
         if constexpr (POOL) sel.push_pool(pool, pass, v[u], t.s + 64 * u);
         else sel.push(pass, v[u], t.s + 64 * u);
-        if (sel.n_flush != flushes_before) publish(tau_before);
+        if (sel.n_flush != flushes_before) {
+          publish(tau_before);
+          // (the tile's remaining slots meet the threshold the flush just raised -- the first tiles of a query admit
+          // everything, and a short list, 32 probes of 244 slots at k = 100, spends as much on its flushes as on its look-ups)
+          refresh_tau();
+        }
       }
     };
 
