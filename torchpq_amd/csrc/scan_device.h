@@ -943,8 +943,9 @@ constexpr int packed_tile_shift(int M) { return 6 + TPQ_SLOTS_LOG2; }
 // (round 6, after the look-ups of the small blocks went from 3.25 to 2 VALU: the per-tile part weighs more, and four
 // slots per lane now win from m = 12 on -- same box, S = 2 -> 4, C2 shape k = 100 / k = 1 / 244-slot cells: m = 12 +5 / +6 /
 // +2 %, 16 +7 / +9 / +7 %, 20 +8 / +6 / +4 %, 24 0 / +3 / +3 %; m = 40 -13 %, 48 -10 %, 56 -26 %: those keep theirs)
+// (m = 40: two slots per lane once the per-slot part had shrunk -- +4 % at the C2 shape, +8 % on 244-slot cells, same box)
 constexpr int packed_slots(int M) {
-  return M <= 32 ? 4 : ((M == 48 || M == 56) ? 2 : 1);
+  return M <= 32 ? 4 : ((M == 40 || M == 48 || M == 56) ? 2 : 1);
 }
 constexpr int packed_tile_shift(int M) { return packed_slots(M) == 4 ? 8 : (packed_slots(M) == 2 ? 7 : 6); }
 #endif
@@ -1018,6 +1019,13 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
   // 24 4.69 / 5.02, 32 5.88 / 5.90, 64 6.92 / 7.07)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = lane_id();
+  {
+    // scan_layout's look-up address folds the table's LDS address into lane constants that are XORed with position bits
+    // (accumulate, accumulate16): the table must start at a multiple of 128 bytes.  It does -- the dynamic allocation starts
+    // at 0 as long as this kernel declares no static __shared__ --; a build that breaks that traps instead of mis-scanning.
+    typedef const __attribute__((address_space(3))) char* lds_char_ptr;
+    if (((uint32_t)(uintptr_t)(lds_char_ptr)smem & 127u) != 0u) __builtin_trap();
+  }
   int q, part, parts;  // query, this workgroup's part of it, the parts it is dealt in
   if (DUMP && (int)blockIdx.x < a.unsplit) {  // (tail split, ScanArgs::unsplit: the leading queries are not split)
     q = (int)blockIdx.x;
@@ -1176,6 +1184,7 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
     }
   };
 
+  constexpr bool kOneAhead = R > 4 || (R >= 2 && NW == 8 && !DUMP);  // (tile loop of m <= 64: see there)
   if constexpr (packed_slots(M) == 1) {
     constexpr int kFetchLoads = L::kChunks + (RES ? 1 : 0);  // global loads of one fetch (without tombstones)
     struct Tile {
@@ -1249,11 +1258,24 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
       Tile m0{0, false, 0.f, 0u}, m1{0, false, 0.f, 0u};
       // TWO tiles ahead (round 6): a register set is refilled -- with the tile after next -- right behind its own
       // look-ups, so one to two tiles of loads are in flight at every moment and the probe-table walk of a fetch uses the
-      // registers of the tile just consumed as its temporaries.  (One tile ahead -- fetch(T + NW) into the OTHER set, then
-      // consume(T) -- had the walk's temporaries land in the other set's registers at the loop header: hipcc put
-      // `s_waitcnt vmcnt(0)` in front of every other prefetch, the wave drained its loads before issuing the next ones.)
+      // registers of the tile just consumed as its temporaries: m = 16 +5 %, 24 +4..13 %, 48 +4..7 % on the same box.
+      // (hipcc re-rotates the loop and still puts `s_waitcnt vmcnt(0)` in front of every other prefetch -- DESIGN 3.1 --,
+      // so the wave does drain once per two tiles; what the order buys is the earlier issue of the other prefetch.)
+      // (Lists of two registers and more in the eight-wave workgroups of the sorted-list path -- m > 32, k = 300 / 500 --
+      // keep the one-ahead order: two ahead cost them 4-5 % on the same box.)
       int T = t_begin + wave;
-      if (T < t_end) {  // (a wave without a tile loads nothing: slot 0 need not exist)
+      if constexpr (kOneAhead) {
+        if (T < t_end) fetch(T, m0, w0);
+        while (T < t_end) {
+          fetch(T + NW, m1, w1);
+          consume(w0, m0);
+          T += NW;
+          if (T >= t_end) break;
+          fetch(T + NW, m0, w0);
+          consume(w1, m1);
+          T += NW;
+        }
+      } else if (T < t_end) {  // (a wave without a tile loads nothing: slot 0 need not exist)
         fetch(T, m0, w0);
         fetch(T + NW, m1, w1);
 #ifdef TPQ_SCAN_PROFILE
@@ -1381,9 +1403,20 @@ __global__ __launch_bounds__(scan_waves(M, RM) * 64, 4) void scan_packed_kernel(
       typename L::chunk_t w0[S][L::kChunks], w1[S][L::kChunks];
       Side r0 = {}, r1 = {};
       Tile m0{0, 0, 0.f, 0u}, m1{0, 0, 0.f, 0u};
-      // (two tiles ahead: see the one-slot-per-lane loop above)
+      // (two tiles ahead, one ahead for long lists: see the one-slot-per-lane loop above)
       int T = t_begin + wave;
-      if (T < t_end) {  // (a wave without a tile loads nothing: slot 0 need not exist)
+      if constexpr (kOneAhead) {
+        if (T < t_end) fetch(T, m0, w0, r0);
+        while (T < t_end) {
+          fetch(T + NW, m1, w1, r1);
+          consume(w0, r0, m0);
+          T += NW;
+          if (T >= t_end) break;
+          fetch(T + NW, m0, w0, r0);
+          consume(w1, r1, m1);
+          T += NW;
+        }
+      } else if (T < t_end) {  // (a wave without a tile loads nothing: slot 0 need not exist)
         fetch(T, m0, w0, r0);
         fetch(T + NW, m1, w1, r1);
         while (true) {
