@@ -64,17 +64,21 @@ __device__ __forceinline__ Key readlane_key(Key k, int l) {
 //   J = 1, 2: DPP quad_perm; J = 4: row_half_mirror o quad_perm(3,2,1,0) (i^7 then ^3);
 //   J = 8: DPP row_ror:8; J = 16: ds_swizzle bit-mask mode (xor 0x10, no address VGPR);
 //   J = 32: ds_bpermute.  (hipcc lowers __shfl_xor to ds_bpermute_b32 for every J.)
+// (The DPP moves carry NO old value -- mov_dpp, bound_ctrl set: every lane of these permutations has a source lane inside
+// its row, and the networks run with all 64 lanes active.  Written as update_dpp(x, x, ...) the destination was tied to x
+// and hipcc copied both words of the key before every exchange: 7 VALU per compare-exchange, 5 now -- a flush is 45 of
+// them, and a short list spends as much on its flushes as on its look-ups)
 template <int J>
 __device__ __forceinline__ int xor_lane_i(int x) {
   if constexpr (J == 1) {
-    return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
   } else if constexpr (J == 2) {
-    return __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
   } else if constexpr (J == 4) {
-    const int t = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false);  // row_half_mirror
-    return __builtin_amdgcn_update_dpp(t, t, 0x1B, 0xF, 0xF, false);          // quad_perm [3,2,1,0]
+    const int t = __builtin_amdgcn_mov_dpp(x, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    return __builtin_amdgcn_mov_dpp(t, 0x1B, 0xF, 0xF, true);          // quad_perm [3,2,1,0]
   } else if constexpr (J == 8) {
-    return __builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false);  // row_ror:8
+    return __builtin_amdgcn_mov_dpp(x, 0x128, 0xF, 0xF, true);  // row_ror:8
   } else if constexpr (J == 16) {
     return __builtin_amdgcn_ds_swizzle(x, 0x401F);  // and 0x1f, or 0, xor 0x10
   } else {
